@@ -1,0 +1,126 @@
+"""ctypes binding of libbltvqg_hip.so (C ABI declared in include/bltvqg_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing the import of the product path fails loudly.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbltvqg_hip.so")
+
+F32, BF16 = 0, 1
+
+P = ctypes.c_void_p
+I = ctypes.c_int
+L = ctypes.c_int64
+F = ctypes.c_float
+U64 = ctypes.c_uint64
+U32 = ctypes.c_uint32
+S = ctypes.c_char_p
+
+
+class Config(ctypes.Structure):
+    """struct bltvqg_config (include/bltvqg_hip.h)."""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("hidden_dim", ctypes.c_int32), ("pwffn_dim", ctypes.c_int32), ("latent_dim", ctypes.c_int32),
+        ("emb_dim", ctypes.c_int32), ("num_layers", ctypes.c_int32), ("num_heads", ctypes.c_int32), ("vocab_size", ctypes.c_int32),
+        ("len_context", ctypes.c_int32), ("len_posterior", ctypes.c_int32), ("len_target", ctypes.c_int32),
+        ("image_h", ctypes.c_int32), ("image_w", ctypes.c_int32), ("dtype", ctypes.c_int32),
+        ("attention_dropout", ctypes.c_float), ("relu_dropout", ctypes.c_float),
+        ("kl_ceiling", ctypes.c_float), ("aux_ceiling", ctypes.c_float), ("image_recon_lambda", ctypes.c_float),
+    ]
+
+
+# name -> (restype, argtypes) ; must list every function the header declares (tests/test_abi.py checks this)
+SIGNATURES = {
+    "bltvqg_version": (I, []),
+    "bltvqg_last_error_string": (S, []),
+    "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, P]),
+    "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
+    "bltvqg_conv2d_stat_rows": (I, [I, I, I, I, I, I, I, I]),
+    "bltvqg_img_pack": (I, [I, P, P, I, I, I, I, I, P]),
+    "bltvqg_conv_pack_w": (I, [I, P, P, I, I, I, I, I, P]),
+    "bltvqg_layernorm_fwd": (I, [I, P, P, P, P, P, P, L, I, F, P]),
+    "bltvqg_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, L, I, P]),
+    "bltvqg_bn_scratch_doubles": (I, [I]),
+    "bltvqg_bn_finalize": (I, [P, P, I, I, L, P, P, F, F, P, P, P, P, P, P]),
+    "bltvqg_bn_apply": (I, [I, P, P, P, P, P, L, I, I, P]),
+    "bltvqg_bn_relu_maxpool": (I, [I, P, P, P, P, I, I, I, I, P]),
+    "bltvqg_avgpool": (I, [I, P, P, I, I, I, P]),
+    "bltvqg_bn1d_fwd": (I, [I, P, P, P, P, P, P, P, P, I, I, F, F, P]),
+    "bltvqg_bn1d_bwd": (I, [I, P, P, P, P, P, P, P, P, I, I, P]),
+    "bltvqg_attn_fwd": (I, [I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
+    "bltvqg_attn_bwd": (I, [I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
+    "bltvqg_embed_gather": (I, [I, P, P, P, L, I, I, P]),
+    "bltvqg_embed_scatter": (I, [I, P, I, P, P, L, I, I, P]),
+    "bltvqg_ce_fwd_bwd": (I, [I, P, I, P, L, I, P, F, P, I, P]),
+    "bltvqg_bow_ce_fwd_bwd": (I, [I, P, I, P, I, I, I, P, F, P, P, P]),
+    "bltvqg_mse_fwd_bwd": (I, [I, P, P, L, F, P, P, P, P]),
+    "bltvqg_latent_fwd": (I, [I, P, P, P, P, P, I, I, I, P]),
+    "bltvqg_latent_bwd": (I, [I, P, P, P, P, F, P, P, I, I, I, P]),
+    "bltvqg_sumsq": (I, [P, L, P, P]),
+    "bltvqg_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, I, P]),
+    "bltvqg_dropout_mask": (I, [U64, U32, L, I, I, F, P, P]),
+    "bltvqg_cast": (I, [I, P, I, I, P, I, L, I, P]),
+    "bltvqg_engine_create": (P, [ctypes.POINTER(Config)]),
+    "bltvqg_engine_destroy": (None, [P]),
+    "bltvqg_engine_num_params": (I, [P, I]),
+    "bltvqg_engine_param_info": (I, [P, I, I, ctypes.c_char_p, I, ctypes.POINTER(L), ctypes.POINTER(L),
+                                     ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "bltvqg_engine_flat_size": (L, [P, I]),
+    "bltvqg_engine_late_offset": (L, [P]),
+    "bltvqg_engine_workspace_bytes": (L, [P]),
+    "bltvqg_engine_bind": (I, [P, P, P, P, P, P, P, L]),
+    "bltvqg_engine_invalidate_frozen": (None, [P]),
+    "bltvqg_engine_forward": (I, [P, P, P, P, P, P, I, U64, P]),
+    "bltvqg_engine_loss_backward": (I, [P, F, P]),
+    "bltvqg_engine_backward_external": (I, [P, P, P, F, P, P, P]),
+    "bltvqg_engine_optimizer_step": (I, [P, F, F, F, F, F, P]),
+    "bltvqg_engine_read": (I, [P, I, P, P]),
+    "bltvqg_engine_dropout_stream_id": (U32, [I, I, I]),
+    "bltvqg_engine_num_buckets": (I, [P]),
+    "bltvqg_engine_bucket_info": (I, [P, I, ctypes.POINTER(L), ctypes.POINTER(L), ctypes.POINTER(ctypes.c_int32)]),
+    "bltvqg_engine_bucket_wait": (I, [P, I, P]),
+}
+
+_lib = None
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once).  Raises if it has not been built — there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `make -C blt-vqg_amd/csrc` (or __graft_entry__.build()). "
+            "The BLT-VQG hot path has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().bltvqg_last_error_string()
+        raise HipError("%s failed (%d): %s" % (what or "libbltvqg_hip call", rc, (msg or b"").decode("utf-8", "replace")))
+
+
+def ptr(t):
+    """Device (or host) pointer of a tensor, None -> NULL."""
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,139 @@
+// extern "C" operator-level entry points (see include/bltvqg_hip.h): thin argument marshalling over kernels.h.
+#include "kernels.h"
+#include "../../include/bltvqg_hip.h"
+
+static inline int ilog2i(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+extern "C" {
+
+int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, int ldb, int transB, void* C, int ldc, int M, int N, int K,
+                const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id, const void* maskY, int ldm, float mask_scale,
+                const void* R, int ldr, int accumulate, int out_f32, int force_tile, void* stream) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.transA = transA; g.B = B; g.ldb = ldb; g.transB = transB; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id; g.maskY = maskY; g.ldm = ldm;
+    g.mask_scale = mask_scale; g.R = R; g.ldr = ldr; g.accumulate = accumulate; g.out_f32 = out_f32; g.force_tile = force_tile;
+    return blt_gemm(dtype, g, (hipStream_t)stream);
+}
+
+static GemmArgs conv_args(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad) {
+    GemmArgs g;
+    const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;
+    g.A = x; g.B = w; g.C = y;
+    g.M = N * Ho * Wo; g.N = Cout; g.K = KH * KW * Cin;
+    g.lda = Cin; g.ldb = g.K; g.ldc = Cout; g.is_conv = 1;
+    g.cg.Hi = Hi; g.cg.Wi = Wi; g.cg.Cin = Cin; g.cg.cin_log2 = ilog2i(Cin); g.cg.Ho = Ho; g.cg.Wo = Wo; g.cg.KH = KH; g.cg.KW = KW;
+    g.cg.stride = stride; g.cg.pad = pad;
+    return g;
+}
+
+int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride,
+                  int pad, float* stat_sum, float* stat_sq, void* stream) {
+    BLT_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "conv2d: bad sizes");
+    BLT_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv2d: stat_sum and stat_sq go together");
+    GemmArgs g = conv_args(x, w, y, N, Hi, Wi, Cin, Cout, KH, KW, stride, pad);
+    g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+    return blt_gemm(dtype, g, (hipStream_t)stream);
+}
+
+int bltvqg_conv2d_stat_rows(int N, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad) {
+    GemmArgs g = conv_args(nullptr, nullptr, nullptr, N, Hi, Wi, 8, Cout, KH, KW, stride, pad);
+    return blt_gemm_stat_rows(g);
+}
+
+int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, void* stream) {
+    return blt_img_pack(dtype, nchw, nhwc, N, C, H, W, Cpad, (hipStream_t)stream);
+}
+int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, void* stream) {
+    return blt_conv_pack_w(dtype, w, out, Cout, Cin, KH, KW, Cpad, (hipStream_t)stream);
+}
+
+int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,
+                         int cols, float eps, void* stream) {
+    return blt_layernorm_fwd(dtype, x, gamma, beta, y, mean, rstd, (long)rows, cols, eps, (hipStream_t)stream);
+}
+int bltvqg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, const void* dres,
+                         void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, void* stream) {
+    return blt_layernorm_bwd(dtype, dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, (long)rows, cols, (hipStream_t)stream);
+}
+
+int bltvqg_bn_scratch_doubles(int C) { return blt_bn_scratch_doubles(C); }
+int bltvqg_bn_finalize(const float* psum, const float* psq, int nparts, int C, int64_t count, const float* gamma, const float* beta, float eps,
+                       float momentum, float* running_mean, float* running_var, float* scale, float* shift, double* scratch, void* stream) {
+    return blt_bn_finalize(psum, psq, nparts, C, (long)count, gamma, beta, eps, momentum, running_mean, running_var, scale, shift, nullptr,
+                           nullptr, scratch, (hipStream_t)stream);
+}
+int bltvqg_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t rows, int C, int relu,
+                    void* stream) {
+    return blt_bn_apply(dtype, x, scale, shift, res, y, (long)rows, C, relu, (hipStream_t)stream);
+}
+int bltvqg_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi, int C, void* stream) {
+    return blt_bn_relu_maxpool(dtype, x, scale, shift, y, N, Hi, Wi, C, (hipStream_t)stream);
+}
+int bltvqg_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, void* stream) {
+    return blt_avgpool(dtype, x, y, N, HW, C, (hipStream_t)stream);
+}
+int bltvqg_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean,
+                    float* running_var, int B, int C, float eps, float momentum, void* stream) {
+    return blt_bn1d_fwd(dtype, x, gamma, beta, y, mean, rstd, running_mean, running_var, B, C, eps, momentum, (hipStream_t)stream);
+}
+int bltvqg_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx, float* dgamma,
+                    float* dbeta, int B, int C, void* stream) {
+    return blt_bn1d_bwd(dtype, dy, x, gamma, mean, rstd, dx, dgamma, dbeta, B, C, (hipStream_t)stream);
+}
+
+int bltvqg_attn_fwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, const int32_t* key_ids,
+                    int B, int heads, int Tq, int Tk, int d, int causal, float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnArgs a;
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.key_ids = key_ids; a.B = B; a.heads = heads;
+    a.Tq = Tq; a.Tk = Tk; a.d = d; a.causal = causal; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.stream_id = stream_id;
+    return blt_attn_fwd(dtype, a, (hipStream_t)stream);
+}
+int bltvqg_attn_bwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo, void* dQ, int lddq,
+                    void* dK, int lddk, void* dV, int lddv, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal, float scale,
+                    float drop_p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnArgs a;
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.key_ids = key_ids; a.B = B; a.heads = heads;
+    a.Tq = Tq; a.Tk = Tk; a.d = d; a.causal = causal; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.stream_id = stream_id;
+    a.dO = dO; a.lddo = lddo; a.dQ = dQ; a.lddq = lddq; a.dK = dK; a.lddk = lddk; a.dV = dV; a.lddv = lddv;
+    return blt_attn_bwd(dtype, a, (hipStream_t)stream);
+}
+
+int bltvqg_embed_gather(int dtype, const float* table, const int32_t* ids, void* out, int64_t rows, int E, int ld, void* stream) {
+    return blt_embed_gather(dtype, table, ids, out, (long)rows, E, ld, (hipStream_t)stream);
+}
+int bltvqg_embed_scatter(int dtype, const void* d, int ld, const int32_t* ids, float* dtable, int64_t rows, int E, int pad_id, void* stream) {
+    return blt_embed_scatter(dtype, d, ld, ids, dtable, (long)rows, E, pad_id, (hipStream_t)stream);
+}
+int bltvqg_ce_fwd_bwd(int dtype, void* logits, int ld, const int32_t* target, int64_t M, int V, const float* count, float gscale, float* loss_out,
+                      int write_grad, void* stream) {
+    return blt_ce_fwd_bwd(dtype, logits, ld, target, (long)M, V, count, gscale, loss_out, write_grad, (hipStream_t)stream);
+}
+int bltvqg_bow_ce_fwd_bwd(int dtype, const void* zlogit, int ld, const int32_t* target, int B, int T, int V, const float* count, float gscale,
+                          float* loss_out, void* dz, void* stream) {
+    return blt_bow_ce_fwd_bwd(dtype, zlogit, ld, target, B, T, V, count, gscale, loss_out, dz, (hipStream_t)stream);
+}
+int bltvqg_mse_fwd_bwd(int dtype, const void* a, const void* b, int64_t n, float gscale, float* loss_out, void* da, void* db, void* stream) {
+    return blt_mse_fwd_bwd(dtype, a, b, (long)n, gscale, loss_out, da, db, (hipStream_t)stream);
+}
+int bltvqg_latent_fwd(int dtype, const void* mlv_prior, const void* mlv_post, const float* eps, void* z, float* kld_out, int B, int Z, int ld,
+                      void* stream) {
+    return blt_latent_fwd(dtype, mlv_prior, mlv_post, eps, z, kld_out, B, Z, ld, (hipStream_t)stream);
+}
+int bltvqg_latent_bwd(int dtype, const void* mlv_prior, const void* mlv_post, const float* eps, const void* dz, float kld_gscale, void* dmlv_prior,
+                      void* dmlv_post, int B, int Z, int ld, void* stream) {
+    return blt_latent_bwd(dtype, mlv_prior, mlv_post, eps, dz, kld_gscale, dmlv_prior, dmlv_post, B, Z, ld, (hipStream_t)stream);
+}
+int bltvqg_sumsq(const float* x, int64_t n, float* out, void* stream) { return blt_sumsq(x, (long)n, out, (hipStream_t)stream); }
+int bltvqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq, float max_norm, float lr, float beta1,
+                     float beta2, float eps, int step, void* stream) {
+    return blt_adam_step(p, g, m, v, (long)n, gnorm_sq, max_norm, lr, beta1, beta2, eps, step, (hipStream_t)stream);
+}
+int bltvqg_dropout_mask(uint64_t seed, uint32_t stream_id, int64_t rows, int cols, int ld_index, float p, uint8_t* out, void* stream) {
+    return blt_dropout_mask(seed, stream_id, (long)rows, cols, ld_index, p, out, (hipStream_t)stream);
+}
+int bltvqg_cast(int dtype_src, const void* src, int ld_src, int dtype_dst, void* dst, int ld_dst, int64_t rows, int cols, void* stream) {
+    return blt_cast_rows(dtype_src, src, ld_src, dtype_dst, dst, ld_dst, (long)rows, cols, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,956 @@
+// Train-step engine: the whole IQ forward / loss / backward / optimiser step as a fixed sequence of HIP kernel launches
+// on one stream (static shapes: B, S_a, S_p, T are fixed per engine, so the sequence can be captured into a hipGraph).
+// No autograd tape: the backward sequence is written by hand against the saved activations in the workspace arena.
+//
+// Mirrors (reference file:line): models/iq.py:82-114 (IQ.forward), models/encoder_cnn.py:30-35,
+// models/encoder_transformer.py:22-37, models/decoder_transformer.py:22-41, models/transformer_layers.py:41-59,138-152,
+// 205-221,260-282,326-364,400-408,486-532, models/mlp.py:49-56, train_iq.py:81-103 (losses), 259-261,372 (Adam, clip).
+#include <map>
+#include <string>
+#include <vector>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include "kernels.h"
+#include "../../include/bltvqg_hip.h"
+
+namespace {
+
+struct PInfo {
+    std::string name;
+    int64_t off = 0, numel = 0;
+    int dims[4] = {0, 0, 0, 0};
+    int ndim = 0;
+    int late = 0;
+};
+
+struct ConvSpec {
+    std::string wname, bnname;
+    int Cin, CinPad, Cout, K, stride, pad, Hi, Wi, Ho, Wo;
+    void* wpacked = nullptr;
+    float *scale = nullptr, *shift = nullptr;
+    void* out = nullptr;   // raw conv output / in-place BN result [B,Ho,Wo,Cout]
+};
+
+struct Layer {   // saved activations of one transformer layer
+    void *xn1, *qkv, *ctx, *x1, *xn2, *h, *y2, *x2;
+    float *m1, *r1, *m2, *r2;
+    // decoder only
+    void *q2, *kv2, *ctx2, *x1b, *xn3;
+    float *m3, *r3;
+};
+
+struct Stack {
+    std::string prefix;   // e.g. "answer_encoder.encoder"
+    bool dec = false;
+    int id = 0;           // dropout stream namespace
+    int S = 0, M = 0;
+    const int* key_ids = nullptr;
+    void* x_in = nullptr;
+    std::vector<Layer> layers;
+    void* out = nullptr;
+    float *mF = nullptr, *rF = nullptr;
+};
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+inline int ilog2(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
+
+}  // namespace
+
+struct bltvqg_engine {
+    bltvqg_config c;
+    int dt, es;                 // dtype, element size
+    int B, H, F, Z, E, L, NH, V, Sa, Sp, T;
+    int Ma, Mp, Mt, Mtot, Epad, ldV, dh;
+    std::vector<PInfo> tp, fp;
+    std::map<std::string, int> ti, fi;
+    int64_t tsize = 0, late_off = 0, fsize = 0, ws_bytes = 0;
+    // bound memory
+    float *train = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr, *frozen = nullptr;
+    char* ws = nullptr;
+    bool bound = false, frozen_dirty = true, fwd_done = false;
+    int phase2 = 0;
+    uint64_t seed = 0;
+    int step_main = 0, step_late = 0;
+    int last_bwd_phase2 = 0;
+    // workspace buffers
+    void* wshadow = nullptr;    // bf16 mirror of the flat trainable buffer (bf16 mode)
+    void* wemb_pad = nullptr;   // padded shadow of embedding.1.weight when E % chunk != 0
+    int ld_wemb = 0;
+    float* timing = nullptr;
+    int *ids_all, *pos_all, *tgt_shift, *tgt32, *ctx32, *post32;
+    float* counters;
+    float* stats;               // 8 floats
+    void *img, *pool0, *pooled, *featpre, *feats;
+    float *bn1_mean, *bn1_rstd;
+    std::vector<ConvSpec> convs;
+    float *stat_sum, *stat_sq;
+    double* stat_tmp;
+    void *emb_rows, *X_all;
+    Stack enc, renc, dec;
+    void *mlvp_h1, *mlvp_h2, *mlvp, *cat_in, *mlvq_h1, *mlvq_h2, *mlvq, *zlat, *zproj, *zc_in, *zlogit, *logits;
+    void *r_in, *hrec, *recon;
+    float* eps_dev;
+    // gradient scratch
+    void *gA, *gB, *gC, *gF, *gQKV, *gKV, *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
+    void *g_b1, *g_b2, *g_b3, *g_b4, *g_cat, *g_mq;   // small [B, *] scratch
+    hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+    int64_t bucket_off[3], bucket_len[3];
+    int bucket_late[3];
+
+    // ---------------------------------------------------------------------------------------------
+    void add_t(const std::string& n, int r, int cdim, int late) {
+        PInfo p;
+        p.name = n; p.late = late;
+        p.ndim = cdim ? 2 : 1;
+        p.dims[0] = r; p.dims[1] = cdim;
+        p.numel = (int64_t)r * (cdim ? cdim : 1);
+        p.off = tsize;
+        tsize += (p.numel + 3) / 4 * 4;
+        ti[n] = (int)tp.size();
+        tp.push_back(p);
+    }
+    void add_f(const std::string& n, int d0, int d1, int d2, int d3, int ndim) {
+        PInfo p;
+        p.name = n; p.ndim = ndim;
+        p.dims[0] = d0; p.dims[1] = d1; p.dims[2] = d2; p.dims[3] = d3;
+        p.numel = (int64_t)d0 * (ndim > 1 ? d1 : 1) * (ndim > 2 ? d2 : 1) * (ndim > 3 ? d3 : 1);
+        p.off = fsize;
+        fsize += (p.numel + 3) / 4 * 4;
+        fi[n] = (int)fp.size();
+        fp.push_back(p);
+    }
+    void add_mha(const std::string& pre, int late) {
+        add_t(pre + "query_linear.weight", H, H, late);
+        add_t(pre + "key_linear.weight", H, H, late);
+        add_t(pre + "value_linear.weight", H, H, late);
+        add_t(pre + "output_linear.weight", H, H, late);
+    }
+    void add_ffn(const std::string& pre, int late) {
+        add_t(pre + "layers.0.weight", F, H, late);
+        add_t(pre + "layers.0.bias", F, 0, late);
+        add_t(pre + "layers.1.weight", H, F, late);
+        add_t(pre + "layers.1.bias", H, 0, late);
+    }
+    void add_ln(const std::string& pre, int late) {
+        add_t(pre + ".weight", H, 0, late);
+        add_t(pre + ".bias", H, 0, late);
+    }
+    void add_enc_stack(const std::string& pre, int late) {
+        add_ln(pre + ".layer_norm", late);
+        for (int l = L - 1; l >= 0; --l) {
+            const std::string lp = pre + ".enc." + std::to_string(l) + ".";
+            add_mha(lp + "multi_head_attention.", late);
+            add_ffn(lp + "positionwise_feed_forward.", late);
+            add_ln(lp + "layer_norm_mha", late);
+            add_ln(lp + "layer_norm_ffn", late);
+        }
+    }
+
+    void build_params() {
+        // ---- trainable, in the order backward completes them (gradient buckets are prefixes of this order) ----
+        add_t("decoder.output.weight", V, H, 0);
+        add_t("decoder.output.bias", V, 0, 0);
+        add_ln("decoder.decoder.layer_norm", 0);
+        for (int l = L - 1; l >= 0; --l) {
+            const std::string lp = "decoder.decoder.dec." + std::to_string(l) + ".";
+            add_mha(lp + "multi_head_attention_dec.", 0);
+            add_mha(lp + "multi_head_attention_enc_dec.", 0);
+            add_ffn(lp + "positionwise_feed_forward.", 0);
+            add_ln(lp + "layer_norm_mha_dec", 0);
+            add_ln(lp + "layer_norm_mha_enc", 0);
+            add_ln(lp + "layer_norm_ffn", 0);
+        }
+        bucket_off[0] = 0; bucket_len[0] = tsize; bucket_late[0] = 0;
+        add_t("image_reconstructor.layers.fc0.weight", F, H, 0);
+        add_t("image_reconstructor.layers.fc0.bias", F, 0, 0);
+        add_t("image_reconstructor.layers.fc1.weight", H, F, 0);
+        add_t("image_reconstructor.layers.fc1.bias", H, 0, 0);
+        add_enc_stack("answer_encoder.encoder", 0);
+        add_t("embedding.1.weight", H, E, 0);
+        add_t("embedding.1.bias", H, 0, 0);
+        add_t("embedding.0.weight", V, E, 0);
+        add_t("encoder_cnn.cnn.fc.weight", H, 512, 0);
+        add_t("encoder_cnn.cnn.fc.bias", H, 0, 0);
+        add_t("encoder_cnn.bn.weight", H, 0, 0);
+        add_t("encoder_cnn.bn.bias", H, 0, 0);
+        bucket_off[1] = bucket_len[0]; bucket_len[1] = tsize - bucket_len[0]; bucket_late[1] = 0;
+        late_off = tsize;
+        add_t("decoder.z_classifier.weight", V, H, 1);
+        add_t("decoder.z_classifier.bias", V, 0, 1);
+        add_t("latent_projection.weight", H, Z, 1);
+        add_t("latent_projection.bias", H, 0, 1);
+        const char* nets[2] = {"latent_layer.mean_logvar_posterior", "latent_layer.mean_logvar_prior"};
+        for (int n = 0; n < 2; ++n) {
+            const int din = (n == 0) ? 2 * H : H;
+            add_t(std::string(nets[n]) + ".0.weight", 2 * Z, din, 1);
+            add_t(std::string(nets[n]) + ".0.bias", 2 * Z, 0, 1);
+            add_t(std::string(nets[n]) + ".3.weight", 2 * Z, 2 * Z, 1);
+            add_t(std::string(nets[n]) + ".3.bias", 2 * Z, 0, 1);
+            add_t(std::string(nets[n]) + ".6.weight", 2 * Z, 2 * Z, 1);
+            add_t(std::string(nets[n]) + ".6.bias", 2 * Z, 0, 1);
+        }
+        add_enc_stack("answer_encoder.r_encoder", 1);
+        bucket_off[2] = late_off; bucket_len[2] = tsize - late_off; bucket_late[2] = 1;
+
+        // ---- frozen backbone (torchvision resnet18 names, encoder_cnn.py:17) + running statistics ----
+        auto add_bn = [&](const std::string& n, int C) {
+            add_f(n + ".weight", C, 0, 0, 0, 1);
+            add_f(n + ".bias", C, 0, 0, 0, 1);
+            add_f(n + ".running_mean", C, 0, 0, 0, 1);
+            add_f(n + ".running_var", C, 0, 0, 0, 1);
+        };
+        const std::string R = "encoder_cnn.cnn.";
+        int hi = c.image_h, wi = c.image_w;
+        auto add_conv = [&](const std::string& wn, const std::string& bn, int cin, int cout, int k, int s, int p, int h, int w) {
+            add_f(wn, cout, cin, k, k, 4);
+            add_bn(bn, cout);
+            ConvSpec cs;
+            cs.wname = wn; cs.bnname = bn; cs.Cin = cin; cs.CinPad = cin < 8 ? 8 : cin; cs.Cout = cout; cs.K = k;
+            cs.stride = s; cs.pad = p; cs.Hi = h; cs.Wi = w;
+            cs.Ho = (h + 2 * p - k) / s + 1;
+            cs.Wo = (w + 2 * p - k) / s + 1;
+            convs.push_back(cs);
+        };
+        add_conv(R + "conv1.weight", R + "bn1", 3, 64, 7, 2, 3, hi, wi);
+        hi = convs.back().Ho; wi = convs.back().Wo;
+        hi = (hi + 2 - 3) / 2 + 1; wi = (wi + 2 - 3) / 2 + 1;   // maxpool 3x3/2 pad 1
+        int cin = 64;
+        const int couts[4] = {64, 128, 256, 512};
+        for (int li = 0; li < 4; ++li)
+            for (int b = 0; b < 2; ++b) {
+                const int cout = couts[li];
+                const int s = (li > 0 && b == 0) ? 2 : 1;
+                const std::string bp = R + "layer" + std::to_string(li + 1) + "." + std::to_string(b) + ".";
+                add_conv(bp + "conv1.weight", bp + "bn1", cin, cout, 3, s, 1, hi, wi);
+                const int ho = convs.back().Ho, wo = convs.back().Wo;
+                add_conv(bp + "conv2.weight", bp + "bn2", cout, cout, 3, 1, 1, ho, wo);
+                if (s != 1 || cin != cout) add_conv(bp + "downsample.0.weight", bp + "downsample.1", cin, cout, 1, s, 0, hi, wi);
+                hi = ho; wi = wo; cin = cout;
+            }
+        add_f("encoder_cnn.bn.running_mean", H, 0, 0, 0, 1);
+        add_f("encoder_cnn.bn.running_var", H, 0, 0, 0, 1);
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // workspace layout: called once with base = nullptr (sizes) and once at bind (pointers)
+    // ---------------------------------------------------------------------------------------------
+    int64_t layout(char* base) {
+        int64_t off = 0;
+        auto A = [&](int64_t bytes) -> void* {
+            char* p = base + off;
+            off += (bytes + 255) / 256 * 256;
+            return (void*)p;
+        };
+        auto AT = [&](int64_t elems) -> void* { return A(elems * es); };
+        auto AF = [&](int64_t n) -> float* { return (float*)A(n * 4); };
+        auto AI = [&](int64_t n) -> int* { return (int*)A(n * 4); };
+        wshadow = (dt == BLT_BF16) ? A(tsize * 2) : nullptr;
+        const int ce = 16 / es;
+        ld_wemb = round_up(E, ce);
+        wemb_pad = (E % ce != 0) ? AT((int64_t)H * ld_wemb) : nullptr;
+        timing = AF((int64_t)64 * H);
+        ids_all = AI(Mtot); pos_all = AI(Mtot); tgt_shift = AI(Mt); tgt32 = AI(Mt); ctx32 = AI(Ma); post32 = AI(Mp);
+        counters = AF(1 + B);
+        stats = AF(8);
+        eps_dev = AF((int64_t)B * Z);
+        // CNN
+        img = AT((int64_t)B * c.image_h * c.image_w * 8);
+        int64_t max_stat = 0;
+        for (auto& cs : convs) {
+            cs.wpacked = AT((int64_t)cs.Cout * cs.K * cs.K * cs.CinPad);
+            cs.scale = AF(cs.Cout); cs.shift = AF(cs.Cout);
+            cs.out = AT((int64_t)B * cs.Ho * cs.Wo * cs.Cout);
+            const int64_t M = (int64_t)B * cs.Ho * cs.Wo;
+            const int64_t rows = 2 * ((M + 63) / 64);   // upper bound for either tile size
+            if (rows * cs.Cout > max_stat) max_stat = rows * cs.Cout;
+        }
+        stat_sum = AF(max_stat); stat_sq = AF(max_stat);
+        stat_tmp = (double*)A((int64_t)blt_bn_scratch_doubles(512) * 8);
+        {
+            const int ph = (convs[0].Ho + 2 - 3) / 2 + 1, pw = (convs[0].Wo + 2 - 3) / 2 + 1;
+            pool0 = AT((int64_t)B * ph * pw * 64);
+        }
+        pooled = AT((int64_t)B * 512);
+        featpre = AT((int64_t)B * H); feats = AT((int64_t)B * H);
+        bn1_mean = AF(H); bn1_rstd = AF(H);
+        // embedding
+        emb_rows = AT((int64_t)Mtot * Epad);
+        X_all = AT((int64_t)Mtot * H);
+        auto lay_stack = [&](Stack& s) {
+            s.layers.resize(L);
+            for (int l = 0; l < L; ++l) {
+                Layer& y = s.layers[l];
+                const int64_t M = s.M;
+                y.xn1 = AT(M * H); y.qkv = AT(M * 3 * H); y.ctx = AT(M * H); y.x1 = AT(M * H); y.xn2 = AT(M * H);
+                y.h = AT(M * F); y.y2 = AT(M * H); y.x2 = AT(M * H);
+                y.m1 = AF(M); y.r1 = AF(M); y.m2 = AF(M); y.r2 = AF(M);
+                if (s.dec) {
+                    y.q2 = AT(M * H); y.kv2 = AT((int64_t)Ma * 2 * H); y.ctx2 = AT(M * H); y.x1b = AT(M * H); y.xn3 = AT(M * H);
+                    y.m3 = AF(M); y.r3 = AF(M);
+                }
+            }
+            s.out = AT((int64_t)s.M * H);
+            s.mF = AF(s.M); s.rF = AF(s.M);
+        };
+        lay_stack(enc); lay_stack(renc); lay_stack(dec);
+        mlvp_h1 = AT((int64_t)B * 2 * Z); mlvp_h2 = AT((int64_t)B * 2 * Z); mlvp = AT((int64_t)B * 2 * Z);
+        cat_in = AT((int64_t)B * 2 * H);
+        mlvq_h1 = AT((int64_t)B * 2 * Z); mlvq_h2 = AT((int64_t)B * 2 * Z); mlvq = AT((int64_t)B * 2 * Z);
+        zlat = AT((int64_t)B * Z); zproj = AT((int64_t)B * H); zc_in = AT((int64_t)B * H);
+        zlogit = AT((int64_t)B * ldV);
+        logits = AT((int64_t)Mt * ldV);
+        r_in = AT((int64_t)B * H); hrec = AT((int64_t)B * F); recon = AT((int64_t)B * H);
+        // gradient scratch
+        const int64_t Mmax = (Mp > Mt ? Mp : Mt);
+        gA = AT(Mmax * H); gB = AT(Mmax * H); gC = AT(Mmax * H); gF = AT(Mmax * F); gQKV = AT(Mmax * 3 * H);
+        gKV = AT((int64_t)Ma * 2 * H);
+        d_enc = AT((int64_t)Ma * H); d_renc = AT((int64_t)Mp * H);
+        dX_all = AT((int64_t)Mtot * H); dE = AT((int64_t)Mtot * Epad);
+        d_feats = AT((int64_t)B * H); d_zproj = AT((int64_t)B * H); d_recon = AT((int64_t)B * H); dzl = AT((int64_t)B * ldV);
+        const int64_t wide = (int64_t)B * (2 * Z > F ? 2 * Z : F);
+        g_b1 = AT(wide); g_b2 = AT(wide); g_b3 = AT(wide); g_b4 = AT(wide); g_cat = AT((int64_t)B * 2 * H); g_mq = AT((int64_t)B * 2 * Z);
+        return off;
+    }
+
+    explicit bltvqg_engine(const bltvqg_config& cfg) : c(cfg) {
+        dt = c.dtype; es = (dt == BLT_BF16) ? 2 : 4;
+        B = c.batch; H = c.hidden_dim; F = c.pwffn_dim; Z = c.latent_dim; E = c.emb_dim; L = c.num_layers; NH = c.num_heads;
+        V = c.vocab_size; Sa = c.len_context; Sp = c.len_posterior; T = c.len_target;
+        Ma = B * Sa; Mp = B * Sp; Mt = B * T; Mtot = Ma + Mt + Mp;
+        Epad = round_up(E, 32); ldV = round_up(V, 8); dh = H / NH;
+        build_params();
+        enc.prefix = "answer_encoder.encoder"; enc.id = 0; enc.S = Sa; enc.M = Ma;
+        renc.prefix = "answer_encoder.r_encoder"; renc.id = 1; renc.S = Sp; renc.M = Mp;
+        dec.prefix = "decoder.decoder"; dec.id = 2; dec.S = T; dec.M = Mt; dec.dec = true;
+        ws_bytes = layout(nullptr);
+    }
+
+    // ---- parameter access ----------------------------------------------------------------------------
+    const PInfo& tpi(const std::string& n) const { return tp[ti.at(n)]; }
+    float* P(const std::string& n) const { return train + tpi(n).off; }
+    float* G(const std::string& n) const { return grad + tpi(n).off; }
+    float* FZ(const std::string& n) const { return frozen + fp[fi.at(n)].off; }
+    // GEMM-operand view of a 2-D weight (shadow in bf16 mode)
+    const void* W(const std::string& n, int* ld) const {
+        const PInfo& p = tpi(n);
+        if (n == "embedding.1.weight" && wemb_pad) { *ld = ld_wemb; return wemb_pad; }
+        *ld = p.dims[1];
+        if (dt == BLT_BF16) return (const char*)wshadow + p.off * 2;
+        return train + p.off;
+    }
+
+    // ---- GEMM helpers ----------------------------------------------------------------------------------
+    GemmArgs mk(const void* A_, int lda, int tA, const void* B_, int ldb, int tB, void* C_, int ldc, int M, int N, int K) {
+        GemmArgs g;
+        g.A = A_; g.lda = lda; g.transA = tA; g.B = B_; g.ldb = ldb; g.transB = tB; g.C = C_; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+        return g;
+    }
+    // Y[M,N] = X[M,K] W[N,K]^T (+bias)
+    GemmArgs lin(const void* X, int ldx, const std::string& wname, const char* bias, void* Y, int ldy, int M) {
+        int ldw;
+        const void* w = W(wname, &ldw);
+        const PInfo& p = tpi(wname);
+        GemmArgs g = mk(X, ldx, 0, w, ldw, 0, Y, ldy, M, p.dims[0], p.dims[1]);
+        if (bias) g.bias = P(bias);
+        return g;
+    }
+    // dX[M,K] = dY[M,N] W[N,K]
+    GemmArgs dgrad(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M) {
+        int ldw;
+        const void* w = W(wname, &ldw);
+        const PInfo& p = tpi(wname);
+        return mk(dY, ldy, 0, w, ldw, 1, dX, ldx, M, p.dims[1], p.dims[0]);
+    }
+    // dW[N,K] = dY[M,N]^T X[M,K]  (fp32, into the flat gradient buffer) ; db[N] = colsum(dY)
+    int wgrad(const void* dY, int ldy, const void* X, int ldx, const std::string& wname, const char* bias, int M, hipStream_t s) {
+        const PInfo& p = tpi(wname);
+        GemmArgs g = mk(dY, ldy, 1, X, ldx, 1, G(wname), p.dims[1], p.dims[0], p.dims[1], M);
+        g.out_f32 = 1;
+        int rc = blt_gemm(dt, g, s);
+        if (rc) return rc;
+        if (bias) rc = blt_colsum(dt, dY, ldy, M, p.dims[0], G(bias), 1, s);
+        return rc;
+    }
+
+    uint32_t sid(int stack, int layer, int site) const { return (uint32_t)(stack * 1000 + layer * 10 + site); }
+
+#define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
+
+    // ---------------------------------------------------------------------------------------------
+    // forward pieces
+    // ---------------------------------------------------------------------------------------------
+    int attn_fwd(const void* q, int ldq, const void* k, const void* v, int ldkv, void* o, const int* key_ids, int Tq, int Tk,
+                 int causal, uint32_t stream_id, hipStream_t s) {
+        AttnArgs a;
+        a.Q = q; a.ldq = ldq; a.K = k; a.V = v; a.ldk = ldkv; a.ldv = ldkv; a.O = o; a.ldo = H; a.key_ids = key_ids;
+        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh);
+        a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
+        return blt_attn_fwd(dt, a, s);
+    }
+    int attn_bwd(const void* q, int ldq, const void* k, const void* v, int ldkv, const void* dO, void* dq, int lddq, void* dk,
+                 void* dv, int lddkv, const int* key_ids, int Tq, int Tk, int causal, uint32_t stream_id, hipStream_t s) {
+        AttnArgs a;
+        a.Q = q; a.ldq = ldq; a.K = k; a.V = v; a.ldk = ldkv; a.ldv = ldkv; a.key_ids = key_ids;
+        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh);
+        a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
+        a.dO = dO; a.lddo = H; a.dQ = dq; a.lddq = lddq; a.dK = dk; a.dV = dv; a.lddk = lddkv; a.lddv = lddkv;
+        return blt_attn_bwd(dt, a, s);
+    }
+
+    int ffn_fwd(const std::string& fp_, const void* xn, const void* xres, Layer& y, int M, int stack, int l, hipStream_t s) {
+        GemmArgs g = lin(xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, F, M);
+        g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 1);
+        RC(blt_gemm(dt, g, s));
+        g = lin(y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), y.x2, H, M);
+        g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 2);
+        g.C2 = y.y2; g.ldc2 = H; g.R = xres; g.ldr = H;
+        return blt_gemm(dt, g, s);
+    }
+
+    int stack_fwd(Stack& st, const void* enc_out, const int* src_ids, hipStream_t s) {
+        const int M = st.M, S = st.S;
+        const void* x = st.x_in;
+        for (int l = 0; l < L; ++l) {
+            Layer& y = st.layers[l];
+            const std::string lp = st.prefix + (st.dec ? ".dec." : ".enc.") + std::to_string(l) + ".";
+            const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
+            const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
+            RC(blt_layernorm_fwd(dt, x, P(ln1 + ".weight"), P(ln1 + ".bias"), y.xn1, y.m1, y.r1, M, H, 1e-5f, s));
+            // fused QKV projection: query/key/value weights are adjacent in the flat buffer -> one [3H,H] operand
+            {
+                int ldw;
+                const void* w = W(a1 + "query_linear.weight", &ldw);
+                GemmArgs g = mk(y.xn1, H, 0, w, ldw, 0, y.qkv, 3 * H, M, 3 * H, H);
+                RC(blt_gemm(dt, g, s));
+            }
+            RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
+                        st.dec ? 1 : 0, sid(st.id, l, 0), s));
+            {
+                GemmArgs g = lin(y.ctx, H, a1 + "output_linear.weight", nullptr, y.x1, H, M);
+                g.R = x; g.ldr = H;
+                RC(blt_gemm(dt, g, s));
+            }
+            const void* xr = y.x1;
+            if (st.dec) {
+                const std::string a2 = lp + "multi_head_attention_enc_dec.";
+                const std::string ln2 = lp + "layer_norm_mha_enc";
+                RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
+                RC(blt_gemm(dt, lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M), s));
+                {
+                    int ldw;
+                    const void* w = W(a2 + "key_linear.weight", &ldw);
+                    RC(blt_gemm(dt, mk(enc_out, H, 0, w, ldw, 0, y.kv2, 2 * H, Ma, 2 * H, H), s));
+                }
+                RC(attn_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, src_ids, S, Sa, 0, sid(st.id, l, 3), s));
+                GemmArgs g = lin(y.ctx2, H, a2 + "output_linear.weight", nullptr, y.x1b, H, M);
+                g.R = y.x1; g.ldr = H;
+                RC(blt_gemm(dt, g, s));
+                const std::string ln3 = lp + "layer_norm_ffn";
+                RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y, M, st.id, l, s));
+            } else {
+                const std::string ln2 = lp + "layer_norm_ffn";
+                RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn2, xr, y, M, st.id, l, s));
+            }
+            x = y.x2;
+        }
+        const std::string lnf = st.prefix + ".layer_norm";
+        return blt_layernorm_fwd(dt, x, P(lnf + ".weight"), P(lnf + ".bias"), st.out, st.mF, st.rF, M, H, 1e-5f, s);
+    }
+
+    int conv_fwd(ConvSpec& cs, const void* x, hipStream_t s) {
+        GemmArgs g;
+        g.A = x; g.B = cs.wpacked; g.C = cs.out;
+        g.M = B * cs.Ho * cs.Wo; g.N = cs.Cout; g.K = cs.K * cs.K * cs.CinPad;
+        g.lda = cs.CinPad; g.ldb = g.K; g.ldc = cs.Cout;
+        g.is_conv = 1;
+        g.cg.Hi = cs.Hi; g.cg.Wi = cs.Wi; g.cg.Cin = cs.CinPad; g.cg.cin_log2 = ilog2(cs.CinPad); g.cg.Ho = cs.Ho; g.cg.Wo = cs.Wo;
+        g.cg.KH = cs.K; g.cg.KW = cs.K; g.cg.stride = cs.stride; g.cg.pad = cs.pad;
+        g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+        RC(blt_gemm(dt, g, s));
+        const int nparts = blt_gemm_stat_rows(g);
+        return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)g.M, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
+                               0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,
+                               nullptr, stat_tmp, s);
+    }
+
+    int cnn_fwd(const float* images, hipStream_t s) {
+        if (frozen_dirty) {
+            for (auto& cs : convs)
+                RC(blt_conv_pack_w(dt, FZ(cs.wname), cs.wpacked, cs.Cout, cs.Cin, cs.K, cs.K, cs.CinPad, s));
+            frozen_dirty = false;
+        }
+        RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 8, s));
+        size_t ci = 0;
+        ConvSpec& c1 = convs[ci++];
+        RC(conv_fwd(c1, img, s));
+        RC(blt_bn_relu_maxpool(dt, c1.out, c1.scale, c1.shift, pool0, B, c1.Ho, c1.Wo, 64, s));
+        const void* x = pool0;
+        int cin = 64;
+        const int couts[4] = {64, 128, 256, 512};
+        for (int li = 0; li < 4; ++li)
+            for (int b = 0; b < 2; ++b) {
+                const int cout = couts[li];
+                const int st = (li > 0 && b == 0) ? 2 : 1;
+                ConvSpec& ca = convs[ci++];
+                ConvSpec& cb = convs[ci++];
+                RC(conv_fwd(ca, x, s));
+                RC(blt_bn_apply(dt, ca.out, ca.scale, ca.shift, nullptr, ca.out, (long)B * ca.Ho * ca.Wo, ca.Cout, 1, s));
+                RC(conv_fwd(cb, ca.out, s));
+                const void* res = x;
+                if (st != 1 || cin != cout) {
+                    ConvSpec& cd = convs[ci++];
+                    RC(conv_fwd(cd, x, s));
+                    RC(blt_bn_apply(dt, cd.out, cd.scale, cd.shift, nullptr, cd.out, (long)B * cd.Ho * cd.Wo, cd.Cout, 0, s));
+                    res = cd.out;
+                }
+                RC(blt_bn_apply(dt, cb.out, cb.scale, cb.shift, res, cb.out, (long)B * cb.Ho * cb.Wo, cb.Cout, 1, s));
+                x = cb.out;
+                cin = cout;
+            }
+        RC(blt_avgpool(dt, x, pooled, B, convs.back().Ho * convs.back().Wo, 512, s));
+        RC(blt_gemm(dt, lin(pooled, 512, "encoder_cnn.cnn.fc.weight", "encoder_cnn.cnn.fc.bias", featpre, H, B), s));
+        return blt_bn1d_fwd(dt, featpre, P("encoder_cnn.bn.weight"), P("encoder_cnn.bn.bias"), feats, bn1_mean, bn1_rstd,
+                            FZ("encoder_cnn.bn.running_mean"), FZ("encoder_cnn.bn.running_var"), B, H, 1e-5f, 0.01f, s);
+    }
+
+    int mlp3_fwd(const std::string& net, const void* x, int din, void* h1, void* h2, void* out, hipStream_t s) {
+        GemmArgs g = lin(x, din, net + ".0.weight", (net + ".0.bias").c_str(), h1, 2 * Z, B);
+        g.relu = 1;   // the ReLU that opens the next Sequential stage is applied to the stored activation
+        RC(blt_gemm(dt, g, s));
+        g = lin(h1, 2 * Z, net + ".3.weight", (net + ".3.bias").c_str(), h2, 2 * Z, B);
+        g.relu = 1;
+        RC(blt_gemm(dt, g, s));
+        return blt_gemm(dt, lin(h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), out, 2 * Z, B), s);
+    }
+    // backward of mlp3: dout [B,2Z] -> parameter grads, dx [B,din] (written, or accumulated into dx if acc)
+    int mlp3_bwd(const std::string& net, const void* x, int din, const void* h1, const void* h2, const void* dout, void* dx, int lddx,
+                 int acc, hipStream_t s) {
+        RC(wgrad(dout, 2 * Z, h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), B, s));
+        GemmArgs g = dgrad(dout, 2 * Z, net + ".6.weight", g_b1, 2 * Z, B);
+        g.maskY = h2; g.ldm = 2 * Z; g.mask_scale = 1.f;
+        RC(blt_gemm(dt, g, s));
+        RC(wgrad(g_b1, 2 * Z, h1, 2 * Z, net + ".3.weight", (net + ".3.bias").c_str(), B, s));
+        g = dgrad(g_b1, 2 * Z, net + ".3.weight", g_b2, 2 * Z, B);
+        g.maskY = h1; g.ldm = 2 * Z; g.mask_scale = 1.f;
+        RC(blt_gemm(dt, g, s));
+        RC(wgrad(g_b2, 2 * Z, x, din, net + ".0.weight", (net + ".0.bias").c_str(), B, s));
+        g = dgrad(g_b2, 2 * Z, net + ".0.weight", dx, lddx, B);
+        g.accumulate = acc;
+        return blt_gemm(dt, g, s);
+    }
+
+    int forward(const float* images, const int64_t* ctx, const int64_t* post, const int64_t* tgt, const float* eps, int p2,
+                uint64_t seed_, hipStream_t s) {
+        BLT_REQUIRE(bound, "engine_forward: engine not bound");
+        BLT_REQUIRE(images && ctx && post && tgt, "engine_forward: null input");
+        BLT_REQUIRE(!p2 || eps, "engine_forward: eps required in phase 2");
+        phase2 = p2; seed = seed_; fwd_done = false;
+        if (hipMemsetAsync(stats, 0, 8 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
+        // weight shadows
+        if (dt == BLT_BF16) RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
+        if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
+        RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
+                           tgt32, ctx32, post32, counters, s));
+        RC(cnn_fwd(images, s));
+        // shared embedding over the three token streams at once (iq.py:72-78): gather -> Linear(E,H) + bias + timing signal
+        RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Mtot, E, Epad, s));
+        {
+            int ldw;
+            const void* w = W("embedding.1.weight", &ldw);
+            GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Mtot, H, E);
+            g.bias = P("embedding.1.bias");
+            g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
+            RC(blt_gemm(dt, g, s));
+        }
+        enc.x_in = X_all; enc.key_ids = ctx32;
+        dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = tgt_shift;
+        renc.x_in = (char*)X_all + (size_t)(Ma + Mt) * H * es; renc.key_ids = post32;
+        // the reference runs r_encoder in both phases (encoder_transformer.py:23-25)
+        RC(stack_fwd(renc, nullptr, nullptr, s));
+        RC(stack_fwd(enc, nullptr, nullptr, s));
+        RC(blt_rows_add(dt, enc.out, (long)Sa * H, feats, H, nullptr, 0, B, H, 1, s));   // encoder_outputs[:,0] += image_features
+        if (phase2) {
+            if (hipMemcpyAsync(eps_dev, eps, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                blt_set_error("engine_forward: eps copy failed");
+                return BLT_ERR_HIP;
+            }
+            // Latent.forward (transformer_layers.py:41-59): prior(x), posterior(cat(x_p, x))
+            RC(blt_copy2d(dt, enc.out, Sa * H, (char*)cat_in + (size_t)H * es, 2 * H, B, H, s));
+            RC(blt_copy2d(dt, renc.out, Sp * H, cat_in, 2 * H, B, H, s));
+            RC(mlp3_fwd("latent_layer.mean_logvar_prior", (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, mlvp, s));
+            RC(mlp3_fwd("latent_layer.mean_logvar_posterior", cat_in, 2 * H, mlvq_h1, mlvq_h2, mlvq, s));
+            RC(blt_latent_fwd(dt, mlvp, mlvq, eps_dev, zlat, stats + 2, B, Z, 2 * Z, s));
+            RC(blt_gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
+            // target_embedding[:,0] += image_features + z ; z_logit = z_classifier(z + image_features)
+            RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, zproj, H, B, H, 1, s));
+            RC(blt_rows_add(dt, zc_in, H, feats, H, zproj, H, B, H, 0, s));
+            RC(blt_gemm(dt, lin(zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", zlogit, ldV, B), s));
+            RC(blt_rows_add(dt, r_in, H, enc.out, (long)Sa * H, zproj, H, B, H, 0, s));
+        } else {
+            RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, nullptr, 0, B, H, 1, s));
+            RC(blt_copy2d(dt, enc.out, Sa * H, r_in, H, B, H, s));
+        }
+        RC(stack_fwd(dec, enc.out, ctx32, s));
+        RC(blt_gemm(dt, lin(dec.out, H, "decoder.output.weight", "decoder.output.bias", logits, ldV, Mt), s));
+        // image_reconstructor (mlp.py:49-56): Linear, ReLU, Dropout(0), Linear
+        {
+            GemmArgs g = lin(r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", hrec, F, B);
+            g.relu = 1;
+            RC(blt_gemm(dt, g, s));
+            RC(blt_gemm(dt, lin(hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", recon, H, B), s));
+        }
+        fwd_done = true;
+        return BLT_OK;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // backward pieces.  `dx` holds the gradient w.r.t. the layer OUTPUT on entry and w.r.t. its INPUT on exit.
+    // ---------------------------------------------------------------------------------------------
+    int ffn_bwd(const std::string& fp_, const void* xn, const void* xres, const float* m, const float* r, const std::string& ln,
+                Layer& y, void* dx, int M, hipStream_t s) {
+        const float ks = (c.relu_dropout > 0.f) ? 1.f / (1.f - c.relu_dropout) : 1.f;
+        RC(blt_mask_scale(dt, dx, y.y2, gA, (long)M * H, ks, s));
+        RC(wgrad(gA, H, y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), M, s));
+        GemmArgs g = dgrad(gA, H, fp_ + "layers.1.weight", gF, F, M);
+        g.maskY = y.h; g.ldm = F; g.mask_scale = ks;
+        RC(blt_gemm(dt, g, s));
+        RC(wgrad(gF, F, xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), M, s));
+        RC(blt_gemm(dt, dgrad(gF, F, fp_ + "layers.0.weight", gB, H, M), s));
+        return blt_layernorm_bwd(dt, gB, xres, P(ln + ".weight"), m, r, dx, dx, G(ln + ".weight"), G(ln + ".bias"), M, H, s);
+    }
+
+    int stack_bwd(Stack& st, void* dx, const void* enc_out, const int* src_ids, hipStream_t s) {
+        const int M = st.M, S = st.S;
+        for (int l = L - 1; l >= 0; --l) {
+            Layer& y = st.layers[l];
+            const void* x = (l == 0) ? st.x_in : st.layers[l - 1].x2;
+            const std::string lp = st.prefix + (st.dec ? ".dec." : ".enc.") + std::to_string(l) + ".";
+            const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
+            const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
+            if (st.dec) {
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, dx, M, s));
+                // encoder-decoder attention
+                const std::string a2 = lp + "multi_head_attention_enc_dec.";
+                RC(wgrad(dx, H, y.ctx2, H, a2 + "output_linear.weight", nullptr, M, s));
+                RC(blt_gemm(dt, dgrad(dx, H, a2 + "output_linear.weight", gA, H, M), s));
+                RC(attn_bwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, gA, gB, H, gKV, (char*)gKV + (size_t)H * es, 2 * H, src_ids, S,
+                            Sa, 0, sid(st.id, l, 3), s));
+                RC(wgrad(gB, H, y.xn2, H, a2 + "query_linear.weight", nullptr, M, s));
+                RC(blt_gemm(dt, dgrad(gB, H, a2 + "query_linear.weight", gC, H, M), s));
+                {   // key/value projections of encoder_outputs: [2H,H] fused
+                    const PInfo& pk = tpi(a2 + "key_linear.weight");
+                    GemmArgs g = mk(gKV, 2 * H, 1, enc_out, H, 1, grad + pk.off, H, 2 * H, H, Ma);
+                    g.out_f32 = 1;
+                    RC(blt_gemm(dt, g, s));
+                    int ldw;
+                    const void* w = W(a2 + "key_linear.weight", &ldw);
+                    g = mk(gKV, 2 * H, 0, w, ldw, 1, d_enc, H, Ma, H, 2 * H);
+                    g.accumulate = (l == L - 1) ? 0 : 1;
+                    RC(blt_gemm(dt, g, s));
+                }
+                const std::string ln2 = lp + "layer_norm_mha_enc";
+                RC(blt_layernorm_bwd(dt, gC, y.x1, P(ln2 + ".weight"), y.m2, y.r2, dx, dx, G(ln2 + ".weight"), G(ln2 + ".bias"), M, H, s));
+            } else {
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, dx, M, s));
+            }
+            // self attention
+            RC(wgrad(dx, H, y.ctx, H, a1 + "output_linear.weight", nullptr, M, s));
+            RC(blt_gemm(dt, dgrad(dx, H, a1 + "output_linear.weight", gA, H, M), s));
+            RC(attn_bwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, gA, gQKV, 3 * H,
+                        (char*)gQKV + (size_t)H * es, (char*)gQKV + (size_t)2 * H * es, 3 * H, st.key_ids, S, S, st.dec ? 1 : 0, sid(st.id, l, 0), s));
+            {
+                const PInfo& pq = tpi(a1 + "query_linear.weight");
+                GemmArgs g = mk(gQKV, 3 * H, 1, y.xn1, H, 1, grad + pq.off, H, 3 * H, H, M);
+                g.out_f32 = 1;
+                RC(blt_gemm(dt, g, s));
+                int ldw;
+                const void* w = W(a1 + "query_linear.weight", &ldw);
+                RC(blt_gemm(dt, mk(gQKV, 3 * H, 0, w, ldw, 1, gB, H, M, H, 3 * H), s));
+            }
+            RC(blt_layernorm_bwd(dt, gB, x, P(ln1 + ".weight"), y.m1, y.r1, dx, dx, G(ln1 + ".weight"), G(ln1 + ".bias"), M, H, s));
+        }
+        return BLT_OK;
+    }
+
+    // Everything downstream of the loss-gradient seeds: `logits` holds d(output), dzl holds d(z_logit) (phase 2),
+    // d_feats holds the direct gradient of image_features, d_recon that of the reconstruction.
+    int backward_core(float kld_g, hipStream_t s) {
+        // ---- vocabulary projection + decoder ----
+        RC(wgrad(logits, ldV, dec.out, H, "decoder.output.weight", "decoder.output.bias", Mt, s));
+        RC(blt_gemm(dt, dgrad(logits, ldV, "decoder.output.weight", gA, H, Mt), s));
+        void* dxT = (char*)dX_all + (size_t)Ma * H * es;
+        {
+            const void* xL = dec.layers[L - 1].x2;
+            RC(blt_layernorm_bwd(dt, gA, xL, P("decoder.decoder.layer_norm.weight"), dec.mF, dec.rF, nullptr, dxT,
+                                 G("decoder.decoder.layer_norm.weight"), G("decoder.decoder.layer_norm.bias"), Mt, H, s));
+        }
+        RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
+        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], s);
+        // target_embedding[:,0] += image_features (+ z)
+        RC(blt_rows_add(dt, d_feats, H, dxT, (long)T * H, nullptr, 0, B, H, 1, s));
+        if (phase2) RC(blt_rows_add(dt, d_zproj, H, dxT, (long)T * H, nullptr, 0, B, H, 0, s));
+        // ---- image reconstructor ----
+        RC(wgrad(d_recon, H, hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", B, s));
+        {
+            GemmArgs g = dgrad(d_recon, H, "image_reconstructor.layers.fc1.weight", g_b1, F, B);
+            g.maskY = hrec; g.ldm = F; g.mask_scale = 1.f;
+            RC(blt_gemm(dt, g, s));
+        }
+        RC(wgrad(g_b1, F, r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", B, s));
+        RC(blt_gemm(dt, dgrad(g_b1, F, "image_reconstructor.layers.fc0.weight", g_b2, H, B), s));   // d r_in
+        RC(blt_rows_add(dt, d_enc, (long)Sa * H, g_b2, H, nullptr, 0, B, H, 1, s));
+        if (phase2) {
+            RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
+            // ---- z_classifier ----
+            RC(wgrad(dzl, ldV, zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", B, s));
+            RC(blt_gemm(dt, dgrad(dzl, ldV, "decoder.z_classifier.weight", g_b2, H, B), s));
+            RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
+            RC(blt_rows_add(dt, d_feats, H, g_b2, H, nullptr, 0, B, H, 1, s));
+            // ---- latent projection, reparameterisation + KL, prior / posterior nets ----
+            RC(wgrad(d_zproj, H, zlat, Z, "latent_projection.weight", "latent_projection.bias", B, s));
+            RC(blt_gemm(dt, dgrad(d_zproj, H, "latent_projection.weight", g_b3, Z, B), s));   // dz
+            RC(blt_latent_bwd(dt, mlvp, mlvq, eps_dev, g_b3, kld_g, g_b4, g_mq, B, Z, 2 * Z, s));
+            // posterior net: d cat(x_p, x)
+            RC(mlp3_bwd("latent_layer.mean_logvar_posterior", cat_in, 2 * H, mlvq_h1, mlvq_h2, g_mq, g_cat, 2 * H, 0, s));
+            // prior net: d x accumulated into the x half of d cat
+            RC(mlp3_bwd("latent_layer.mean_logvar_prior", (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, g_b4,
+                        (char*)g_cat + (size_t)H * es, 2 * H, 1, s));
+            RC(blt_rows_add(dt, d_enc, (long)Sa * H, (char*)g_cat + (size_t)H * es, 2 * H, nullptr, 0, B, H, 1, s));
+        }
+        // encoder_outputs[:,0] += image_features
+        RC(blt_rows_add(dt, d_feats, H, d_enc, (long)Sa * H, nullptr, 0, B, H, 1, s));
+        // ---- context encoder ----
+        {
+            const void* xL = enc.layers[L - 1].x2;
+            RC(blt_layernorm_bwd(dt, d_enc, xL, P("answer_encoder.encoder.layer_norm.weight"), enc.mF, enc.rF, nullptr, dX_all,
+                                 G("answer_encoder.encoder.layer_norm.weight"), G("answer_encoder.encoder.layer_norm.bias"), Ma, H, s));
+        }
+        RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
+        int Memb = Ma + Mt;
+        if (phase2) {
+            // ---- posterior encoder: only row 0 of its output carries gradient (x_p = r_encoder_outputs[:,0]) ----
+            if (hipMemsetAsync(d_renc, 0, (size_t)Mp * H * es, s) != hipSuccess) { blt_set_error("backward: memset failed"); return BLT_ERR_HIP; }
+            RC(blt_rows_add(dt, d_renc, (long)Sp * H, g_cat, 2 * H, nullptr, 0, B, H, 0, s));
+            void* dxP = (char*)dX_all + (size_t)(Ma + Mt) * H * es;
+            const void* xL = renc.layers[L - 1].x2;
+            RC(blt_layernorm_bwd(dt, d_renc, xL, P("answer_encoder.r_encoder.layer_norm.weight"), renc.mF, renc.rF, nullptr, dxP,
+                                 G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s));
+            RC(stack_bwd(renc, dxP, nullptr, nullptr, s));
+            Memb = Mtot;
+        }
+        // ---- shared embedding (rows of the streams that received gradient) ----
+        {
+            const PInfo& pw = tpi("embedding.1.weight");
+            GemmArgs g = mk(dX_all, H, 1, emb_rows, Epad, 1, grad + pw.off, E, H, E, Memb);
+            g.out_f32 = 1;
+            RC(blt_gemm(dt, g, s));
+            RC(blt_colsum(dt, dX_all, H, Memb, H, G("embedding.1.bias"), 1, s));
+            int ldw;
+            const void* w = W("embedding.1.weight", &ldw);
+            RC(blt_gemm(dt, mk(dX_all, H, 0, w, ldw, 1, dE, Epad, Memb, E, H), s));
+            RC(blt_embed_scatter(dt, dE, Epad, ids_all, G("embedding.0.weight"), Memb, E, 0, s));
+        }
+        // ---- CNN head: BatchNorm1d -> fc (the backbone itself is frozen, encoder_cnn.py:18-19) ----
+        RC(blt_bn1d_bwd(dt, d_feats, featpre, P("encoder_cnn.bn.weight"), bn1_mean, bn1_rstd, g_b1, G("encoder_cnn.bn.weight"),
+                        G("encoder_cnn.bn.bias"), B, H, s));
+        RC(wgrad(g_b1, H, pooled, 512, "encoder_cnn.cnn.fc.weight", "encoder_cnn.cnn.fc.bias", B, s));
+        if (bucket_ev[1]) (void)hipEventRecord(bucket_ev[1], s);
+        if (bucket_ev[2]) (void)hipEventRecord(bucket_ev[2], s);
+        last_bwd_phase2 = phase2;
+        return BLT_OK;
+    }
+    int zero_grads(hipStream_t s) {
+        if (hipMemsetAsync(grad, 0, sizeof(float) * (size_t)tsize, s) != hipSuccess) { blt_set_error("backward: grad memset failed"); return BLT_ERR_HIP; }
+        return BLT_OK;
+    }
+
+    int loss_backward(float kl_weight, hipStream_t s) {
+        BLT_REQUIRE(bound && fwd_done, "engine_loss_backward: forward has not run");
+        RC(zero_grads(s));
+        // train_iq.py:81-103
+        RC(blt_ce_fwd_bwd(dt, logits, ldV, tgt32, Mt, V, counters, 1.f, stats + 0, 1, s));
+        RC(blt_mse_fwd_bwd(dt, feats, recon, (long)B * H, c.image_recon_lambda, stats + 1, d_feats, d_recon, s));
+        float kld_g = 0.f;
+        if (phase2) {
+            RC(blt_bow_ce_fwd_bwd(dt, zlogit, ldV, tgt32, B, T, V, counters, c.aux_ceiling, stats + 3, dzl, s));
+            kld_g = c.kl_ceiling * kl_weight;
+        }
+        return backward_core(kld_g, s);
+    }
+
+    int backward_external(const float* d_output, const float* d_zlogit, float d_kld, const float* d_feats_in, const float* d_recon_in,
+                          hipStream_t s) {
+        BLT_REQUIRE(bound && fwd_done, "engine_backward_external: forward has not run");
+        RC(zero_grads(s));
+        if (d_output) RC(blt_cast_rows(BLT_F32, d_output, V, dt, logits, ldV, Mt, V, s));
+        else if (hipMemsetAsync(logits, 0, (size_t)Mt * ldV * es, s) != hipSuccess) return BLT_ERR_HIP;
+        if (d_feats_in) RC(blt_cast_rows(BLT_F32, d_feats_in, H, dt, d_feats, H, B, H, s));
+        else if (hipMemsetAsync(d_feats, 0, (size_t)B * H * es, s) != hipSuccess) return BLT_ERR_HIP;
+        if (d_recon_in) RC(blt_cast_rows(BLT_F32, d_recon_in, H, dt, d_recon, H, B, H, s));
+        else if (hipMemsetAsync(d_recon, 0, (size_t)B * H * es, s) != hipSuccess) return BLT_ERR_HIP;
+        if (phase2) {
+            if (d_zlogit) RC(blt_cast_rows(BLT_F32, d_zlogit, V, dt, dzl, ldV, B, V, s));
+            else if (hipMemsetAsync(dzl, 0, (size_t)B * ldV * es, s) != hipSuccess) return BLT_ERR_HIP;
+        }
+        return backward_core(d_kld, s);
+    }
+
+    int optimizer_step(float lr, float max_norm, float b1, float b2, float eps, hipStream_t s) {
+        BLT_REQUIRE(bound, "engine_optimizer_step: engine not bound");
+        const int64_t n_main = late_off, n_late = tsize - late_off;
+        if (hipMemsetAsync(stats + 4, 0, sizeof(float), s) != hipSuccess) return BLT_ERR_HIP;
+        RC(blt_sumsq(grad, n_main, stats + 4, s));
+        if (last_bwd_phase2) RC(blt_sumsq(grad + late_off, n_late, stats + 4, s));
+        ++step_main;
+        RC(blt_adam_step(train, grad, adam_m, adam_v, n_main, stats + 4, max_norm, lr, b1, b2, eps, step_main, s));
+        if (last_bwd_phase2) {
+            ++step_late;
+            RC(blt_adam_step(train + late_off, grad + late_off, adam_m + late_off, adam_v + late_off, n_late, stats + 4, max_norm, lr, b1, b2,
+                             eps, step_late, s));
+        }
+        return BLT_OK;
+    }
+#undef RC
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------------------------
+extern "C" {
+
+bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
+    if (!cfg) { blt_set_error("engine_create: null config"); return nullptr; }
+    const bltvqg_config& c = *cfg;
+    if (c.batch <= 0 || c.hidden_dim <= 0 || c.hidden_dim % 8 != 0 || c.num_heads <= 0 || c.hidden_dim % c.num_heads != 0 ||
+        c.pwffn_dim % 8 != 0 || c.latent_dim % 8 != 0 || c.emb_dim <= 0 || c.num_layers <= 0 || c.vocab_size < 6 ||
+        c.len_context <= 0 || c.len_context > 64 || c.len_posterior <= 0 || c.len_posterior > 64 || c.len_target < 2 || c.len_target > 64 ||
+        c.image_h < 32 || c.image_w < 32 || (c.dtype != BLT_F32 && c.dtype != BLT_BF16) || c.hidden_dim > 2048 ||
+        c.attention_dropout < 0.f || c.attention_dropout >= 1.f || c.relu_dropout < 0.f || c.relu_dropout >= 1.f) {
+        blt_set_error("engine_create: unsupported configuration (need H,F,Z %% 8 == 0, H %% heads == 0, H <= 2048, sequence lengths <= 64, images >= 32x32)");
+        return nullptr;
+    }
+    if (c.emb_dim % 4 != 0) { blt_set_error("engine_create: emb_dim must be a multiple of 4"); return nullptr; }
+    return new bltvqg_engine(c);
+}
+
+void bltvqg_engine_destroy(bltvqg_engine* e) {
+    if (!e) return;
+    for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
+    delete e;
+}
+
+int bltvqg_engine_num_params(const bltvqg_engine* e, int which) { return e ? (int)(which == 0 ? e->tp.size() : e->fp.size()) : 0; }
+
+int bltvqg_engine_param_info(const bltvqg_engine* e, int which, int index, char* name_host, int name_cap, int64_t* offset, int64_t* numel,
+                             int32_t* dims4_host, int32_t* ndim, int32_t* late) {
+    BLT_REQUIRE(e && (which == 0 || which == 1), "engine_param_info: bad args");
+    const std::vector<PInfo>& v = which == 0 ? e->tp : e->fp;
+    BLT_REQUIRE(index >= 0 && index < (int)v.size(), "engine_param_info: index %d out of range", index);
+    const PInfo& p = v[index];
+    if (name_host && name_cap > 0) snprintf(name_host, name_cap, "%s", p.name.c_str());
+    if (offset) *offset = p.off;
+    if (numel) *numel = p.numel;
+    if (dims4_host) for (int i = 0; i < 4; ++i) dims4_host[i] = p.dims[i];
+    if (ndim) *ndim = p.ndim;
+    if (late) *late = p.late;
+    return BLT_OK;
+}
+
+int64_t bltvqg_engine_flat_size(const bltvqg_engine* e, int which) { return e ? (which == 0 ? e->tsize : e->fsize) : 0; }
+int64_t bltvqg_engine_late_offset(const bltvqg_engine* e) { return e ? e->late_off : 0; }
+int64_t bltvqg_engine_workspace_bytes(const bltvqg_engine* e) { return e ? e->ws_bytes : 0; }
+
+int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_m, float* adam_v, float* frozen, void* workspace,
+                       int64_t workspace_bytes) {
+    BLT_REQUIRE(e && train && grad && frozen && workspace, "engine_bind: null pointer");
+    BLT_REQUIRE(workspace_bytes >= e->ws_bytes, "engine_bind: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)e->ws_bytes);
+    BLT_REQUIRE(((uintptr_t)workspace % 256) == 0 && ((uintptr_t)train % 16) == 0 && ((uintptr_t)grad % 16) == 0 && ((uintptr_t)frozen % 16) == 0,
+                "engine_bind: misaligned buffer");
+    e->train = train; e->grad = grad; e->adam_m = adam_m; e->adam_v = adam_v; e->frozen = frozen; e->ws = (char*)workspace;
+    e->layout(e->ws);
+    if (hipMemset(workspace, 0, (size_t)e->ws_bytes) != hipSuccess) { blt_set_error("engine_bind: workspace memset failed"); return BLT_ERR_HIP; }
+    // sinusoid timing signal, transformer_layers.py:542-558: [sin(pos*w_i) | cos(pos*w_i)], float64 then cast
+    {
+        const int H = e->H, nt = H / 2;
+        std::vector<float> tab((size_t)64 * H, 0.f);
+        const double inc = log(1.0e4 / 1.0) / ((double)nt - 1.0);
+        for (int pos = 0; pos < 64; ++pos)
+            for (int i = 0; i < nt; ++i) {
+                const double st = (double)pos * (1.0 * exp((double)i * -inc));
+                tab[(size_t)pos * H + i] = (float)sin(st);
+                tab[(size_t)pos * H + nt + i] = (float)cos(st);
+            }
+        if (hipMemcpy(e->timing, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+            blt_set_error("engine_bind: timing table upload failed");
+            return BLT_ERR_HIP;
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        if (!e->bucket_ev[i] && hipEventCreateWithFlags(&e->bucket_ev[i], hipEventDisableTiming) != hipSuccess) {
+            blt_set_error("engine_bind: event creation failed");
+            return BLT_ERR_HIP;
+        }
+    e->bound = true; e->frozen_dirty = true; e->fwd_done = false;
+    return BLT_OK;
+}
+
+void bltvqg_engine_invalidate_frozen(bltvqg_engine* e) { if (e) e->frozen_dirty = true; }
+
+int bltvqg_engine_forward(bltvqg_engine* e, const float* images, const int64_t* context, const int64_t* posterior, const int64_t* target,
+                          const float* eps, int phase2, uint64_t seed, void* stream) {
+    BLT_REQUIRE(e, "engine_forward: null engine");
+    return e->forward(images, context, posterior, target, eps, phase2, seed, (hipStream_t)stream);
+}
+
+int bltvqg_engine_loss_backward(bltvqg_engine* e, float kl_weight, void* stream) {
+    BLT_REQUIRE(e, "engine_loss_backward: null engine");
+    return e->loss_backward(kl_weight, (hipStream_t)stream);
+}
+
+int bltvqg_engine_backward_external(bltvqg_engine* e, const float* d_output, const float* d_zlogit, float d_kld, const float* d_feats,
+                                    const float* d_recon, void* stream) {
+    BLT_REQUIRE(e, "engine_backward_external: null engine");
+    return e->backward_external(d_output, d_zlogit, d_kld, d_feats, d_recon, (hipStream_t)stream);
+}
+
+int bltvqg_engine_optimizer_step(bltvqg_engine* e, float lr, float max_norm, float beta1, float beta2, float eps, void* stream) {
+    BLT_REQUIRE(e, "engine_optimizer_step: null engine");
+    return e->optimizer_step(lr, max_norm, beta1, beta2, eps, (hipStream_t)stream);
+}
+
+int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
+    BLT_REQUIRE(e && e->bound && dst, "engine_read: bad args");
+    hipStream_t s = (hipStream_t)stream;
+    switch (what) {
+        case 0: return blt_cast_rows(e->dt, e->logits, e->ldV, BLT_F32, dst, e->V, e->Mt, e->V, s);
+        case 1: return blt_cast_rows(e->dt, e->zlogit, e->ldV, BLT_F32, dst, e->V, e->B, e->V, s);
+        case 2: return blt_cast_rows(e->dt, e->feats, e->H, BLT_F32, dst, e->H, e->B, e->H, s);
+        case 3: return blt_cast_rows(e->dt, e->recon, e->H, BLT_F32, dst, e->H, e->B, e->H, s);
+        case 4:
+            if (hipMemcpyAsync(dst, e->stats, 8 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return BLT_ERR_HIP;
+            return hipMemcpyAsync(dst + 5, e->counters, sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? BLT_OK : BLT_ERR_HIP;
+        case 5: return blt_cast_rows(e->dt, e->enc.out, e->H, BLT_F32, dst, e->H, e->Ma, e->H, s);
+        case 6: return blt_cast_rows(e->dt, e->dec.out, e->H, BLT_F32, dst, e->H, e->Mt, e->H, s);
+        default: blt_set_error("engine_read: unknown item %d", what); return BLT_ERR_ARG;
+    }
+}
+
+uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site) { return (uint32_t)(stack * 1000 + layer * 10 + site); }
+
+int bltvqg_engine_num_buckets(const bltvqg_engine* e) { return e ? 3 : 0; }
+int bltvqg_engine_bucket_info(const bltvqg_engine* e, int i, int64_t* offset, int64_t* numel, int32_t* late) {
+    BLT_REQUIRE(e && i >= 0 && i < 3, "engine_bucket_info: bad args");
+    if (offset) *offset = e->bucket_off[i];
+    if (numel) *numel = e->bucket_len[i];
+    if (late) *late = e->bucket_late[i];
+    return BLT_OK;
+}
+int bltvqg_engine_bucket_wait(bltvqg_engine* e, int i, void* stream) {
+    BLT_REQUIRE(e && i >= 0 && i < 3 && e->bucket_ev[i], "engine_bucket_wait: bad args");
+    return hipStreamWaitEvent((hipStream_t)stream, e->bucket_ev[i], 0) == hipSuccess ? BLT_OK : BLT_ERR_HIP;
+}
+
+}  // extern "C"

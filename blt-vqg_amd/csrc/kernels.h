@@ -1,0 +1,143 @@
+// Internal C++ launch API of libbltvqg_hip.so.  Every launcher enqueues asynchronously on `stream`,
+// allocates nothing and returns BLT_OK or a negative error (message via bltvqg_last_error_string()).
+// `dtype` is BLT_F32 or BLT_BF16 and names the storage type T of activations / (shadow) weights.
+#pragma once
+#include "common.h"
+
+struct ConvGeom {
+    int Hi, Wi, Cin, cin_log2, Ho, Wo, KH, KW, stride, pad;
+};
+
+// C[M,N] = epilogue( alpha * sum_k A^[m,k] * B^[n,k] )
+//   transA = 0: A stored [M, lda] (k contiguous)      transA = 1: A stored [K, lda] (m contiguous)
+//   transB = 0: B stored [N, ldb] (k contiguous)      transB = 1: B stored [K, ldb] (n contiguous)
+// epilogue order: *alpha, +bias[n], +rowtab[rowidx[m]][n], relu, dropout, *(maskY!=0)*mask_scale,
+//                 ->C2 (optional copy), +R[m,n], +old C (accumulate), ->C
+struct GemmArgs {
+    const void* A = nullptr;
+    const void* B = nullptr;
+    void* C = nullptr;
+    int M = 0, N = 0, K = 0;
+    int lda = 0, ldb = 0, ldc = 0;
+    int transA = 0, transB = 0;
+    int out_f32 = 0;
+    float alpha = 1.f;
+    const float* bias = nullptr;
+    const float* rowtab = nullptr;
+    const int* rowidx = nullptr;
+    int ldt = 0;
+    int relu = 0;
+    float drop_p = 0.f;
+    uint64_t seed = 0;
+    uint32_t stream_id = 0;
+    const void* maskY = nullptr;
+    int ldm = 0;
+    float mask_scale = 1.f;
+    void* C2 = nullptr;
+    int ldc2 = 0;
+    const void* R = nullptr;
+    int ldr = 0;
+    int accumulate = 0;
+    float* stat_sum = nullptr;   // [2*tiles_m, N] per-half-tile column sums of the raw accumulators
+    float* stat_sq = nullptr;
+    int is_conv = 0;
+    ConvGeom cg = {};
+    int force_tile = 0;          // 0 = heuristic, 64 or 128
+};
+int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
+int blt_gemm_stat_rows(const GemmArgs& a);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
+int blt_gemm_tile(const GemmArgs& a);
+
+// ---- normalisation -----------------------------------------------------------------
+int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      long rows, int cols, float eps, hipStream_t s);
+// dx = LNbwd(dy) (+ dres if non-null); dgamma/dbeta are ACCUMULATED (+=) with float atomics
+int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s);
+
+// BatchNorm2d (train mode) on NHWC: finalize partial sums -> scale/shift (+ running stat update)
+int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long count, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                    float* scale, float* shift, float* save_mean, float* save_var, double* scratch, hipStream_t s);
+int blt_bn_scratch_doubles(int C);   // doubles of scratch blt_bn_finalize needs
+// y = [relu]( x*scale[c] + shift[c] (+ res) ), in place allowed
+int blt_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, long rows,
+                 int C, int relu, hipStream_t s);
+// y[n,ho,wo,c] = max 3x3/2 pad1 of relu(x*scale+shift)
+int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
+                        int C, hipStream_t s);
+int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, hipStream_t s);
+// BatchNorm1d over the batch (train mode); saves mean / rstd; updates running stats (unbiased var)
+int blt_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                 float* running_mean, float* running_var, int B, int C, float eps, float momentum, hipStream_t s);
+int blt_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                 void* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t s);
+
+// ---- attention -----------------------------------------------------------------------
+struct AttnArgs {
+    const void* Q = nullptr; const void* K = nullptr; const void* V = nullptr;   // row strides in elements
+    int ldq = 0, ldk = 0, ldv = 0;
+    void* O = nullptr; int ldo = 0;
+    const int* key_ids = nullptr;   // [B, Tk] token ids; id == 0 -> key masked
+    int B = 0, heads = 0, Tq = 0, Tk = 0, d = 0;
+    int causal = 0;
+    float scale = 1.f;
+    float drop_p = 0.f; uint64_t seed = 0; uint32_t stream_id = 0;
+    // backward only
+    const void* dO = nullptr; int lddo = 0;
+    void* dQ = nullptr; void* dK = nullptr; void* dV = nullptr; int lddq = 0, lddk = 0, lddv = 0;
+    int accumulate_dkv = 0;
+};
+int blt_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
+int blt_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s);
+
+// ---- embedding / token plumbing --------------------------------------------------------
+// out[m, 0:E] = table[ids[m], :] ; out[m, E:ld] = 0
+int blt_embed_gather(int dtype, const float* table, const int* ids, void* out, long rows, int E, int ld, hipStream_t s);
+// dtable[ids[m], :] += d[m, 0:E]  for ids[m] != pad
+int blt_embed_scatter(int dtype, const void* d, int ld, const int* ids, float* dtable, long rows, int E, int pad_id,
+                      hipStream_t s);
+// builds int32 token streams from the int64 batch tensors (see engine.hip)
+int blt_prep_tokens(const long long* ctx, const long long* post, const long long* tgt, int B, int Sa, int Sp, int T,
+                    int* ids_all, int* pos_all, int* tgt_shift, int* tgt32, int* ctx32, int* post32, float* counters,
+                    hipStream_t s);
+
+// ---- elementwise ---------------------------------------------------------------------------
+// y[b*ystride + j] (+)= a[b*astride + j] (+ c[b*cstride + j]) for j < n  (row-0 injections and their gradients)
+int blt_rows_add(int dtype, void* y, long ystride, const void* a, long astride, const void* c, long cstride, int B, int n,
+                 int accumulate, hipStream_t s);
+// y = dy * (ymask != 0) * scale
+int blt_mask_scale(int dtype, const void* dy, const void* ymask, void* y, long n, float scale, hipStream_t s);
+// out[n] (+)= sum_m x[m, n]
+int blt_colsum(int dtype, const void* x, int ld, long M, int N, float* out, int accumulate, hipStream_t s);
+int blt_cast_pad(const float* src, int rows, int cols, void* dst, int ld, int dtype, hipStream_t s);
+int blt_cast_rows(int dtype_src, const void* src, int lds_, int dtype_dst, void* dst, int ldd, long rows, int cols,
+                  hipStream_t s);
+int blt_img_pack(int dtype, const float* nchw, void* nhwc8, int N, int C, int H, int W, int Cpad, hipStream_t s);
+int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, hipStream_t s);
+int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long rows, int cols, hipStream_t s);
+
+// ---- losses ------------------------------------------------------------------------------------
+// token CE with ignore_index=0, mean over non-pad targets (count from counters[0]); writes d(logits) IN PLACE scaled by
+// gscale/count; loss_out += sum(-logp)/count.  logits [M, ld] with pad columns zeroed in the gradient.
+int blt_ce_fwd_bwd(int dtype, void* logits, int ld, const int* target, long M, int V, const float* count, float gscale,
+                   float* loss_out, int write_grad, hipStream_t s);
+// bag-of-words CE: one logit row per sample against T targets (train_iq.py:92-94)
+int blt_bow_ce_fwd_bwd(int dtype, const void* zlogit, int ld, const int* target, int B, int T, int V, const float* count,
+                       float gscale, float* loss_out, void* dz, hipStream_t s);
+// mse = mean((a-b)^2); da = gscale*2(a-b)/n ; db = -da   (train_iq.py:84: gradient flows to both arguments)
+int blt_mse_fwd_bwd(int dtype, const void* a, const void* b, long n, float gscale, float* loss_out, void* da, void* db,
+                    hipStream_t s);
+// reparameterisation + KL (transformer_layers.py:41-59, 536-540)
+int blt_latent_fwd(int dtype, const void* mlv_p, const void* mlv_q, const float* eps, void* z, float* kld_out, int B,
+                   int Z, int ld, hipStream_t s);
+int blt_latent_bwd(int dtype, const void* mlv_p, const void* mlv_q, const float* eps, const void* dz, float kld_gscale,
+                   void* dmlv_p, void* dmlv_q, int B, int Z, int ld, hipStream_t s);
+
+// ---- optimiser ---------------------------------------------------------------------------------
+int blt_sumsq(const float* x, long n, float* out /* += */, hipStream_t s);
+// clip_grad_norm_(max_norm) + Adam (torch defaults) over a flat fp32 buffer; gnorm_sq is a device scalar
+int blt_adam_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float max_norm, float lr,
+                  float beta1, float beta2, float eps, int step, hipStream_t s);
+int blt_dropout_mask(uint64_t seed, uint32_t stream_id, long rows, int cols, int ld_index, float p, unsigned char* out,
+                     hipStream_t s);

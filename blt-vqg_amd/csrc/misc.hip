@@ -1,0 +1,522 @@
+// HBM-bound plumbing kernels of the train step: token preparation, embedding gather / scatter-add, row-0 injections,
+// ReLU/dropout backward mask, bias-gradient column sums, dtype casts / layout packs, the loss kernels (token CE with
+// fused backward, bag-of-words CE, MSE, reparameterisation + KL), gradient norm and fused clip + Adam.
+//
+// Reference call sites: models/iq.py:57-79 (embedding), models/decoder_transformer.py:24-35 (shift / injection),
+// models/transformer_layers.py:41-59,536-540 (Latent, gaussian_kld), train_iq.py:81-103 (losses),
+// train_iq.py:259-261,372 (Adam, clip_grad_norm 5).
+#include "kernels.h"
+
+namespace {
+
+inline int ew_grid(long n, int per_block = 256) {
+    long g = (n + per_block - 1) / per_block;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tokens
+// ---------------------------------------------------------------------------------------------------------------
+// ids_all = [ctx (B*Sa) | shifted target (B*T) | post (B*Sp)], pos_all = position inside the sequence,
+// tgt_shift = [<start>, target[:, :-1]] (decoder_transformer.py:24-27), counters[0] = #non-pad targets,
+// counters[1 + b] = #non-pad targets of sample b.
+__global__ void prep_tokens_kernel(const long long* __restrict__ ctx, const long long* __restrict__ post,
+                                   const long long* __restrict__ tgt, int B, int Sa, int Sp, int T, int* __restrict__ ids_all,
+                                   int* __restrict__ pos_all, int* __restrict__ tgt_shift, int* __restrict__ tgt32,
+                                   int* __restrict__ ctx32, int* __restrict__ post32, float* __restrict__ counters) {
+    const int na = B * Sa, np = B * Sp, nt = B * T;
+    const int total = na + np + nt;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        if (i < na) {
+            const int v = (int)ctx[i];
+            ids_all[i] = v; ctx32[i] = v; pos_all[i] = i % Sa;
+        } else if (i < na + nt) {
+            const int j = i - na;
+            const int t = j % T;
+            const int v = (t == 0) ? 1 : (int)tgt[j - 1];
+            ids_all[i] = v; tgt_shift[j] = v; pos_all[i] = t;
+            tgt32[j] = (int)tgt[j];
+        } else {
+            const int j = i - na - nt;
+            const int v = (int)post[j];
+            ids_all[i] = v; post32[j] = v; pos_all[i] = j % Sp;
+        }
+    }
+    if (blockIdx.x == 0) {
+        // per-sample non-pad counts (T <= 64 keeps this trivial)
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            int c = 0;
+            for (int t = 0; t < T; ++t) c += (tgt[b * T + t] != 0);
+            counters[1 + b] = (float)c;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // serial, deterministic; B <= a few thousand
+            float c = 0.f;
+            for (int b = 0; b < B; ++b) {
+                int cb = 0;
+                for (int t = 0; t < T; ++t) cb += (tgt[b * T + t] != 0);
+                c += (float)cb;
+            }
+            counters[0] = c;
+        }
+    }
+}
+
+template <typename T>
+__global__ void embed_gather_kernel(const float* __restrict__ table, const int* __restrict__ ids, T* __restrict__ out, long rows,
+                                    int E, int ld) {
+    const long total = rows * ld;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / ld;
+        const int e = (int)(i - m * ld);
+        out[i] = from_f32<T>(e < E ? table[(long)ids[m] * E + e] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ void embed_scatter_kernel(const T* __restrict__ d, int ld, const int* __restrict__ ids, float* __restrict__ dtable,
+                                     long rows, int E, int pad_id) {
+    const long total = rows * E;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / E;
+        const int e = (int)(i - m * E);
+        const int id = ids[m];
+        if (id != pad_id) atomicAdd(dtable + (long)id * E + e, to_f32(d[m * ld + e]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// elementwise
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void rows_add_kernel(T* __restrict__ y, long ys, const T* __restrict__ a, long as, const T* __restrict__ c, long cs,
+                                int B, int n, int accumulate) {
+    const long total = (long)B * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / n;
+        const int j = (int)(i - b * n);
+        float v = to_f32(a[b * as + j]);
+        if (c != nullptr) v += to_f32(c[b * cs + j]);
+        if (accumulate) v += to_f32(y[b * ys + j]);
+        y[b * ys + j] = from_f32<T>(v);
+    }
+}
+
+template <typename T>
+__global__ void mask_scale_kernel(const T* __restrict__ dy, const T* __restrict__ ym, T* __restrict__ y, long nchunks, float scale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        float d[8], m[8];
+        Vec8<T>::load(dy + i * 8, d);
+        Vec8<T>::load(ym + i * 8, m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d[e] = (m[e] != 0.f) ? d[e] * scale : 0.f;
+        Vec8<T>::store(y + i * 8, d);
+    }
+}
+
+// column sums: block = 64 columns x 4 row-lanes; grid.y splits rows; float atomics combine the row splits
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long M, int N, float* __restrict__ out) {
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + cx;
+    float s = 0.f;
+    if (n < N)
+        for (long m = (long)blockIdx.y * 4 + ry; m < M; m += (long)gridDim.y * 4) s += to_f32(x[m * ld + n]);
+    sh[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && n < N) atomicAdd(out + n, sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]);
+}
+
+template <typename TS, typename TD>
+__global__ void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __restrict__ dst, int ldd, long rows, int cols) {
+    const long total = rows * ldd;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / ldd;
+        const int c = (int)(i - r * ldd);
+        dst[i] = from_f32<TD>(c < cols ? to_f32(src[r * lds_ + c]) : 0.f);
+    }
+}
+
+// NCHW fp32 image -> NHWC with C padded to Cpad (zeros)
+template <typename T>
+__global__ void img_pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H, int W, int Cpad) {
+    const long total = (long)N * H * W * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        long t = i / Cpad;
+        const int w = (int)(t % W); t /= W;
+        const int h = (int)(t % H);
+        const long n = t / H;
+        dst[i] = from_f32<T>(c < C ? src[((n * C + c) * H + h) * W + w] : 0.f);
+    }
+}
+
+// conv weight [Cout, Cin, KH, KW] fp32 -> [Cout, KH, KW, Cpad] T (k index = (r*KW + s)*Cpad + c)
+template <typename T>
+__global__ void conv_pack_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH, int KW, int Cpad) {
+    const long total = (long)Cout * KH * KW * Cpad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cpad);
+        long t = i / Cpad;
+        const int s = (int)(t % KW); t /= KW;
+        const int r = (int)(t % KH);
+        const long o = t / KH;
+        out[i] = from_f32<T>(c < Cin ? w[((o * Cin + c) * KH + r) * KW + s] : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// losses
+// ---------------------------------------------------------------------------------------------------------------
+// One block per logits row: three passes (max, sum-exp, gradient) over a row that stays in L2/L1.
+template <typename T>
+__global__ __launch_bounds__(256) void ce_kernel(T* __restrict__ logits, int ld, const int* __restrict__ target, int V,
+                                                const float* __restrict__ count, float gscale, float* __restrict__ loss_out,
+                                                int write_grad) {
+    __shared__ float red[16];
+    const long row = blockIdx.x;
+    T* x = logits + row * ld;
+    const int tgt = target[row];
+    const float inv_count = 1.f / fmaxf(count[0], 1.f);
+    if (tgt == 0) {   // ignore_index: contributes nothing, gradient row is zero
+        if (write_grad)
+            for (int v = threadIdx.x; v < ld; v += blockDim.x) x[v] = from_f32<T>(0.f);
+        return;
+    }
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) m = fmaxf(m, to_f32(x[v]));
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) s += __expf(to_f32(x[v]) - m);
+    s = block_sum(s, red);
+    const float lse = m + __logf(s);
+    const float xt = to_f32(x[tgt]);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_out, (lse - xt) * inv_count);
+    if (write_grad) {
+        const float g = gscale * inv_count;
+        for (int v = threadIdx.x; v < ld; v += blockDim.x) {
+            float d = 0.f;
+            if (v < V) d = (__expf(to_f32(x[v]) - lse) - (v == tgt ? 1.f : 0.f)) * g;
+            x[v] = from_f32<T>(d);
+        }
+    }
+}
+
+// bag-of-words CE (train_iq.py:92-94 without materialising the (B,T,V) repeat): one block per sample.
+template <typename T>
+__global__ __launch_bounds__(256) void bow_ce_kernel(const T* __restrict__ z, int ld, const int* __restrict__ target, int Tn, int V,
+                                                    const float* __restrict__ count, float gscale, float* __restrict__ loss_out,
+                                                    T* __restrict__ dz) {
+    __shared__ float red[16];
+    __shared__ int tg[64];
+    const int b = blockIdx.x;
+    const T* x = z + (long)b * ld;
+    if (threadIdx.x < Tn) tg[threadIdx.x] = target[b * Tn + threadIdx.x];
+    __syncthreads();
+    int nb = 0;
+    for (int t = 0; t < Tn; ++t) nb += (tg[t] != 0);
+    const float inv_count = 1.f / fmaxf(count[0], 1.f);
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) m = fmaxf(m, to_f32(x[v]));
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) s += __expf(to_f32(x[v]) - m);
+    s = block_sum(s, red);
+    const float lse = m + __logf(s);
+    if (threadIdx.x == 0) {
+        float l = 0.f;
+        for (int t = 0; t < Tn; ++t)
+            if (tg[t] != 0) l += lse - to_f32(x[tg[t]]);
+        atomicAdd(loss_out, l * inv_count);
+    }
+    if (dz != nullptr) {
+        const float g = gscale * inv_count;
+        T* d = dz + (long)b * ld;
+        for (int v = threadIdx.x; v < ld; v += blockDim.x) {
+            float o = 0.f;
+            if (v < V) {
+                int hits = 0;
+                for (int t = 0; t < Tn; ++t) hits += (tg[t] == v && v != 0);
+                o = ((float)nb * __expf(to_f32(x[v]) - lse) - (float)hits) * g;
+            }
+            d[v] = from_f32<T>(o);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, long n, float gscale,
+                                                 float* __restrict__ loss_out, T* __restrict__ da, T* __restrict__ db) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const float inv = 1.f / (float)n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = to_f32(a[i]) - to_f32(b[i]);
+        s += d * d;
+        const float g = 2.f * d * inv * gscale;
+        if (da) da[i] = from_f32<T>(g);
+        if (db) db[i] = from_f32<T>(-g);
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(loss_out, s * inv);
+}
+
+// z = eps*exp(0.5*logvar_q) + mu_q ; kld = mean_b( -0.5 sum(1 + lq - lp - (mp-mq)^2/e^lp - e^lq/e^lp) )
+template <typename T>
+__global__ __launch_bounds__(256) void latent_fwd_kernel(const T* __restrict__ mlvp, const T* __restrict__ mlvq,
+                                                        const float* __restrict__ eps, T* __restrict__ z, float* __restrict__ kld,
+                                                        int B, int Z, int ld) {
+    __shared__ float red[16];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int j = threadIdx.x; j < Z; j += blockDim.x) {
+        const float mp = to_f32(mlvp[(long)b * ld + j]), lp = to_f32(mlvp[(long)b * ld + Z + j]);
+        const float mq = to_f32(mlvq[(long)b * ld + j]), lq = to_f32(mlvq[(long)b * ld + Z + j]);
+        z[(long)b * Z + j] = from_f32<T>(eps[(long)b * Z + j] * __expf(0.5f * lq) + mq);
+        const float ip = __expf(-lp);
+        s += 1.f + (lq - lp) - (mp - mq) * (mp - mq) * ip - __expf(lq) * ip;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(kld, -0.5f * s / (float)B);
+}
+
+template <typename T>
+__global__ void latent_bwd_kernel(const T* __restrict__ mlvp, const T* __restrict__ mlvq, const float* __restrict__ eps,
+                                  const T* __restrict__ dz, float G, T* __restrict__ dmlvp, T* __restrict__ dmlvq, int B, int Z, int ld) {
+    const long total = (long)B * Z;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / Z;
+        const int j = (int)(i - b * Z);
+        const float mp = to_f32(mlvp[b * ld + j]), lp = to_f32(mlvp[b * ld + Z + j]);
+        const float mq = to_f32(mlvq[b * ld + j]), lq = to_f32(mlvq[b * ld + Z + j]);
+        const float g = to_f32(dz[i]);
+        const float ip = __expf(-lp), r = __expf(lq) * ip, dm = mp - mq;
+        dmlvq[b * ld + j] = from_f32<T>(g - G * dm * ip);
+        dmlvq[b * ld + Z + j] = from_f32<T>(g * 0.5f * eps[i] * __expf(0.5f * lq) - 0.5f * G * (1.f - r));
+        dmlvp[b * ld + j] = from_f32<T>(G * dm * ip);
+        dmlvp[b * ld + Z + j] = from_f32<T>(-0.5f * G * (-1.f + dm * dm * ip + r));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// optimiser
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
+    __shared__ float red[16];
+    float s = 0.f;
+    const long n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) { const float v = x[(n4 << 2) + threadIdx.x]; s += v * v; }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) atomicAdd(out, s);
+}
+
+// torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam.step (defaults: amsgrad off, wd 0)
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, long n, const float* __restrict__ gnorm_sq, float max_norm,
+                                                  float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+    float clip = 1.f;
+    if (max_norm > 0.f) {
+        const float norm = sqrtf(gnorm_sq[0]);
+        clip = fminf(max_norm / (norm + 1e-6f), 1.f);
+    }
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * clip;
+        const float mi = beta1 * m[i] + (1.f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= step_size * (mi / denom);
+    }
+}
+
+__global__ void dropout_mask_kernel(uint64_t seed, uint32_t stream_id, long rows, int cols, int ld_index, uint32_t thresh,
+                                    unsigned char* __restrict__ out) {
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        out[i] = dropout_keep(seed, stream_id, (uint64_t)r * (uint64_t)ld_index + (uint64_t)c, thresh) ? 1 : 0;
+    }
+}
+
+}  // namespace
+
+#define T_SWITCH(dtype, NAME, GRID, BLOCK, LDS, STREAM, ...)                                        \
+    do {                                                                                           \
+        if ((dtype) == BLT_F32) hipLaunchKernelGGL(NAME<float>, GRID, BLOCK, LDS, STREAM, __VA_ARGS__); \
+        else hipLaunchKernelGGL(NAME<bf16>, GRID, BLOCK, LDS, STREAM, __VA_ARGS__);                 \
+    } while (0)
+
+#define CHECK_DTYPE(dtype, what) BLT_REQUIRE((dtype) == BLT_F32 || (dtype) == BLT_BF16, what ": bad dtype %d", (int)(dtype))
+
+int blt_prep_tokens(const long long* ctx, const long long* post, const long long* tgt, int B, int Sa, int Sp, int T,
+                    int* ids_all, int* pos_all, int* tgt_shift, int* tgt32, int* ctx32, int* post32, float* counters,
+                    hipStream_t s) {
+    BLT_REQUIRE(ctx && post && tgt && ids_all && pos_all && tgt_shift && tgt32 && ctx32 && post32 && counters, "prep_tokens: null pointer");
+    BLT_REQUIRE(B > 0 && Sa > 0 && Sp > 0 && T > 0 && T <= 64, "prep_tokens: bad sizes");
+    hipLaunchKernelGGL(prep_tokens_kernel, dim3(ew_grid((long)B * (Sa + Sp + T))), dim3(256), 0, s, ctx, post, tgt, B, Sa, Sp, T,
+                       ids_all, pos_all, tgt_shift, tgt32, ctx32, post32, counters);
+    return blt_check_launch("prep_tokens");
+}
+
+int blt_embed_gather(int dtype, const float* table, const int* ids, void* out, long rows, int E, int ld, hipStream_t s) {
+    CHECK_DTYPE(dtype, "embed_gather");
+    BLT_REQUIRE(table && ids && out && rows > 0 && E > 0 && ld >= E, "embed_gather: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(embed_gather_kernel<float>, dim3(ew_grid(rows * ld)), dim3(256), 0, s, table, ids, (float*)out, rows, E, ld);
+    else hipLaunchKernelGGL(embed_gather_kernel<bf16>, dim3(ew_grid(rows * ld)), dim3(256), 0, s, table, ids, (bf16*)out, rows, E, ld);
+    return blt_check_launch("embed_gather");
+}
+
+int blt_embed_scatter(int dtype, const void* d, int ld, const int* ids, float* dtable, long rows, int E, int pad_id, hipStream_t s) {
+    CHECK_DTYPE(dtype, "embed_scatter");
+    BLT_REQUIRE(d && ids && dtable && rows > 0 && E > 0 && ld >= E, "embed_scatter: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(embed_scatter_kernel<float>, dim3(ew_grid(rows * E)), dim3(256), 0, s, (const float*)d, ld, ids, dtable, rows, E, pad_id);
+    else hipLaunchKernelGGL(embed_scatter_kernel<bf16>, dim3(ew_grid(rows * E)), dim3(256), 0, s, (const bf16*)d, ld, ids, dtable, rows, E, pad_id);
+    return blt_check_launch("embed_scatter");
+}
+
+int blt_rows_add(int dtype, void* y, long ys, const void* a, long as, const void* c, long cs, int B, int n, int accumulate, hipStream_t s) {
+    CHECK_DTYPE(dtype, "rows_add");
+    BLT_REQUIRE(y && a && B > 0 && n > 0, "rows_add: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(rows_add_kernel<float>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (float*)y, ys, (const float*)a, as, (const float*)c, cs, B, n, accumulate);
+    else hipLaunchKernelGGL(rows_add_kernel<bf16>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (bf16*)y, ys, (const bf16*)a, as, (const bf16*)c, cs, B, n, accumulate);
+    return blt_check_launch("rows_add");
+}
+
+int blt_mask_scale(int dtype, const void* dy, const void* ym, void* y, long n, float scale, hipStream_t s) {
+    CHECK_DTYPE(dtype, "mask_scale");
+    BLT_REQUIRE(dy && ym && y && n > 0 && n % 8 == 0, "mask_scale: n=%ld must be a positive multiple of 8", n);
+    if (dtype == BLT_F32) hipLaunchKernelGGL(mask_scale_kernel<float>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const float*)dy, (const float*)ym, (float*)y, n / 8, scale);
+    else hipLaunchKernelGGL(mask_scale_kernel<bf16>, dim3(ew_grid(n / 8)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)ym, (bf16*)y, n / 8, scale);
+    return blt_check_launch("mask_scale");
+}
+
+int blt_colsum(int dtype, const void* x, int ld, long M, int N, float* out, int accumulate, hipStream_t s) {
+    CHECK_DTYPE(dtype, "colsum");
+    BLT_REQUIRE(x && out && M > 0 && N > 0 && ld >= N, "colsum: bad args");
+    if (!accumulate) {
+        if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) { blt_set_error("colsum: memset failed"); return BLT_ERR_HIP; }
+    }
+    int gy = (int)((M + 255) / 256);
+    if (gy > 64) gy = 64;
+    if (gy < 1) gy = 1;
+    if (dtype == BLT_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 64), gy), dim3(256), 0, s, (const float*)x, ld, M, N, out);
+    else hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(cdiv(N, 64), gy), dim3(256), 0, s, (const bf16*)x, ld, M, N, out);
+    return blt_check_launch("colsum");
+}
+
+int blt_cast_rows(int dtype_src, const void* src, int lds_, int dtype_dst, void* dst, int ldd, long rows, int cols, hipStream_t s) {
+    CHECK_DTYPE(dtype_src, "cast_rows");
+    CHECK_DTYPE(dtype_dst, "cast_rows");
+    BLT_REQUIRE(src && dst && rows > 0 && cols > 0 && lds_ >= cols && ldd >= cols, "cast_rows: bad args");
+    const dim3 g(ew_grid(rows * ldd)), b(256);
+    if (dtype_src == BLT_F32 && dtype_dst == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<float, float>), g, b, 0, s, (const float*)src, lds_, (float*)dst, ldd, rows, cols);
+    else if (dtype_src == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<float, bf16>), g, b, 0, s, (const float*)src, lds_, (bf16*)dst, ldd, rows, cols);
+    else if (dtype_dst == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<bf16, float>), g, b, 0, s, (const bf16*)src, lds_, (float*)dst, ldd, rows, cols);
+    else hipLaunchKernelGGL((cast_rows_kernel<bf16, bf16>), g, b, 0, s, (const bf16*)src, lds_, (bf16*)dst, ldd, rows, cols);
+    return blt_check_launch("cast_rows");
+}
+
+int blt_cast_pad(const float* src, int rows, int cols, void* dst, int ld, int dtype, hipStream_t s) {
+    return blt_cast_rows(BLT_F32, src, cols, dtype, dst, ld, rows, cols, s);
+}
+
+int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long rows, int cols, hipStream_t s) {
+    return blt_cast_rows(dtype, src, lds_, dtype, dst, ldd, rows, cols, s);
+}
+
+int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, hipStream_t s) {
+    CHECK_DTYPE(dtype, "img_pack");
+    BLT_REQUIRE(nchw && nhwc && N > 0 && C > 0 && C <= Cpad && H > 0 && W > 0, "img_pack: bad args");
+    const long n = (long)N * H * W * Cpad;
+    if (dtype == BLT_F32) hipLaunchKernelGGL(img_pack_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (float*)nhwc, N, C, H, W, Cpad);
+    else hipLaunchKernelGGL(img_pack_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (bf16*)nhwc, N, C, H, W, Cpad);
+    return blt_check_launch("img_pack");
+}
+
+int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, hipStream_t s) {
+    CHECK_DTYPE(dtype, "conv_pack_w");
+    BLT_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cin <= Cpad, "conv_pack_w: bad args");
+    const long n = (long)Cout * KH * KW * Cpad;
+    if (dtype == BLT_F32) hipLaunchKernelGGL(conv_pack_w_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, w, (float*)out, Cout, Cin, KH, KW, Cpad);
+    else hipLaunchKernelGGL(conv_pack_w_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, w, (bf16*)out, Cout, Cin, KH, KW, Cpad);
+    return blt_check_launch("conv_pack_w");
+}
+
+int blt_ce_fwd_bwd(int dtype, void* logits, int ld, const int* target, long M, int V, const float* count, float gscale,
+                   float* loss_out, int write_grad, hipStream_t s) {
+    CHECK_DTYPE(dtype, "ce");
+    BLT_REQUIRE(logits && target && count && loss_out && M > 0 && V > 0 && ld >= V, "ce: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(ce_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (float*)logits, ld, target, V, count, gscale, loss_out, write_grad);
+    else hipLaunchKernelGGL(ce_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (bf16*)logits, ld, target, V, count, gscale, loss_out, write_grad);
+    return blt_check_launch("ce");
+}
+
+int blt_bow_ce_fwd_bwd(int dtype, const void* z, int ld, const int* target, int B, int T, int V, const float* count, float gscale,
+                       float* loss_out, void* dz, hipStream_t s) {
+    CHECK_DTYPE(dtype, "bow_ce");
+    BLT_REQUIRE(z && target && count && loss_out && B > 0 && T > 0 && T <= 64 && V > 0 && ld >= V, "bow_ce: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(bow_ce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)z, ld, target, T, V, count, gscale, loss_out, (float*)dz);
+    else hipLaunchKernelGGL(bow_ce_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)z, ld, target, T, V, count, gscale, loss_out, (bf16*)dz);
+    return blt_check_launch("bow_ce");
+}
+
+int blt_mse_fwd_bwd(int dtype, const void* a, const void* b, long n, float gscale, float* loss_out, void* da, void* db, hipStream_t s) {
+    CHECK_DTYPE(dtype, "mse");
+    BLT_REQUIRE(a && b && loss_out && n > 0, "mse: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(mse_kernel<float>, dim3(ew_grid(n, 1024)), dim3(256), 0, s, (const float*)a, (const float*)b, n, gscale, loss_out, (float*)da, (float*)db);
+    else hipLaunchKernelGGL(mse_kernel<bf16>, dim3(ew_grid(n, 1024)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, n, gscale, loss_out, (bf16*)da, (bf16*)db);
+    return blt_check_launch("mse");
+}
+
+int blt_latent_fwd(int dtype, const void* mlv_p, const void* mlv_q, const float* eps, void* z, float* kld_out, int B, int Z, int ld, hipStream_t s) {
+    CHECK_DTYPE(dtype, "latent_fwd");
+    BLT_REQUIRE(mlv_p && mlv_q && eps && z && kld_out && B > 0 && Z > 0 && ld >= 2 * Z, "latent_fwd: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(latent_fwd_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)mlv_p, (const float*)mlv_q, eps, (float*)z, kld_out, B, Z, ld);
+    else hipLaunchKernelGGL(latent_fwd_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)mlv_p, (const bf16*)mlv_q, eps, (bf16*)z, kld_out, B, Z, ld);
+    return blt_check_launch("latent_fwd");
+}
+
+int blt_latent_bwd(int dtype, const void* mlv_p, const void* mlv_q, const float* eps, const void* dz, float kld_gscale,
+                   void* dmlv_p, void* dmlv_q, int B, int Z, int ld, hipStream_t s) {
+    CHECK_DTYPE(dtype, "latent_bwd");
+    BLT_REQUIRE(mlv_p && mlv_q && eps && dz && dmlv_p && dmlv_q && B > 0 && Z > 0 && ld >= 2 * Z, "latent_bwd: bad args");
+    const float G = kld_gscale / (float)B;
+    if (dtype == BLT_F32) hipLaunchKernelGGL(latent_bwd_kernel<float>, dim3(ew_grid((long)B * Z)), dim3(256), 0, s, (const float*)mlv_p, (const float*)mlv_q, eps, (const float*)dz, G, (float*)dmlv_p, (float*)dmlv_q, B, Z, ld);
+    else hipLaunchKernelGGL(latent_bwd_kernel<bf16>, dim3(ew_grid((long)B * Z)), dim3(256), 0, s, (const bf16*)mlv_p, (const bf16*)mlv_q, eps, (const bf16*)dz, G, (bf16*)dmlv_p, (bf16*)dmlv_q, B, Z, ld);
+    return blt_check_launch("latent_bwd");
+}
+
+int blt_sumsq(const float* x, long n, float* out, hipStream_t s) {
+    BLT_REQUIRE(x && out && n > 0 && ((uintptr_t)x % 16) == 0, "sumsq: bad args");
+    hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n / 4 + 1, 1024)), dim3(256), 0, s, x, n, out);
+    return blt_check_launch("sumsq");
+}
+
+int blt_adam_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float max_norm, float lr,
+                  float beta1, float beta2, float eps, int step, hipStream_t s) {
+    BLT_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam: bad args");
+    BLT_REQUIRE(max_norm <= 0.f || gnorm_sq != nullptr, "adam: clipping needs gnorm_sq");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    return blt_check_launch("adam");
+}
+
+int blt_dropout_mask(uint64_t seed, uint32_t stream_id, long rows, int cols, int ld_index, float p, unsigned char* out, hipStream_t s) {
+    BLT_REQUIRE(out && rows > 0 && cols > 0 && ld_index >= cols && p >= 0.f && p < 1.f, "dropout_mask: bad args");
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, s, seed, stream_id, rows, cols, ld_index, dropout_threshold(p), out);
+    return blt_check_launch("dropout_mask");
+}

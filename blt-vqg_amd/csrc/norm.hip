@@ -1,0 +1,417 @@
+// LayerNorm (fwd/bwd), BatchNorm2d train-mode statistics/apply for the frozen ResNet stack, BatchNorm1d (fwd/bwd),
+// max-pool and global average pool.  All are HBM-bound: one wave per row (LayerNorm) or 8 channels per lane (NHWC
+// elementwise), 16-byte vector accesses, wave-shuffle reductions.
+//
+// Replaces: torch LayerNorm (models/transformer_layers.py:134,202,256-257,320-322), torchvision BatchNorm2d in train
+// mode + MaxPool2d + AdaptiveAvgPool2d (models/encoder_cnn.py:17,33), BatchNorm1d(momentum=0.01) (encoder_cnn.py:21,34).
+#include "kernels.h"
+
+namespace {
+
+constexpr int LN_MAX_CHUNKS = 4;   // per lane: 4 chunks x 8 elements x 64 lanes = 2048 columns
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, T* __restrict__ y,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, long rows,
+                                                           int cols, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nch = cols >> 3;
+    float v[LN_MAX_CHUNKS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nch) {
+            Vec8<T>::load(x + row * cols + c * 8, v[j]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[j][e];
+        }
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mu; q += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+        const int c = lane + 64 * j;
+        if (c < nch) {
+            float g[8], b[8], o[8];
+            Vec8<float>::load(gamma + c * 8, g);
+            Vec8<float>::load(beta + c * 8, b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
+            Vec8<T>::store(y + row * cols + c * 8, o);
+        }
+    }
+}
+
+// Each wave walks rows with a grid stride, keeps its slice of dgamma/dbeta in registers and adds it to the
+// global fp32 gradient once at the end (one float atomic per column per wave).
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const T* dres,
+                                                           T* dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int nch = cols >> 3;
+    float ag[LN_MAX_CHUNKS][8], ab[LN_MAX_CHUNKS][8], g[LN_MAX_CHUNKS][8];
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+        const int c = lane + 64 * j;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; g[j][e] = 0.f; }
+        if (c < nch) Vec8<float>::load(gamma + c * 8, g[j]);
+    }
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float xh[LN_MAX_CHUNKS][8], dxh[LN_MAX_CHUNKS][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                float d[8];
+                Vec8<T>::load(dy + row * cols + c * 8, d);
+                Vec8<T>::load(x + row * cols + c * 8, xh[j]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[j][e] = (xh[j][e] - mu) * rs;
+                    dxh[j][e] = d[e] * g[j][e];
+                    s1 += dxh[j][e];
+                    s2 += dxh[j][e] * xh[j][e];
+                    ag[j][e] += d[e] * xh[j][e];
+                    ab[j][e] += d[e];
+                }
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)cols, c2 = wave_sum(s2) / (float)cols;
+#pragma unroll
+        for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+            const int c = lane + 64 * j;
+            if (c < nch) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (dxh[j][e] - c1 - xh[j][e] * c2);
+                if (dres != nullptr) {
+                    float r[8];
+                    Vec8<T>::load(dres + row * cols + c * 8, r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                }
+                Vec8<T>::store(dx + row * cols + c * 8, o);
+            }
+        }
+    }
+    // combine the 4 waves of the block through LDS, then one atomic per column per block
+    __shared__ float red[4][LN_MAX_CHUNKS * 64 * 8 / 4];   // reused in two passes (gamma then beta), 512 cols per pass
+    const int w = threadIdx.x >> 6;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) red[w][lane * 8 + e] = pass == 0 ? ag[j][e] : ab[j][e];
+            __syncthreads();
+            // 512 columns of chunk-group j: column = (lane' + 64 j) * 8 + e  -> index lane'*8+e in red
+            for (int i = threadIdx.x; i < 512; i += 256) {
+                const int col = 64 * 8 * j + i;
+                if (col < cols) {
+                    const float t = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+                    atomicAdd((pass == 0 ? dgamma : dbeta) + col, t);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// BatchNorm2d, train mode.  Stage 1 reduces the GEMM's per-half-tile partial sums (fp32) into `S` slices in fp64;
+// stage 2 finishes per channel and applies the reference's running-statistics update (momentum 0.1, unbiased var).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
+                                                       int nparts, int C, double* __restrict__ tmp /* [S][2][C] */) {
+    __shared__ double sh[2][4][64];
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int S = gridDim.y, sl = blockIdx.y;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int part = sl * 4 + py; part < nparts; part += S * 4) {
+            a += (double)psum[(size_t)part * C + c];
+            b += (double)psq[(size_t)part * C + c];
+        }
+    sh[0][py][cx] = a;
+    sh[1][py][cx] = b;
+    __syncthreads();
+    if (py == 0 && c < C) {
+        tmp[((size_t)sl * 2 + 0) * C + c] = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+        tmp[((size_t)sl * 2 + 1) * C + c] = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+    }
+}
+
+__global__ void bn_finish_kernel(const double* __restrict__ tmp, int S, int C, double count, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
+                                 float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
+                                 float* __restrict__ save_mean, float* __restrict__ save_var) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) { a += tmp[((size_t)s * 2) * C + c]; b += tmp[((size_t)s * 2 + 1) * C + c]; }
+    const double mu = a / count;
+    double var = b / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (save_mean) save_mean[c] = (float)mu;
+    if (save_var) save_var[c] = (float)var;
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const T* __restrict__ res,
+                                                      T* __restrict__ y, long nchunks, int cpr /* chunks per row */, int relu) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpr) * 8;
+        float v[8], sc[8], sh[8];
+        Vec8<T>::load(x + i * 8, v);
+        Vec8<float>::load(scale + c, sc);
+        Vec8<float>::load(shift + c, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * sc[e] + sh[e];
+        if (res != nullptr) {
+            float r[8];
+            Vec8<T>::load(res + i * 8, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        Vec8<T>::store(y + i * 8, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, T* __restrict__ y, int N,
+                                                             int Hi, int Wi, int C, int Ho, int Wo) {
+    const int cpr = C >> 3;
+    const long total = (long)N * Ho * Wo * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cpr);
+        long t = i / cpr;
+        const int wo = (int)(t % Wo); t /= Wo;
+        const int ho = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        float sc[8], sh[8], m[8];
+        Vec8<float>::load(scale + cc * 8, sc);
+        Vec8<float>::load(shift + cc * 8, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 0.f;   // relu output >= 0 and every 3x3/2 pad-1 window holds >= 1 valid pixel
+        for (int r = 0; r < 3; ++r) {
+            const int hi = ho * 2 - 1 + r;
+            if ((unsigned)hi >= (unsigned)Hi) continue;
+            for (int s = 0; s < 3; ++s) {
+                const int wi = wo * 2 - 1 + s;
+                if ((unsigned)wi >= (unsigned)Wi) continue;
+                float v[8];
+                Vec8<T>::load(x + (((long)n * Hi + hi) * Wi + wi) * C + cc * 8, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e] * sc[e] + sh[e]);
+            }
+        }
+        Vec8<T>::store(y + i * 8, m);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C) {
+    const int cpr = C >> 3;
+    const long total = (long)N * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cpr);
+        const long n = i / cpr;
+        float a[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = 0.f;
+        for (int p = 0; p < HW; ++p) {
+            float v[8];
+            Vec8<T>::load(x + (n * HW + p) * C + cc * 8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += v[e];
+        }
+        const float inv = 1.f / (float)HW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] *= inv;
+        Vec8<T>::store(y + n * C + cc * 8, a);
+    }
+}
+
+// BatchNorm1d over the batch dimension: one thread per column (coalesced across columns).
+template <typename T>
+__global__ void bn1d_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                float* __restrict__ rvar, int B, int C, float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += to_f32(x[(long)b * C + c]);
+    const float mu = s / (float)B;
+    float q = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = to_f32(x[(long)b * C + c]) - mu; q += d * d; }
+    const float var = q / (float)B;
+    const float rs = rsqrtf(var + eps);
+    mean[c] = mu;
+    rstd[c] = rs;
+    const float g = gamma[c], be = beta[c];
+    for (int b = 0; b < B; ++b) y[(long)b * C + c] = from_f32<T>((to_f32(x[(long)b * C + c]) - mu) * rs * g + be);
+    if (rmean) {
+        const float unb = B > 1 ? var * (float)B / (float)(B - 1) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+
+template <typename T>
+__global__ void bn1d_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mu = mean[c], rs = rstd[c], g = gamma[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float d = to_f32(dy[(long)b * C + c]);
+        s1 += d;
+        s2 += d * (to_f32(x[(long)b * C + c]) - mu) * rs;
+    }
+    dgamma[c] = s2;
+    dbeta[c] = s1;
+    const float inv = 1.f / (float)B;
+    for (int b = 0; b < B; ++b) {
+        const float d = to_f32(dy[(long)b * C + c]);
+        const float xh = (to_f32(x[(long)b * C + c]) - mu) * rs;
+        dx[(long)b * C + c] = from_f32<T>(g * rs * (d - s1 * inv - xh * s2 * inv));
+    }
+}
+
+inline int ew_grid(long n) {
+    long g = (n + 255) / 256;
+    if (g > 2048) g = 2048;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, expr_f32, expr_bf16) \
+    do {                                       \
+        if ((dtype) == BLT_F32) { expr_f32; }  \
+        else { expr_bf16; }                    \
+    } while (0)
+
+int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                      long rows, int cols, float eps, hipStream_t s) {
+    BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_fwd: bad dtype");
+    BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_fwd: cols=%d must be a multiple of 8 and <= %d", cols, LN_MAX_CHUNKS * 512);
+    BLT_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
+    const int grid = cdiv(rows, 4);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps),
+               hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps));
+    return blt_check_launch("layernorm_fwd");
+}
+
+int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                      const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s) {
+    BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_bwd: bad dtype");
+    BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_bwd: bad cols=%d", cols);
+    BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
+    int grid = cdiv(rows, 4);
+    if (grid > 512) grid = 512;
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols),
+               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols));
+    return blt_check_launch("layernorm_bwd");
+}
+
+static constexpr int BN_SLICES = 32;
+int blt_bn_scratch_doubles(int C) { return BN_SLICES * 2 * C; }
+
+int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long count, const float* gamma,
+                    const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                    float* shift, float* save_mean, float* save_var, double* scratch, hipStream_t s) {
+    BLT_REQUIRE(psum && psq && gamma && beta && scale && shift && scratch, "bn_finalize: null pointer");
+    BLT_REQUIRE(nparts > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
+    BLT_REQUIRE(((uintptr_t)scratch % 8) == 0, "bn_finalize: scratch must be 8-byte aligned");
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 64), BN_SLICES), dim3(256), 0, s, psum, psq, nparts, C, scratch);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double*)scratch, BN_SLICES, C, (double)count, gamma, beta, eps,
+                       momentum, running_mean, running_var, scale, shift, save_mean, save_var);
+    return blt_check_launch("bn_finalize");
+}
+
+int blt_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, long rows,
+                 int C, int relu, hipStream_t s) {
+    BLT_REQUIRE(x && scale && shift && y && rows > 0 && C % 8 == 0, "bn_apply: bad args (C=%d)", C);
+    const long n = rows * (C / 8);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu),
+               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu));
+    return blt_check_launch("bn_apply");
+}
+
+int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
+                        int C, hipStream_t s) {
+    BLT_REQUIRE(x && scale && shift && y && C % 8 == 0 && N > 0, "bn_relu_maxpool: bad args");
+    const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
+    const long n = (long)N * Ho * Wo * (C / 8);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (float*)y, N, Hi, Wi, C, Ho, Wo),
+               hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (bf16*)y, N, Hi, Wi, C, Ho, Wo));
+    return blt_check_launch("bn_relu_maxpool");
+}
+
+int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, hipStream_t s) {
+    BLT_REQUIRE(x && y && C % 8 == 0 && N > 0 && HW > 0, "avgpool: bad args");
+    const long n = (long)N * (C / 8);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(avgpool_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, (float*)y, N, HW, C),
+               hipLaunchKernelGGL(avgpool_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, HW, C));
+    return blt_check_launch("avgpool");
+}
+
+int blt_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                 float* running_mean, float* running_var, int B, int C, float eps, float momentum, hipStream_t s) {
+    BLT_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0, "bn1d_fwd: bad args");
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn1d_fwd_kernel<float>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum),
+               hipLaunchKernelGGL(bn1d_fwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum));
+    return blt_check_launch("bn1d_fwd");
+}
+
+int blt_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                 void* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t s) {
+    BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && B > 0 && C > 0, "bn1d_bwd: bad args");
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn1d_bwd_kernel<float>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, B, C),
+               hipLaunchKernelGGL(bn1d_bwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, B, C));
+    return blt_check_launch("bn1d_bwd");
+}

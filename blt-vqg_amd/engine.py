@@ -1,0 +1,165 @@
+"""Python handle on the HIP train-step engine (csrc/engine.hip).
+
+Owns the device memory the C library borrows: one flat fp32 buffer of trainable parameters (and same-layout gradient /
+Adam-moment buffers), one flat fp32 buffer of frozen backbone parameters + BatchNorm running statistics, and the
+activation workspace.  Parameters are exposed as views into the flat buffers under the reference's state_dict names.
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import Config, check, ptr, stream_ptr
+
+F32, BF16 = _lib.F32, _lib.BF16
+
+
+def make_config(batch, hidden_dim, pwffn_dim, latent_dim, emb_dim, num_layers, num_heads, vocab_size, len_context=5,
+                len_posterior=21, len_target=20, image_hw=(224, 224), dtype=BF16, attention_dropout=0.1, relu_dropout=0.1,
+                kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1):
+    return Config(batch=batch, hidden_dim=hidden_dim, pwffn_dim=pwffn_dim, latent_dim=latent_dim, emb_dim=emb_dim,
+                  num_layers=num_layers, num_heads=num_heads, vocab_size=vocab_size, len_context=len_context,
+                  len_posterior=len_posterior, len_target=len_target, image_h=image_hw[0], image_w=image_hw[1], dtype=dtype,
+                  attention_dropout=attention_dropout, relu_dropout=relu_dropout, kl_ceiling=kl_ceiling,
+                  aux_ceiling=aux_ceiling, image_recon_lambda=image_recon_lambda)
+
+
+class ParamInfo(object):
+    __slots__ = ("name", "offset", "numel", "shape", "late")
+
+    def __init__(self, name, offset, numel, shape, late):
+        self.name, self.offset, self.numel, self.shape, self.late = name, offset, numel, shape, late
+
+
+class StepEngine(object):
+    """One engine = one static shape (batch, sequence lengths, image size, dtype)."""
+
+    def __init__(self, cfg, device="cuda"):
+        self.lib = _lib.load()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self.h = self.lib.bltvqg_engine_create(ctypes.byref(cfg))
+        if not self.h:
+            raise _lib.HipError("bltvqg_engine_create: " + self.lib.bltvqg_last_error_string().decode())
+        self.h = ctypes.c_void_p(self.h)
+        self.train_info = self._infos(0)
+        self.frozen_info = self._infos(1)
+        self.train_size = int(self.lib.bltvqg_engine_flat_size(self.h, 0))
+        self.frozen_size = int(self.lib.bltvqg_engine_flat_size(self.h, 1))
+        self.late_offset = int(self.lib.bltvqg_engine_late_offset(self.h))
+        self.workspace_bytes = int(self.lib.bltvqg_engine_workspace_bytes(self.h))
+        self.flat_train = self.flat_grad = self.adam_m = self.adam_v = self.flat_frozen = self.workspace = None
+        self.bound = False
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.bltvqg_engine_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def _infos(self, which):
+        n = self.lib.bltvqg_engine_num_params(self.h, which)
+        out = OrderedDict()
+        buf = ctypes.create_string_buffer(256)
+        off, numel = _lib.L(), _lib.L()
+        dims = (ctypes.c_int32 * 4)()
+        ndim, late = ctypes.c_int32(), ctypes.c_int32()
+        for i in range(n):
+            check(self.lib.bltvqg_engine_param_info(self.h, which, i, buf, 256, ctypes.byref(off), ctypes.byref(numel), dims,
+                                                    ctypes.byref(ndim), ctypes.byref(late)), "engine_param_info")
+            name = buf.value.decode()
+            shape = tuple(int(dims[k]) for k in range(ndim.value))
+            out[name] = ParamInfo(name, int(off.value), int(numel.value), shape, int(late.value))
+        return out
+
+    # ------------------------------------------------------------------------------------------------
+    def allocate(self):
+        """Allocates the flat buffers + workspace on the device and binds them."""
+        dev = self.device
+        self.flat_train = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+        self.adam_m = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+        self.adam_v = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+        self.flat_frozen = torch.zeros(self.frozen_size, dtype=torch.float32, device=dev)
+        self.workspace = torch.empty(self.workspace_bytes + 256, dtype=torch.uint8, device=dev)
+        self._bind()
+
+    def _bind(self):
+        base = self.workspace.data_ptr()
+        aligned = (base + 255) // 256 * 256
+        torch.cuda.synchronize(self.device)
+        check(self.lib.bltvqg_engine_bind(self.h, ptr(self.flat_train), ptr(self.flat_grad), ptr(self.adam_m), ptr(self.adam_v),
+                                          ptr(self.flat_frozen), ctypes.c_void_p(aligned), self.workspace_bytes), "engine_bind")
+        self.bound = True
+
+    def view(self, name, which=None):
+        """Tensor view of a parameter inside its flat buffer (state_dict name)."""
+        if name in self.train_info and which in (None, 0):
+            i = self.train_info[name]
+            return self.flat_train[i.offset:i.offset + i.numel].view(i.shape)
+        i = self.frozen_info[name]
+        return self.flat_frozen[i.offset:i.offset + i.numel].view(i.shape)
+
+    def grad_view(self, name):
+        i = self.train_info[name]
+        return self.flat_grad[i.offset:i.offset + i.numel].view(i.shape)
+
+    def load_state(self, state):
+        """Copies a reference-style state dict (name -> tensor) into the flat buffers."""
+        with torch.no_grad():
+            for name in self.train_info:
+                self.view(name, 0).copy_(state[name].to(self.device, torch.float32))
+            for name in self.frozen_info:
+                self.view(name, 1).copy_(state[name].to(self.device, torch.float32))
+        self.lib.bltvqg_engine_invalidate_frozen(self.h)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, images, context, posterior, target, eps=None, phase2=False, seed=0):
+        c = self.cfg
+        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+        assert tuple(images.shape) == (c.batch, 3, c.image_h, c.image_w), images.shape
+        for t, n in ((context, c.len_context), (posterior, c.len_posterior), (target, c.len_target)):
+            assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and tuple(t.shape) == (c.batch, n), (t.shape, n)
+        if eps is not None:
+            assert eps.is_cuda and eps.dtype == torch.float32 and eps.is_contiguous() and tuple(eps.shape) == (c.batch, c.latent_dim)
+        check(self.lib.bltvqg_engine_forward(self.h, ptr(images), ptr(context), ptr(posterior), ptr(target), ptr(eps),
+                                             1 if phase2 else 0, int(seed), stream_ptr()), "engine_forward")
+
+    def loss_backward(self, kl_weight=0.0):
+        check(self.lib.bltvqg_engine_loss_backward(self.h, float(kl_weight), stream_ptr()), "engine_loss_backward")
+
+    def backward_external(self, d_output=None, d_zlogit=None, d_kld=0.0, d_feats=None, d_recon=None):
+        check(self.lib.bltvqg_engine_backward_external(self.h, ptr(d_output), ptr(d_zlogit), float(d_kld), ptr(d_feats), ptr(d_recon),
+                                                       stream_ptr()), "engine_backward_external")
+
+    def optimizer_step(self, lr, max_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-8):
+        check(self.lib.bltvqg_engine_optimizer_step(self.h, float(lr), float(max_norm), float(beta1), float(beta2), float(eps),
+                                                    stream_ptr()), "engine_optimizer_step")
+
+    _READ_SHAPES = {0: lambda c: (c.batch, c.len_target, c.vocab_size), 1: lambda c: (c.batch, c.vocab_size),
+                    2: lambda c: (c.batch, c.hidden_dim), 3: lambda c: (c.batch, c.hidden_dim), 4: lambda c: (8,),
+                    5: lambda c: (c.batch, c.len_context, c.hidden_dim), 6: lambda c: (c.batch, c.len_target, c.hidden_dim)}
+
+    def read(self, what):
+        out = torch.empty(self._READ_SHAPES[what](self.cfg), dtype=torch.float32, device=self.device)
+        check(self.lib.bltvqg_engine_read(self.h, what, ptr(out), stream_ptr()), "engine_read")
+        return out
+
+    def stats(self):
+        """dict of python floats (one host sync): rec, img, kld, aux, grad_norm, n_targets."""
+        s = self.read(4).tolist()
+        return dict(rec=s[0], img=s[1], kld=s[2], aux=s[3], grad_norm=s[4] ** 0.5, n_targets=s[5])
+
+    def buckets(self):
+        out = []
+        off, n, late = _lib.L(), _lib.L(), ctypes.c_int32()
+        for i in range(self.lib.bltvqg_engine_num_buckets(self.h)):
+            check(self.lib.bltvqg_engine_bucket_info(self.h, i, ctypes.byref(off), ctypes.byref(n), ctypes.byref(late)), "bucket_info")
+            out.append((int(off.value), int(n.value), int(late.value)))
+        return out
+
+    def bucket_wait(self, i, stream):
+        check(self.lib.bltvqg_engine_bucket_wait(self.h, i, ctypes.c_void_p(stream.cuda_stream)), "bucket_wait")

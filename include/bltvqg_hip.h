@@ -1,0 +1,175 @@
+/* libbltvqg_hip.so — C ABI of the MI355X-native BLT-VQG training hot path.
+ *
+ * The reference (nihirv/blt-vqg) is pure Python on PyTorch and has no FFI of its own; the operator boundary this
+ * library replaces is the set of torch operator call sites on the train step:
+ *   models/iq.py:82-114            IQ.forward            -> bltvqg_engine_forward
+ *   train_iq.py:81-103             calculate_losses      -> bltvqg_engine_loss_backward (losses fused with backward)
+ *   train_iq.py:105-132 (+ Lightning backward / clip 5 / Adam, train_iq.py:260,372)
+ *                                                        -> bltvqg_engine_loss_backward + bltvqg_engine_optimizer_step
+ * and, one level down, the individual operators, exported for unit parity tests and for callers that want one op:
+ *   nn.Linear / F.conv2d           (transformer_layers.py:453-456,400-408; encoder_cnn.py:20,33)  -> bltvqg_gemm / bltvqg_conv2d
+ *   nn.LayerNorm                   (transformer_layers.py:134,202,256-257,320-322)                -> bltvqg_layernorm_fwd/bwd
+ *   MultiHeadAttention core        (transformer_layers.py:494-526)                                -> bltvqg_attn_fwd/bwd
+ *   nn.CrossEntropyLoss(ignore 0)  (train_iq.py:54-55,82-83,92-94)                                -> bltvqg_ce_fwd_bwd / bltvqg_bow_ce_fwd_bwd
+ *   Latent reparam + gaussian_kld  (transformer_layers.py:41-59,536-540)                          -> bltvqg_latent_fwd/bwd
+ *   BatchNorm2d(train) statistics  (encoder_cnn.py:33)                                            -> bltvqg_bn_finalize / bltvqg_bn_apply
+ *   Adam + clip_grad_norm_         (train_iq.py:260,372)                                          -> bltvqg_adam_step
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host; the library borrows it for the duration of the
+ *     enqueue, allocates nothing persistent on the device and frees nothing;
+ *   - all work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no hidden synchronisation;
+ *   - return value 0 = success, negative = error; bltvqg_last_error_string() describes the last error of the thread;
+ *   - dtype: 0 = fp32 (exact-fp32 MFMA; parity mode), 1 = bf16 storage with fp32 accumulation (performance mode).
+ */
+#ifndef BLTVQG_HIP_H
+#define BLTVQG_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLTVQG_F32 0
+#define BLTVQG_BF16 1
+
+int bltvqg_version(void);
+const char* bltvqg_last_error_string(void);
+
+/* ---------------- operator-level entry points ---------------- */
+
+/* C[M,N] = epilogue(sum_k A^[m,k] * B^[n,k]).  transA/transB: 0 = k-contiguous storage, 1 = m/n-contiguous storage.
+ * Optional epilogue terms (NULL / 0 to disable), applied in this order: +bias[n] (fp32), ReLU, dropout(p, seed, stream_id),
+ * *(maskY != 0)*mask_scale, +R[m,n], +old C (accumulate).  out_f32: store C as fp32 even when dtype is bf16. */
+int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, int ldb, int transB, void* C, int ldc,
+                int M, int N, int K, const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
+                const void* maskY, int ldm, float mask_scale, const void* R, int ldr, int accumulate, int out_f32,
+                int force_tile, void* stream);
+
+/* NHWC implicit-GEMM convolution y[N,Ho,Wo,Cout] = conv(x[N,Hi,Wi,Cin], w[Cout,KH,KW,Cin]); Cin a power of two >= 8 (bf16)
+ * / 4 (fp32).  stat_sum/stat_sq (optional): per-half-tile column partial sums, bltvqg_conv2d_stat_rows() rows of Cout. */
+int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
+                  int stride, int pad, float* stat_sum, float* stat_sq, void* stream);
+int bltvqg_conv2d_stat_rows(int N, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad);
+int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, void* stream);
+int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, void* stream);
+
+int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                         int64_t rows, int cols, float eps, void* stream);
+/* dgamma / dbeta are accumulated (+=). dres (optional) is added to dx. */
+int bltvqg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                         const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, void* stream);
+
+int bltvqg_bn_scratch_doubles(int C);
+int bltvqg_bn_finalize(const float* psum, const float* psq, int nparts, int C, int64_t count, const float* gamma,
+                       const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
+                       float* shift, double* scratch, void* stream);
+int bltvqg_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int64_t rows,
+                    int C, int relu, void* stream);
+int bltvqg_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
+                           int C, void* stream);
+int bltvqg_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, void* stream);
+int bltvqg_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                    float* running_mean, float* running_var, int B, int C, float eps, float momentum, void* stream);
+int bltvqg_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
+                    void* dx, float* dgamma, float* dbeta, int B, int C, void* stream);
+
+/* Attention core on packed projections.  Q [B*Tq, ldq], K/V [B*Tk, ld*]; head h uses columns [h*d, (h+1)*d).
+ * key_ids [B,Tk] int32: id 0 => key masked (value -1e18 like the reference); causal: key j > query i masked. */
+int bltvqg_attn_fwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                    const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal, float scale, float drop_p,
+                    uint64_t seed, uint32_t stream_id, void* stream);
+int bltvqg_attn_bwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo,
+                    void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int32_t* key_ids, int B, int heads, int Tq,
+                    int Tk, int d, int causal, float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
+
+int bltvqg_embed_gather(int dtype, const float* table, const int32_t* ids, void* out, int64_t rows, int E, int ld, void* stream);
+int bltvqg_embed_scatter(int dtype, const void* d, int ld, const int32_t* ids, float* dtable, int64_t rows, int E, int pad_id,
+                         void* stream);
+
+/* Token cross-entropy, ignore_index = 0, mean over count[0] targets.  loss_out += loss.  If write_grad, the logits buffer is
+ * overwritten with gscale * dloss/dlogits (pad columns [V, ld) zeroed). */
+int bltvqg_ce_fwd_bwd(int dtype, void* logits, int ld, const int32_t* target, int64_t M, int V, const float* count, float gscale,
+                      float* loss_out, int write_grad, void* stream);
+int bltvqg_bow_ce_fwd_bwd(int dtype, const void* zlogit, int ld, const int32_t* target, int B, int T, int V, const float* count,
+                          float gscale, float* loss_out, void* dz, void* stream);
+int bltvqg_mse_fwd_bwd(int dtype, const void* a, const void* b, int64_t n, float gscale, float* loss_out, void* da, void* db,
+                       void* stream);
+int bltvqg_latent_fwd(int dtype, const void* mlv_prior, const void* mlv_post, const float* eps, void* z, float* kld_out, int B,
+                      int Z, int ld, void* stream);
+int bltvqg_latent_bwd(int dtype, const void* mlv_prior, const void* mlv_post, const float* eps, const void* dz, float kld_gscale,
+                      void* dmlv_prior, void* dmlv_post, int B, int Z, int ld, void* stream);
+
+int bltvqg_sumsq(const float* x, int64_t n, float* out, void* stream);
+int bltvqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* gnorm_sq, float max_norm, float lr,
+                     float beta1, float beta2, float eps, int step, void* stream);
+/* keep-mask (1 = keep) the kernels use for dropout site `stream_id`: element (r, c) has index r*ld_index + c */
+int bltvqg_dropout_mask(uint64_t seed, uint32_t stream_id, int64_t rows, int cols, int ld_index, float p, uint8_t* out,
+                        void* stream);
+int bltvqg_cast(int dtype_src, const void* src, int ld_src, int dtype_dst, void* dst, int ld_dst, int64_t rows, int cols,
+                void* stream);
+
+/* ---------------- train-step engine ---------------- */
+
+typedef struct bltvqg_config {
+    int32_t batch;          /* per-GPU batch B */
+    int32_t hidden_dim, pwffn_dim, latent_dim, emb_dim, num_layers, num_heads, vocab_size;
+    int32_t len_context;    /* S_a: 5 ("ans") or 3 ("cat") */
+    int32_t len_posterior;  /* S_p: 21 */
+    int32_t len_target;     /* T: 20 */
+    int32_t image_h, image_w;
+    int32_t dtype;          /* BLTVQG_F32 or BLTVQG_BF16 */
+    float attention_dropout, relu_dropout;   /* 0.1 / 0.1 in the reference (transformer_layers.py:97,164) */
+    float kl_ceiling, aux_ceiling, image_recon_lambda;
+} bltvqg_config;
+
+typedef struct bltvqg_engine bltvqg_engine;
+
+/* which: 0 = trainable parameters (flat fp32 buffer, gradients and Adam state share the layout), 1 = frozen backbone
+ * parameters and BatchNorm running statistics (flat fp32 buffer). */
+bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg);
+void bltvqg_engine_destroy(bltvqg_engine* e);
+int bltvqg_engine_num_params(const bltvqg_engine* e, int which);
+/* name_host: caller buffer of name_cap bytes; shape as (rows, cols) with cols = 0 for 1-D and rows = cols = 0 for 4-D conv
+ * weights whose dims come back in dims4_host[4]; offset in floats into the flat buffer; late = 1 for parameters that only
+ * receive gradients after the pre-training phase. */
+int bltvqg_engine_param_info(const bltvqg_engine* e, int which, int index, char* name_host, int name_cap, int64_t* offset,
+                             int64_t* numel, int32_t* dims4_host, int32_t* ndim, int32_t* late);
+int64_t bltvqg_engine_flat_size(const bltvqg_engine* e, int which);      /* floats */
+int64_t bltvqg_engine_late_offset(const bltvqg_engine* e);               /* first float of the phase-2-only region */
+int64_t bltvqg_engine_workspace_bytes(const bltvqg_engine* e);
+/* Binds caller-owned device memory.  workspace must be 256-byte aligned and is zeroed by bind (synchronously). */
+int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_m, float* adam_v, float* frozen,
+                       void* workspace, int64_t workspace_bytes);
+/* Frozen backbone weights changed (load_state_dict): repack on next forward. */
+void bltvqg_engine_invalidate_frozen(bltvqg_engine* e);
+
+/* IQ.forward (iq.py:82-114).  images fp32 NCHW [B,3,h,w]; token tensors int64 like the reference batch; eps fp32 [B,Z]
+ * (may be NULL in phase 1).  train_bn: BatchNorm in train mode (batch statistics + running-stat update), as the reference. */
+int bltvqg_engine_forward(bltvqg_engine* e, const float* images, const int64_t* context, const int64_t* posterior,
+                          const int64_t* target, const float* eps, int phase2, uint64_t seed, void* stream);
+/* calculate_losses (train_iq.py:81-103) fused with the whole backward pass.  Gradients of every trainable parameter are
+ * written to the bound flat gradient buffer (zeroed first).  kl_weight = min(tanh(6*kliter/full_kl_step-3)+1, 1). */
+int bltvqg_engine_loss_backward(bltvqg_engine* e, float kl_weight, void* stream);
+/* Backward from caller-supplied output gradients (fp32, any may be NULL = zero): autograd integration of IQ.forward. */
+int bltvqg_engine_backward_external(bltvqg_engine* e, const float* d_output, const float* d_zlogit, float d_kld,
+                                    const float* d_feats, const float* d_recon, void* stream);
+/* clip_grad_norm_(max_norm) + Adam over the regions that received gradients this step. */
+int bltvqg_engine_optimizer_step(bltvqg_engine* e, float lr, float max_norm, float beta1, float beta2, float eps,
+                                 void* stream);
+/* outputs, converted to contiguous fp32: what = 0 output [B,T,V], 1 z_logit [B,V], 2 image_features [B,H],
+ * 3 reconstructed [B,H], 4 stats float[8] = {loss_rec, loss_img, kld, loss_aux, grad_norm_sq, n_targets, 0, 0},
+ * 5 encoder_outputs [B,S_a,H], 6 decoder_outputs [B,T,H] */
+int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream);
+uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site);
+/* gradient buckets for data-parallel overlap: contiguous float ranges of the flat gradient buffer in the order backward
+ * completes them; bltvqg_engine_bucket_wait makes `stream` wait until bucket i of the last backward is complete. */
+int bltvqg_engine_num_buckets(const bltvqg_engine* e);
+int bltvqg_engine_bucket_info(const bltvqg_engine* e, int i, int64_t* offset, int64_t* numel, int32_t* late);
+int bltvqg_engine_bucket_wait(bltvqg_engine* e, int i, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,429 @@
+"""GPU parity tests of the individual HIP operators, called through the C ABI, against plain fp32/fp64 PyTorch on CPU.
+
+Integer-valued operands make the MFMA GEMM / conv checks BIT-EXACT in both dtypes (every product and partial sum is
+exactly representable), which pins fragment layouts, transposes, tails and the epilogue order independent of rounding.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _ints(shape, lo, hi, g, dtype):
+    return torch.randint(lo, hi + 1, shape, generator=g).to(dtype)
+
+
+def _cuda(*ts):
+    return [None if t is None else t.cuda() for t in ts]
+
+
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("layout", ["NT", "NN", "TT", "TN"])
+@pytest.mark.parametrize("shape", [(128, 128, 128), (100, 97, 72), (257, 40, 300), (64, 520, 64), (33, 8, 8)])
+def test_gemm_exact_integer(dtype, tile, layout, shape):
+    import gpu_ops as G
+    M, N, K = shape
+    ce = 8 if dtype == torch.bfloat16 else 4
+    g = torch.Generator().manual_seed(M * 7 + N * 3 + K)
+    tA, tB = layout[0] == "T", layout[1] == "N"      # "NT" = k-contiguous A and k-contiguous B (Linear forward)
+    pad = lambda n: (n + ce - 1) // ce * ce           # noqa: E731
+    A = _ints((M, K), -3, 3, g, torch.float32)
+    Bm = _ints((N, K), -3, 3, g, torch.float32)
+    ref = A.double() @ Bm.double().t()
+    if tA:
+        As = torch.zeros(K, pad(M)); As[:, :M] = A.t()
+    else:
+        As = torch.zeros(M, pad(K)); As[:, :K] = A
+    if tB:
+        Bs = torch.zeros(K, pad(N)); Bs[:, :N] = Bm.t()
+    else:
+        Bs = torch.zeros(N, pad(K)); Bs[:, :K] = Bm
+    Ad, Bd = As.to(dtype).cuda(), Bs.to(dtype).cuda()
+    C = G.gemm(Ad, Bd, M, N, K, transA=tA, transB=tB, force_tile=tile, ldc=pad(N))
+    torch.cuda.synchronize()
+    got = C[:, :N].float().cpu().double()
+    ref = ref.float().to(dtype).double()       # one output rounding (exact for fp32; RNE to bf16 otherwise)
+    assert torch.equal(got, ref), (got - ref).abs().max()
+    assert float(C[:, N:].float().abs().sum()) == 0.0          # pad columns untouched
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogue_order(dtype):
+    """bias -> relu -> (maskY) -> +R -> accumulate, and fp32 output from bf16 operands (weight-gradient form)."""
+    import gpu_ops as G
+    M, N, K = 70, 48, 64
+    g = torch.Generator().manual_seed(1)
+    A = _ints((M, K), -2, 2, g, torch.float32)
+    Bm = _ints((N, K), -2, 2, g, torch.float32)
+    bias = _ints((N,), -4, 4, g, torch.float32)
+    R = _ints((M, N), -5, 5, g, torch.float32)
+    Y = _ints((M, N), 0, 1, g, torch.float32)
+    C0 = _ints((M, N), -3, 3, g, torch.float32)
+    Ad, Bd, Rd, Yd = A.to(dtype).cuda(), Bm.to(dtype).cuda(), R.to(dtype).cuda(), Y.to(dtype).cuda()
+    # linear forward with bias + relu + residual
+    got = G.gemm(Ad, Bd, M, N, K, bias=bias.cuda(), relu=True, R=Rd).float().cpu()
+    ref = (torch.relu(A @ Bm.t() + bias) + R).to(dtype).float()
+    assert torch.equal(got, ref)
+    # relu/dropout backward mask, scaled by 2 (exact), accumulated into an existing C
+    Cd = C0.to(dtype).cuda()
+    got = G.gemm(Ad, Bd, M, N, K, maskY=Yd, mask_scale=2.0, C=Cd, accumulate=True).float().cpu()
+    ref = ((A @ Bm.t()) * (Y != 0) * 2.0 + C0).to(dtype).float()
+    assert torch.equal(got, ref)
+    # fp32 output
+    got = G.gemm(Ad, Bd, M, N, K, out_f32=True)
+    assert got.dtype == torch.float32 and torch.equal(got.cpu(), A @ Bm.t())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_random_accuracy(dtype):
+    import gpu_ops as G
+    M, N, K = 512, 384, 512
+    g = torch.Generator().manual_seed(2)
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(N, K, generator=g) / math.sqrt(K)
+    Ad, Bd = A.to(dtype).cuda(), Bm.to(dtype).cuda()
+    got = G.gemm(Ad, Bd, M, N, K).float().cpu()
+    ref = (Ad.float().cpu().double() @ Bd.float().cpu().double().t()).float()
+    tol = 2e-6 if dtype == torch.float32 else 8e-3      # bf16: output rounding only (inputs already rounded)
+    assert (got - ref).abs().max() <= tol * ref.abs().max()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_dropout_matches_exported_mask(dtype):
+    import gpu_ops as G
+    M, N, K = 96, 40, 32
+    A = torch.ones(M, K).to(dtype).cuda()
+    Bm = torch.ones(N, K).to(dtype).cuda()
+    p = 0.25
+    got = G.gemm(A, Bm, M, N, K, drop_p=p, seed=1234, stream_id=77).float().cpu()
+    mask = G.dropout_mask(1234, 77, M, N, (N + 7) // 8 * 8, p).cpu().float()
+    assert torch.allclose(got, mask * K / (1 - p), rtol=1e-2 if dtype == torch.bfloat16 else 1e-6)
+    keep = float(mask.mean())
+    assert abs(keep - (1 - p)) < 0.03
+
+
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("geom", [(3, 64, 7, 2, 3, 38, 34), (64, 64, 3, 1, 1, 14, 14), (64, 128, 3, 2, 1, 15, 13),
+                                  (64, 128, 1, 2, 0, 14, 14), (256, 512, 3, 1, 1, 4, 4)])
+def test_conv2d_exact_integer_and_stats(dtype, geom):
+    import gpu_ops as G
+    cin, cout, k, stride, pad, Hi, Wi = geom
+    N = 3
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = _ints((N, cin, Hi, Wi), -2, 2, g, torch.float32)
+    w = _ints((cout, cin, k, k), -1, 1, g, torch.float32)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad).permute(0, 2, 3, 1).contiguous()
+    cpad = max(cin, 8)
+    xp = G.img_pack(x.cuda(), dtype, cpad)
+    wp = G.conv_pack_w(w.cuda(), dtype, cpad)
+    y, ssum, ssq = G.conv2d(xp, wp, N, Hi, Wi, cpad, cout, k, stride, pad, stats=True)
+    torch.cuda.synchronize()
+    got = y.float().cpu().double()
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref.float().to(dtype).double()), (got - ref).abs().max()
+    # statistics come from the fp32 accumulators (before the output rounding)
+    assert torch.equal(ssum.double().sum(0).cpu(), ref.reshape(-1, cout).sum(0))
+    assert torch.equal(ssq.double().sum(0).cpu(), (ref.reshape(-1, cout) ** 2).sum(0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm2d_train_pipeline(dtype):
+    """conv statistics -> finalize (scale/shift + running stats) -> apply(+residual, relu) / relu+maxpool / avgpool."""
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, ptr, stream_ptr
+    lib = G.lib()
+    N, C, Hh, Ww = 4, 64, 12, 10
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, Hh, Ww, generator=g) * 2 + 0.5
+    res = torch.randn(N, C, Hh, Ww, generator=g)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    y_ref = F.batch_norm(x, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    xf = xh.float().reshape(-1, C)
+    nparts = 6
+    parts = xf.chunk(nparts, 0)
+    psum = torch.stack([p.sum(0) for p in parts]).contiguous()
+    psq = torch.stack([(p * p).sum(0) for p in parts]).contiguous()
+    scale = torch.empty(C, device="cuda"); shift = torch.empty(C, device="cuda")
+    rmd, rvd = rm.cuda(), rv.cuda()
+    scratch = torch.empty(lib.bltvqg_bn_scratch_doubles(C), dtype=torch.float64, device="cuda")
+    check(lib.bltvqg_bn_finalize(ptr(psum), ptr(psq), nparts, C, xf.shape[0], ptr(gamma.cuda()), ptr(beta.cuda()), 1e-5, 0.1, ptr(rmd), ptr(rvd),
+                                 ptr(scale), ptr(shift), ptr(scratch), stream_ptr()), "bn_finalize")
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert torch.allclose(rmd.cpu(), rm_ref, atol=tol) and torch.allclose(rvd.cpu(), rv_ref, atol=tol)
+    y = torch.empty_like(xh)
+    resh = res.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    check(lib.bltvqg_bn_apply(G.DT[dtype], ptr(xh), ptr(scale), ptr(shift), ptr(resh), ptr(y), xf.shape[0], C, 1, stream_ptr()), "bn_apply")
+    ref = torch.relu(y_ref + res).permute(0, 2, 3, 1)
+    assert torch.allclose(y.float().cpu(), ref, atol=tol * 4, rtol=tol)
+    # relu + maxpool 3x3/2 pad 1
+    Ho, Wo = (Hh - 1) // 2 + 1, (Ww - 1) // 2 + 1
+    yp = torch.empty(N, Ho, Wo, C, dtype=dtype, device="cuda")
+    check(lib.bltvqg_bn_relu_maxpool(G.DT[dtype], ptr(xh), ptr(scale), ptr(shift), ptr(yp), N, Hh, Ww, C, stream_ptr()), "maxpool")
+    refp = F.max_pool2d(torch.relu(y_ref), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.allclose(yp.float().cpu(), refp, atol=tol * 4, rtol=tol)
+    # global average pool
+    ya = torch.empty(N, C, dtype=dtype, device="cuda")
+    check(lib.bltvqg_avgpool(G.DT[dtype], ptr(xh), ptr(ya), N, Hh * Ww, C, stream_ptr()), "avgpool")
+    assert torch.allclose(ya.float().cpu(), xh.float().cpu().mean(dim=(1, 2)), atol=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm1d_fwd_bwd(dtype):
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, ptr, stream_ptr
+    lib = G.lib()
+    B, C = 24, 72
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(B, C, generator=g) * 1.5 + 0.3).to(dtype)
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    dy = torch.randn(B, C, generator=g).to(dtype)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xr = x.float().clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True); br = beta.clone().requires_grad_(True)
+    y_ref = F.batch_norm(xr, rm, rv, gr, br, True, 0.01, 1e-5)
+    y_ref.backward(dy.float())
+    xd = x.cuda(); y = torch.empty_like(xd)
+    mean = torch.empty(C, device="cuda"); rstd = torch.empty(C, device="cuda")
+    rmd, rvd = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    check(lib.bltvqg_bn1d_fwd(G.DT[dtype], ptr(xd), ptr(gamma.cuda()), ptr(beta.cuda()), ptr(y), ptr(mean), ptr(rstd), ptr(rmd), ptr(rvd), B, C,
+                              1e-5, 0.01, stream_ptr()), "bn1d_fwd")
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(y.float().cpu(), y_ref.detach(), atol=tol * 4, rtol=tol)
+    assert torch.allclose(rmd.cpu(), rm, atol=1e-5) and torch.allclose(rvd.cpu(), rv, atol=1e-5)
+    dx = torch.empty_like(xd); dg = torch.empty(C, device="cuda"); db = torch.empty(C, device="cuda")
+    check(lib.bltvqg_bn1d_bwd(G.DT[dtype], ptr(dy.cuda()), ptr(xd), ptr(gamma.cuda()), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db), B, C,
+                              stream_ptr()), "bn1d_bwd")
+    assert torch.allclose(dx.float().cpu(), xr.grad, atol=tol * 4, rtol=tol * 4)
+    assert torch.allclose(dg.cpu(), gr.grad, atol=tol * 10, rtol=tol) and torch.allclose(db.cpu(), br.grad, atol=tol * 10, rtol=tol)
+
+
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(37, 64), (5120, 512), (9, 1024), (130, 256)])
+def test_layernorm_fwd_bwd(dtype, shape):
+    import gpu_ops as G
+    rows, cols = shape
+    g = torch.Generator().manual_seed(rows + cols)
+    x = (torch.randn(rows, cols, generator=g) * 2 + 1).to(dtype)
+    gamma, beta = torch.rand(cols, generator=g) + 0.5, torch.randn(cols, generator=g)
+    dy = torch.randn(rows, cols, generator=g).to(dtype)
+    dres = torch.randn(rows, cols, generator=g).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    y_ref.backward(dy.float())
+    y, mean, rstd = G.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda())
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(y.float().cpu(), y_ref.detach(), atol=tol * 4, rtol=tol)
+    dx, dg, db = G.layernorm_bwd(dy.cuda(), x.cuda(), gamma.cuda(), mean, rstd, dres.cuda())
+    assert torch.allclose(dx.float().cpu(), xr.grad + dres.float(), atol=tol * 8, rtol=tol * 4)
+    gs = max(1.0, float(gr.grad.abs().max()))
+    assert (dg.cpu() - gr.grad).abs().max() < tol * 4 * gs and (db.cpu() - br.grad).abs().max() < tol * 4 * gs
+    # in-place residual form used by the engine: dres and dx are the same buffer
+    buf = dres.cuda().clone()
+    from bltvqg_amd._lib import check, ptr, stream_ptr
+    dg2 = torch.zeros(cols, device="cuda"); db2 = torch.zeros(cols, device="cuda")
+    check(G.lib().bltvqg_layernorm_bwd(G.DT[dtype], ptr(dy.cuda()), ptr(x.cuda()), ptr(gamma.cuda()), ptr(mean), ptr(rstd), ptr(buf), ptr(buf),
+                                       ptr(dg2), ptr(db2), rows, cols, stream_ptr()), "ln_bwd")
+    assert torch.equal(buf, dx)
+
+
+# --------------------------------------------------------------------------------------------------------------
+def _attn_ref(Q, K, V, key_ids, B, h, Tq, Tk, d, causal, scale, keep=None, p=0.0):
+    """Q [B*Tq, h*d] etc. fp32 tensors with requires_grad; mirrors transformer_layers.py:494-526."""
+    q = Q.view(B, Tq, h, d).permute(0, 2, 1, 3) * scale
+    k = K.view(B, Tk, h, d).permute(0, 2, 1, 3)
+    v = V.view(B, Tk, h, d).permute(0, 2, 1, 3)
+    logits = q @ k.transpose(-1, -2)
+    mask = key_ids.eq(0).view(B, 1, 1, Tk).expand(B, 1, Tq, Tk)
+    if causal:
+        mask = mask | torch.triu(torch.ones(Tq, Tk, dtype=torch.bool), 1).view(1, 1, Tq, Tk)
+    logits = logits.masked_fill(mask, -1e18)
+    w = torch.softmax(logits, -1)
+    if keep is not None:
+        w = w * keep / (1 - p)
+    return (w @ v).permute(0, 2, 1, 3).reshape(B * Tq, h * d)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [dict(B=3, h=4, Tq=5, Tk=5, d=16, causal=False), dict(B=2, h=8, Tq=20, Tk=20, d=64, causal=True),
+                                  dict(B=4, h=4, Tq=20, Tk=5, d=32, causal=False), dict(B=2, h=2, Tq=21, Tk=21, d=64, causal=False)])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_fwd_bwd(dtype, case, p):
+    import gpu_ops as G
+    B, h, Tq, Tk, d, causal = case["B"], case["h"], case["Tq"], case["Tk"], case["d"], case["causal"]
+    Hd = h * d
+    g = torch.Generator().manual_seed(B * 100 + Tq)
+    packed = Tq == Tk
+    if packed:      # self-attention reads Q, K, V out of one [M, 3H] projection buffer
+        qkv = torch.randn(B * Tq, 3 * Hd, generator=g).to(dtype)
+        Q, K, V = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
+    else:
+        Q = torch.randn(B * Tq, Hd, generator=g).to(dtype)
+        kv = torch.randn(B * Tk, 2 * Hd, generator=g).to(dtype)
+        K, V = kv[:, :Hd], kv[:, Hd:]
+    ids = torch.randint(1, 50, (B, Tk), generator=g, dtype=torch.int32)
+    ids[0, Tk - 2:] = 0
+    if not causal:
+        ids[1, :] = 0          # a fully masked key row -> uniform attention, no NaN (masked value is -1e18, not -inf)
+    dO = torch.randn(B * Tq, Hd, generator=g).to(dtype)
+    scale = d ** -0.5
+    seed, sid = 99, 1003
+    keep = None
+    if p > 0:
+        keep = G.dropout_mask(seed, sid, B * h * Tq, Tk, Tk, p).cpu().float().view(B, h, Tq, Tk)
+    Qr, Kr, Vr = [t.float().clone().requires_grad_(True) for t in (Q, K, V)]
+    ref = _attn_ref(Qr, Kr, Vr, ids, B, h, Tq, Tk, d, causal, scale, keep, p)
+    ref.backward(dO.float())
+    if packed:
+        qd = qkv.cuda()
+        Qd, Kd, Vd = qd[:, :Hd], qd[:, Hd:2 * Hd], qd[:, 2 * Hd:]
+    else:
+        Qd = Q.cuda(); kd = kv.cuda(); Kd, Vd = kd[:, :Hd], kd[:, Hd:]
+    O = G.attn_fwd(Qd, Kd, Vd, ids.cuda(), B, h, Tq, Tk, d, causal, scale, p, seed, sid)
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.isfinite(O.float()).all()
+    assert torch.allclose(O.float().cpu(), ref.detach(), atol=tol * 4, rtol=tol)
+    dQ, dK, dV = G.attn_bwd(Qd, Kd, Vd, dO.cuda(), ids.cuda(), B, h, Tq, Tk, d, causal, scale, p, seed, sid)
+    for got, want in ((dQ, Qr.grad), (dK, Kr.grad), (dV, Vr.grad)):
+        assert torch.allclose(got.float().cpu(), want, atol=tol * 8, rtol=tol * 4)
+
+
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("V", [97, 8000])
+def test_cross_entropy_and_bow(dtype, V):
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, ptr, stream_ptr
+    lib = G.lib()
+    B, T = 6, 20
+    M = B * T
+    ld = (V + 7) // 8 * 8
+    g = torch.Generator().manual_seed(V)
+    logits = (torch.randn(M, V, generator=g) * 3).to(dtype)
+    target = torch.randint(1, V, (B, T), generator=g)
+    target[:, 15:] = 0
+    target[2, 3:] = 0
+    count = torch.tensor([float((target != 0).sum())])
+    lr = logits.float().clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(lr, target.reshape(-1), ignore_index=0)
+    loss_ref.backward()
+    buf = torch.zeros(M, ld, dtype=dtype, device="cuda"); buf[:, :V] = logits.cuda()
+    buf[:, V:] = 7.0       # garbage in the pad columns must be zeroed by the gradient write
+    loss = torch.zeros(1, device="cuda")
+    check(lib.bltvqg_ce_fwd_bwd(G.DT[dtype], ptr(buf), ld, ptr(target.reshape(-1).int().cuda()), M, V, ptr(count.cuda()), 1.0, ptr(loss), 1,
+                                stream_ptr()), "ce")
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert abs(float(loss) - float(loss_ref)) < tol * 10
+    assert torch.allclose(buf[:, :V].float().cpu(), lr.grad, atol=tol / 5, rtol=tol * 5)
+    assert float(buf[:, V:].float().abs().sum()) == 0.0
+    # bag-of-words CE (train_iq.py:92-94)
+    z = (torch.randn(B, V, generator=g) * 2).to(dtype)
+    zr = z.float().clone().requires_grad_(True)
+    rep = zr.unsqueeze(1).repeat(1, T, 1)
+    aux_ref = F.cross_entropy(rep.reshape(-1, V), target.reshape(-1), ignore_index=0)
+    aux_ref.backward()
+    zb = torch.zeros(B, ld, dtype=dtype, device="cuda"); zb[:, :V] = z.cuda()
+    dz = torch.empty_like(zb)
+    aux = torch.zeros(1, device="cuda")
+    check(lib.bltvqg_bow_ce_fwd_bwd(G.DT[dtype], ptr(zb), ld, ptr(target.reshape(-1).int().cuda()), B, T, V, ptr(count.cuda()), 1.0, ptr(aux),
+                                    ptr(dz), stream_ptr()), "bow")
+    assert abs(float(aux) - float(aux_ref)) < tol * 10
+    assert torch.allclose(dz[:, :V].float().cpu(), zr.grad, atol=tol / 2, rtol=tol * 5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_latent_and_mse(dtype):
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from oracle.iq_oracle import gaussian_kld
+    lib = G.lib()
+    B, Z = 10, 64
+    g = torch.Generator().manual_seed(8)
+    mlvp = (torch.randn(B, 2 * Z, generator=g) * 0.7).to(dtype)
+    mlvq = (torch.randn(B, 2 * Z, generator=g) * 0.7).to(dtype)
+    eps = torch.randn(B, Z, generator=g)
+    dz = torch.randn(B, Z, generator=g).to(dtype)
+    pr, qr = mlvp.float().clone().requires_grad_(True), mlvq.float().clone().requires_grad_(True)
+    kld_ref = gaussian_kld(qr[:, :Z], qr[:, Z:], pr[:, :Z], pr[:, Z:]).mean()
+    z_ref = eps * torch.exp(0.5 * qr[:, Z:]) + qr[:, :Z]
+    gk = 0.37
+    (gk * kld_ref + (z_ref * dz.float()).sum()).backward()
+    z = torch.empty(B, Z, dtype=dtype, device="cuda"); kld = torch.zeros(1, device="cuda")
+    check(lib.bltvqg_latent_fwd(G.DT[dtype], ptr(mlvp.cuda()), ptr(mlvq.cuda()), ptr(eps.cuda()), ptr(z), ptr(kld), B, Z, 2 * Z, stream_ptr()), "latent_fwd")
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    assert torch.allclose(z.float().cpu(), z_ref.detach(), atol=tol * 4, rtol=tol)
+    assert abs(float(kld) - float(kld_ref)) < max(tol, 1e-4) * max(1.0, abs(float(kld_ref)))
+    dp = torch.empty(B, 2 * Z, dtype=dtype, device="cuda"); dq = torch.empty(B, 2 * Z, dtype=dtype, device="cuda")
+    check(lib.bltvqg_latent_bwd(G.DT[dtype], ptr(mlvp.cuda()), ptr(mlvq.cuda()), ptr(eps.cuda()), ptr(dz.cuda()), gk, ptr(dp), ptr(dq), B, Z, 2 * Z,
+                                stream_ptr()), "latent_bwd")
+    assert torch.allclose(dp.float().cpu(), pr.grad, atol=tol * 2, rtol=tol * 4)
+    assert torch.allclose(dq.float().cpu(), qr.grad, atol=tol * 2, rtol=tol * 4)
+    # MSE with gradient to both arguments (train_iq.py:84)
+    a, b = torch.randn(B, 72, generator=g).to(dtype), torch.randn(B, 72, generator=g).to(dtype)
+    ar, br = a.float().clone().requires_grad_(True), b.float().clone().requires_grad_(True)
+    l_ref = F.mse_loss(ar, br); (0.1 * l_ref).backward()
+    da, db = torch.empty_like(a, device="cuda"), torch.empty_like(b, device="cuda")
+    l = torch.zeros(1, device="cuda")
+    check(lib.bltvqg_mse_fwd_bwd(G.DT[dtype], ptr(a.cuda()), ptr(b.cuda()), B * 72, 0.1, ptr(l), ptr(da), ptr(db), stream_ptr()), "mse")
+    assert abs(float(l) - float(l_ref)) < 1e-5 * max(1.0, float(l_ref))
+    assert torch.allclose(da.float().cpu(), ar.grad, atol=tol / 10, rtol=tol) and torch.allclose(db.float().cpu(), br.grad, atol=tol / 10, rtol=tol)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_embedding_gather_scatter(dtype):
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, ptr, stream_ptr
+    lib = G.lib()
+    V, E, rows, ld = 50, 20, 300, 32
+    g = torch.Generator().manual_seed(9)
+    table = torch.randn(V, E, generator=g)
+    ids = torch.randint(0, V, (rows,), generator=g, dtype=torch.int32)
+    out = torch.full((rows, ld), 5.0, dtype=dtype, device="cuda")
+    check(lib.bltvqg_embed_gather(G.DT[dtype], ptr(table.cuda()), ptr(ids.cuda()), ptr(out), rows, E, ld, stream_ptr()), "gather")
+    assert torch.equal(out[:, :E].float().cpu(), table[ids.long()].to(dtype).float())
+    assert float(out[:, E:].float().abs().sum()) == 0.0
+    d = _ints((rows, ld), -2, 2, g, torch.float32).to(dtype)
+    dtab = torch.zeros(V, E, device="cuda")
+    check(lib.bltvqg_embed_scatter(G.DT[dtype], ptr(d.cuda()), ld, ptr(ids.cuda()), ptr(dtab), rows, E, 0, stream_ptr()), "scatter")
+    ref = torch.zeros(V, E)
+    ref.index_add_(0, ids.long(), d[:, :E].float())
+    ref[0] = 0          # padding_idx row receives no gradient (iq.py:72)
+    assert torch.equal(dtab.cpu(), ref)
+
+
+def test_adam_with_clip_matches_torch():
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, ptr, stream_ptr
+    lib = G.lib()
+    n = 10007
+    g = torch.Generator().manual_seed(10)
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    p = p0.cuda(); m = torch.zeros(n, device="cuda"); v = torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n, generator=g) * (3.0 if step == 2 else 0.01)
+        pr.grad = grad.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        lr = 1e-3 * step
+        for gp in opt.param_groups:
+            gp["lr"] = lr
+        opt.step()
+        gd = grad.cuda()
+        nsq = torch.zeros(1, device="cuda")
+        check(lib.bltvqg_sumsq(ptr(gd), n, ptr(nsq), stream_ptr()), "sumsq")
+        assert abs(float(nsq) - float((grad.double() ** 2).sum())) < 1e-4 * float((grad.double() ** 2).sum())
+        check(lib.bltvqg_adam_step(ptr(p), ptr(gd), ptr(m), ptr(v), n, ptr(nsq), 5.0, lr, 0.9, 0.999, 1e-8, step, stream_ptr()), "adam")
+        assert torch.allclose(p.cpu(), pr.detach(), atol=2e-6, rtol=1e-5)

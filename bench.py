@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-question pairs/s of the BLT-VQG IQ train step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one full reference training step (train_iq.py:105-132 + Lightning's backward / clip 5 / Adam) on one synthetic
+minibatch per GPU, inputs already resident in HBM: frozen ResNet-18 forward (train-mode BatchNorm), both transformer
+encoders, latent, decoder, losses, the whole backward, gradient all-reduce (N > 1), clip + Adam.  Dropout is on at the
+reference's 0.1/0.1.  Workload at N=1 = BASELINE.json configs[1]: the 2-layer d_model=256 model at batch 128, bf16.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+CONFIGS = {
+    # BASELINE.json configs[0]/[1]: train_iq.py defaults-shaped model (small)
+    "small": dict(hidden_dim=256, pwffn_dim=512, latent_dim=256, emb_dim=300, num_layers=2, num_heads=4, vocab_size=8000, batch=128),
+    # BASELINE.json configs[2]/[3]: 6-layer d_model=512 8-head (big)
+    "big": dict(hidden_dim=512, pwffn_dim=2048, latent_dim=512, emb_dim=300, num_layers=6, num_heads=8, vocab_size=8000, batch=256),
+}
+# algorithmic FLOP per pair per train step: CNN fwd x1 + everything trainable x3
+FLOP_PER_PAIR = {"small": 4.25e9, "big": 9.95e9}
+MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="small", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--phase", type=int, default=2, choices=[1, 2], help="1 = pre-training (latent off), 2 = latent on")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, phase2, batch, steps):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host cores:
+    full train step (forward, losses, backward, clip, Adam) on the same synthetic workload at a bounded batch."""
+    from types import SimpleNamespace
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from oracle import iq_oracle as O
+    from synth import synth_state
+    import bltvqg_amd.synthetic as synthetic
+    ns = SimpleNamespace(emb_dim=cfg["emb_dim"], hidden_dim=cfg["hidden_dim"], latent_dim=cfg["latent_dim"], pwffn_dim=cfg["pwffn_dim"],
+                         num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], vocab_size=cfg["vocab_size"])
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    state = synth_state(O.iq_spec(ns), seed=1)
+    P = O.clone_params(state)
+    names = O.trainable_names(P)
+    opt = torch.optim.Adam([P[n] for n in names], lr=1e-4)
+    hp = O.default_hp()
+    b = synthetic.make_batch(batch, ns.vocab_size, ns.latent_dim, seed=1234)
+    gen = torch.Generator().manual_seed(7)
+    times = []
+    for i in range(steps + 1):
+        t0 = time.perf_counter()
+        masks = None
+        out, z_logit, kld, recon, _ = O.iq_forward(P, ns, b["images"], b["answers"], b["posteriors"], b["questions"], phase2,
+                                                   torch.randn(batch, ns.latent_dim, generator=gen), masks, 0.0, True, {})
+        loss, _ = O.calculate_losses(out, recon, kld, z_logit, b["questions"], phase2, 100, hp)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_([P[n] for n in names if P[n].grad is not None], 5.0)
+        opt.step()
+        if i > 0:
+            times.append(time.perf_counter() - t0)
+    t = sorted(times)[len(times) // 2]
+    return dict(value=round(batch / t, 2), unit="pairs/s", cores=cores, kind="port",
+                sample="%d timed train steps (median) of the CPU oracle at batch %d, fp32, dropout off, same model config and synthetic inputs"
+                       % (steps, batch))
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import bltvqg_amd.synthetic as synthetic
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import DataParallelStep, init_reference_style
+
+    cfg = dict(CONFIGS[a.config])
+    B = a.batch or cfg.pop("batch")
+    cfg.pop("batch", None)
+    phase2 = a.phase == 2
+    c = make_config(B, cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"], cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"],
+                    cfg["vocab_size"], dtype=1 if a.dtype == "bf16" else 0)
+    eng = StepEngine(c, dev)
+    eng.allocate()
+    init_reference_style(eng, seed=0)                      # same weights on every rank
+    step = DataParallelStep(eng, dist if world > 1 else None)
+    batch = synthetic.make_batch(B, cfg["vocab_size"], cfg["latent_dim"], seed=1234 + rank)
+    d = {k: v.to(dev) for k, v in batch.items() if k in ("images", "answers", "posteriors", "questions")}
+    gen = torch.Generator(device=dev).manual_seed(99 + rank)
+
+    def one_step(i):
+        eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+        step.run(d["images"], d["answers"], d["posteriors"], d["questions"], eps, phase2, seed=1000 + i,
+                 kl_weight=0.5, lr=1e-4, max_norm=5.0)
+
+    for i in range(a.warmup):
+        one_step(i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.profile_enable(True)
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(a.warmup + i)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    conv_ms, conv_launches, conv_flops = eng.profile_read()
+    eng.profile_enable(False)
+    if dist:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    stats = eng.stats()
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = B * world * a.steps / dt
+        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        out = {
+            "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "IQ train step (fwd+loss+bwd+clip+Adam), %s cfg: %d-layer d_model=%d, per-GPU batch %d, 224x224 images, "
+                                   "T=20/S_a=5/S_p=21, V=%d, phase %d, dropout 0.1" % (a.config, cfg["num_layers"], cfg["hidden_dim"], B,
+                                                                                         cfg["vocab_size"], a.phase),
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "loss_rec": round(stats["rec"], 4),
+                       "model_tflops": round(value * FLOP_PER_PAIR[a.config] / 1e12, 2)},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "kernel": "gemm_kernel<bf16,*,*,conv> (implicit-GEMM conv of the ResNet-18 stack)",
+                         "launches_per_step": conv_launches // max(a.steps, 1),
+                         "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
+                         "kernel_share_of_step": round(conv_ms / (dt * 1e3), 4)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, phase2, a.cpu_batch, a.cpu_steps)
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

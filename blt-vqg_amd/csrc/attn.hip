@@ -117,7 +117,12 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnArgs a) {
     if (lane < a.Tq) {
         float delta = 0.f;
         for (int j = 0; j < a.Tk; ++j) delta += dS[lane * tp + j] * Pn[lane * tp + j];
-        for (int j = 0; j < a.Tk; ++j) dS[lane * tp + j] = Pn[lane * tp + j] * (dS[lane * tp + j] - delta) * a.scale;
+        for (int j = 0; j < a.Tk; ++j) {
+            // masked_fill REPLACES the logit, so no gradient reaches a masked position — this matters for a fully
+            // masked row, whose probabilities are uniform (non-zero) rather than 0
+            const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal && j > lane);
+            dS[lane * tp + j] = masked ? 0.f : Pn[lane * tp + j] * (dS[lane * tp + j] - delta) * a.scale;
+        }
     }
     __syncthreads();
     T* dQ = (T*)a.dQ;

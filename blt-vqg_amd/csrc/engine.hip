@@ -95,6 +95,11 @@ struct bltvqg_engine {
     void *gA, *gB, *gC, *gF, *gQKV, *gKV, *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
     void *g_b1, *g_b2, *g_b3, *g_b4, *g_cat, *g_mq;   // small [B, *] scratch
     hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+    // optional in-stream timing of the dominant kernel (implicit-GEMM conv): one event pair per launch
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_a, prof_b;
+    size_t prof_n = 0;
+    double prof_flops = 0.0;
     int64_t bucket_off[3], bucket_len[3];
     int bucket_late[3];
 
@@ -106,7 +111,7 @@ struct bltvqg_engine {
         p.dims[0] = r; p.dims[1] = cdim;
         p.numel = (int64_t)r * (cdim ? cdim : 1);
         p.off = tsize;
-        tsize += (p.numel + 3) / 4 * 4;
+        tsize += (p.numel + 7) / 8 * 8;    // 16-byte aligned in the bf16 shadow as well
         ti[n] = (int)tp.size();
         tp.push_back(p);
     }
@@ -469,7 +474,20 @@ struct bltvqg_engine {
         g.cg.Hi = cs.Hi; g.cg.Wi = cs.Wi; g.cg.Cin = cs.CinPad; g.cg.cin_log2 = ilog2(cs.CinPad); g.cg.Ho = cs.Ho; g.cg.Wo = cs.Wo;
         g.cg.KH = cs.K; g.cg.KW = cs.K; g.cg.stride = cs.stride; g.cg.pad = cs.pad;
         g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+        if (prof_on) {
+            if (prof_n == prof_a.size()) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { blt_set_error("profile: event creation failed"); return BLT_ERR_HIP; }
+                prof_a.push_back(a); prof_b.push_back(b);
+            }
+            (void)hipEventRecord(prof_a[prof_n], s);
+        }
         RC(blt_gemm(dt, g, s));
+        if (prof_on) {
+            (void)hipEventRecord(prof_b[prof_n], s);
+            ++prof_n;
+            prof_flops += 2.0 * (double)g.M * (double)cs.Cout * (double)(cs.K * cs.K * cs.Cin);   // algorithmic (unpadded Cin)
+        }
         const int nparts = blt_gemm_stat_rows(g);
         return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)g.M, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
                                0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,
@@ -839,6 +857,7 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
 void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (!e) return;
     for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
+    for (size_t i = 0; i < e->prof_a.size(); ++i) { (void)hipEventDestroy(e->prof_a[i]); (void)hipEventDestroy(e->prof_b[i]); }
     delete e;
 }
 
@@ -939,6 +958,31 @@ int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
 }
 
 uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site) { return (uint32_t)(stack * 1000 + layer * 10 + site); }
+
+int bltvqg_engine_profile_enable(bltvqg_engine* e, int on) {
+    BLT_REQUIRE(e, "engine_profile_enable: null engine");
+    e->prof_on = on != 0;
+    e->prof_n = 0;
+    e->prof_flops = 0.0;
+    return BLT_OK;
+}
+
+int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host) {
+    BLT_REQUIRE(e && total_ms_host && launches_host && flops_host, "engine_profile_read: bad args");
+    double total = 0.0;
+    for (size_t i = 0; i < e->prof_n; ++i) {
+        if (hipEventSynchronize(e->prof_b[i]) != hipSuccess) { blt_set_error("engine_profile_read: event sync failed"); return BLT_ERR_HIP; }
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->prof_a[i], e->prof_b[i]) != hipSuccess) { blt_set_error("engine_profile_read: elapsed failed"); return BLT_ERR_HIP; }
+        total += ms;
+    }
+    *total_ms_host = total;
+    *launches_host = (int32_t)e->prof_n;
+    *flops_host = e->prof_flops;
+    e->prof_n = 0;
+    e->prof_flops = 0.0;
+    return BLT_OK;
+}
 
 int bltvqg_engine_num_buckets(const bltvqg_engine* e) { return e ? 3 : 0; }
 int bltvqg_engine_bucket_info(const bltvqg_engine* e, int i, int64_t* offset, int64_t* numel, int32_t* late) {

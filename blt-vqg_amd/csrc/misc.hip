@@ -132,12 +132,13 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
 }
 
 template <typename TS, typename TD>
-__global__ void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __restrict__ dst, int ldd, long rows, int cols) {
-    const long total = rows * ldd;
+__global__ void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __restrict__ dst, int ldd, long rows, int cols, int width) {
+    // width = ldd: columns [cols, ldd) are zero-filled (padded operand); width = cols: plain strided 2-D copy
+    const long total = rows * width;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / ldd;
-        const int c = (int)(i - r * ldd);
-        dst[i] = from_f32<TD>(c < cols ? to_f32(src[r * lds_ + c]) : 0.f);
+        const long r = i / width;
+        const int c = (int)(i - r * width);
+        dst[r * ldd + c] = from_f32<TD>(c < cols ? to_f32(src[r * lds_ + c]) : 0.f);
     }
 }
 
@@ -417,24 +418,30 @@ int blt_colsum(int dtype, const void* x, int ld, long M, int N, float* out, int 
     return blt_check_launch("colsum");
 }
 
-int blt_cast_rows(int dtype_src, const void* src, int lds_, int dtype_dst, void* dst, int ldd, long rows, int cols, hipStream_t s) {
+static int cast_rows_impl(int dtype_src, const void* src, int lds_, int dtype_dst, void* dst, int ldd, long rows, int cols, int width, hipStream_t s) {
     CHECK_DTYPE(dtype_src, "cast_rows");
     CHECK_DTYPE(dtype_dst, "cast_rows");
     BLT_REQUIRE(src && dst && rows > 0 && cols > 0 && lds_ >= cols && ldd >= cols, "cast_rows: bad args");
-    const dim3 g(ew_grid(rows * ldd)), b(256);
-    if (dtype_src == BLT_F32 && dtype_dst == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<float, float>), g, b, 0, s, (const float*)src, lds_, (float*)dst, ldd, rows, cols);
-    else if (dtype_src == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<float, bf16>), g, b, 0, s, (const float*)src, lds_, (bf16*)dst, ldd, rows, cols);
-    else if (dtype_dst == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<bf16, float>), g, b, 0, s, (const bf16*)src, lds_, (float*)dst, ldd, rows, cols);
-    else hipLaunchKernelGGL((cast_rows_kernel<bf16, bf16>), g, b, 0, s, (const bf16*)src, lds_, (bf16*)dst, ldd, rows, cols);
+    const dim3 g(ew_grid(rows * width)), b(256);
+    if (dtype_src == BLT_F32 && dtype_dst == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<float, float>), g, b, 0, s, (const float*)src, lds_, (float*)dst, ldd, rows, cols, width);
+    else if (dtype_src == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<float, bf16>), g, b, 0, s, (const float*)src, lds_, (bf16*)dst, ldd, rows, cols, width);
+    else if (dtype_dst == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<bf16, float>), g, b, 0, s, (const bf16*)src, lds_, (float*)dst, ldd, rows, cols, width);
+    else hipLaunchKernelGGL((cast_rows_kernel<bf16, bf16>), g, b, 0, s, (const bf16*)src, lds_, (bf16*)dst, ldd, rows, cols, width);
     return blt_check_launch("cast_rows");
+}
+
+// dst[r, 0:cols] = cast(src[r, 0:cols]); dst[r, cols:ldd] = 0
+int blt_cast_rows(int dtype_src, const void* src, int lds_, int dtype_dst, void* dst, int ldd, long rows, int cols, hipStream_t s) {
+    return cast_rows_impl(dtype_src, src, lds_, dtype_dst, dst, ldd, rows, cols, ldd, s);
 }
 
 int blt_cast_pad(const float* src, int rows, int cols, void* dst, int ld, int dtype, hipStream_t s) {
     return blt_cast_rows(BLT_F32, src, cols, dtype, dst, ld, rows, cols, s);
 }
 
+// strided 2-D copy: only columns [0, cols) of each destination row are written
 int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long rows, int cols, hipStream_t s) {
-    return blt_cast_rows(dtype, src, lds_, dtype, dst, ldd, rows, cols, s);
+    return cast_rows_impl(dtype, src, lds_, dtype, dst, ldd, rows, cols, cols, s);
 }
 
 int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, hipStream_t s) {

@@ -153,6 +153,15 @@ class StepEngine(object):
         s = self.read(4).tolist()
         return dict(rec=s[0], img=s[1], kld=s[2], aux=s[3], grad_norm=s[4] ** 0.5, n_targets=s[5])
 
+    def profile_enable(self, on=True):
+        check(self.lib.bltvqg_engine_profile_enable(self.h, 1 if on else 0), "profile_enable")
+
+    def profile_read(self):
+        """(total conv-kernel ms, launches, algorithmic flops) since the last read; synchronises on the recorded events."""
+        ms, n, fl = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
+        check(self.lib.bltvqg_engine_profile_read(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "profile_read")
+        return ms.value, n.value, fl.value
+
     def buckets(self):
         out = []
         off, n, late = _lib.L(), _lib.L(), ctypes.c_int32()

@@ -1,0 +1,101 @@
+"""Host-side step driver: reference-style initialisation, the fused train step and its data-parallel form.
+
+Data parallelism mirrors what `pl.Trainer(gpus=N)` gives the reference (train_iq.py:372-373: Lightning DDP = one process per
+GPU, gradient mean across ranks, BatchNorm statistics per replica), re-designed for xGMI: the engine writes gradients into ONE
+flat fp32 buffer laid out in backward-completion order, so the exchange is three large all-reduces (decoder | encoder+embedding+
+CNN head | phase-2-only parameters) issued on a side stream as soon as the engine's bucket events fire, overlapping the rest of
+backward; the optimiser step waits for the side stream.
+"""
+import math
+
+import torch
+
+
+def noam_lr(step, hidden_dim, warmup_steps=4000):
+    """TrainIQ.custom_optimizer (reference train_iq.py:252-257); 0 at step 0."""
+    return math.sqrt(1.0 / hidden_dim) * min(math.sqrt(1.0 / (step + 1)), step * warmup_steps ** -1.5)
+
+
+def kl_weight(kliter, full_kl_step):
+    """reference train_iq.py:96-97."""
+    return min(math.tanh(6.0 * kliter / full_kl_step - 3.0) + 1.0, 1.0)
+
+
+def init_reference_style(eng, seed=0, resnet_state=None):
+    """Fills the engine's flat buffers with the reference's initialisers (distributions, not its RNG stream):
+    nn.Linear default U(+-1/sqrt(fan_in)) (iq.py:76, transformer_layers.py:453-456, ...), embedding randn*0.01 (iq.py:58),
+    cnn.fc N(0, 0.02) / bias 0 (encoder_cnn.py:24-28), MLP He-normal / bias 0 (mlp.py:37-38), LayerNorm/BatchNorm 1/0.
+    The backbone is `resnet18(pretrained=True)` in the reference (encoder_cnn.py:17); those weights cannot be fetched here, so
+    it is He-initialised unless `resnet_state` (a torchvision-format state dict) is given."""
+    g = torch.Generator(device="cpu").manual_seed(int(seed))
+    dev = eng.device
+    with torch.no_grad():
+        for name, info in eng.train_info.items():
+            v = eng.view(name, 0)
+            shape = info.shape
+            if name == "embedding.0.weight":
+                t = torch.randn(shape, generator=g) * 0.01
+            elif name == "encoder_cnn.cnn.fc.weight":
+                t = torch.randn(shape, generator=g) * 0.02
+            elif name.startswith("image_reconstructor") and name.endswith("weight"):
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / shape[1])
+            elif name in ("encoder_cnn.cnn.fc.bias",) or (name.startswith("image_reconstructor") and name.endswith("bias")):
+                t = torch.zeros(shape)
+            elif "layer_norm" in name or name.startswith("encoder_cnn.bn."):
+                t = torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)
+            elif len(shape) == 2:
+                bound = 1.0 / math.sqrt(shape[1])
+                t = (torch.rand(shape, generator=g) * 2 - 1) * bound
+            else:   # bias of an nn.Linear: U(+-1/sqrt(fan_in)) with the fan_in of its weight
+                wname = name[:-4] + "weight"
+                fan_in = eng.train_info[wname].shape[1]
+                t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+            v.copy_(t.to(dev))
+        for name, info in eng.frozen_info.items():
+            v = eng.view(name, 1)
+            shape = info.shape
+            key = name[len("encoder_cnn.cnn."):] if name.startswith("encoder_cnn.cnn.") else None
+            if resnet_state is not None and key in resnet_state:
+                t = resnet_state[key].float()
+            elif len(shape) == 4:
+                fan_out = shape[0] * shape[2] * shape[3]
+                t = torch.randn(shape, generator=g) * math.sqrt(2.0 / fan_out)
+            elif name.endswith("running_var") or name.endswith(".weight"):
+                t = torch.ones(shape)
+            else:
+                t = torch.zeros(shape)
+            v.copy_(t.to(dev))
+    eng.lib.bltvqg_engine_invalidate_frozen(eng.h)
+
+
+class DataParallelStep(object):
+    """forward -> fused losses + backward -> (overlapped gradient all-reduce) -> clip + Adam."""
+
+    def __init__(self, engine, dist=None):
+        self.e = engine
+        self.dist = dist
+        self.comm = torch.cuda.Stream(device=engine.device) if dist is not None else None
+        self.buckets = engine.buckets()
+        if dist is not None:
+            # one-time parameter broadcast from rank 0 (DDP does the same at construction)
+            dist.broadcast(engine.flat_train, 0)
+            dist.broadcast(engine.flat_frozen, 0)
+
+    def reduce_gradients(self, phase2):
+        e, dist = self.e, self.dist
+        main = torch.cuda.current_stream(e.device)
+        for i, (off, n, late) in enumerate(self.buckets):
+            if late and not phase2:
+                continue          # these parameters receive no gradient before the phase switch
+            e.bucket_wait(i, self.comm)
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(e.flat_grad[off:off + n], op=dist.ReduceOp.AVG)
+        main.wait_stream(self.comm)
+
+    def run(self, images, context, posterior, target, eps, phase2, seed, kl_weight, lr, max_norm=5.0):
+        e = self.e
+        e.forward(images, context, posterior, target, eps, phase2, seed)
+        e.loss_backward(kl_weight)
+        if self.dist is not None:
+            self.reduce_gradients(phase2)
+        e.optimizer_step(lr, max_norm)

@@ -163,6 +163,12 @@ int bltvqg_engine_optimizer_step(bltvqg_engine* e, float lr, float max_norm, flo
  * 5 encoder_outputs [B,S_a,H], 6 decoder_outputs [B,T,H] */
 int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream);
 uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site);
+/* In-stream timing of the dominant kernel (the implicit-GEMM convolution launches of the frozen ResNet-18 stack): while enabled,
+ * every conv launch is bracketed by a hipEvent pair on the caller's stream.  profile_read synchronises on those events and
+ * returns the summed kernel time, the number of launches and their ALGORITHMIC flops (2*M*Cout*KH*KW*Cin, unpadded) since
+ * the last read. */
+int bltvqg_engine_profile_enable(bltvqg_engine* e, int on);
+int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host);
 /* gradient buckets for data-parallel overlap: contiguous float ranges of the flat gradient buffer in the order backward
  * completes them; bltvqg_engine_bucket_wait makes `stream` wait until bucket i of the last backward is complete. */
 int bltvqg_engine_num_buckets(const bltvqg_engine* e);

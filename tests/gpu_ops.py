@@ -4,7 +4,20 @@ import ctypes
 import torch
 
 from bltvqg_amd import _lib
-from bltvqg_amd._lib import check, ptr, stream_ptr
+from bltvqg_amd._lib import check, stream_ptr
+
+_KEEP = []
+
+
+def ptr(t):
+    """Device pointer of a tensor; keeps the tensor alive so that a temporary such as ``ptr(x.cuda())`` is not returned to
+    the caching allocator (and overwritten by the next temporary) before the asynchronous kernel has consumed it."""
+    if t is None:
+        return None
+    _KEEP.append(t)
+    if len(_KEEP) > 512:
+        del _KEEP[:256]
+    return _lib.ptr(t)
 
 DT = {torch.float32: 0, torch.bfloat16: 1}
 TD = {0: torch.float32, 1: torch.bfloat16}

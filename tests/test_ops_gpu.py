@@ -138,7 +138,7 @@ def test_conv2d_exact_integer_and_stats(dtype, geom):
 def test_batchnorm2d_train_pipeline(dtype):
     """conv statistics -> finalize (scale/shift + running stats) -> apply(+residual, relu) / relu+maxpool / avgpool."""
     import gpu_ops as G
-    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from gpu_ops import check, ptr, stream_ptr
     lib = G.lib()
     N, C, Hh, Ww = 4, 64, 12, 10
     g = torch.Generator().manual_seed(3)
@@ -181,7 +181,7 @@ def test_batchnorm2d_train_pipeline(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_batchnorm1d_fwd_bwd(dtype):
     import gpu_ops as G
-    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from gpu_ops import check, ptr, stream_ptr
     lib = G.lib()
     B, C = 24, 72
     g = torch.Generator().manual_seed(4)
@@ -232,7 +232,7 @@ def test_layernorm_fwd_bwd(dtype, shape):
     assert (dg.cpu() - gr.grad).abs().max() < tol * 4 * gs and (db.cpu() - br.grad).abs().max() < tol * 4 * gs
     # in-place residual form used by the engine: dres and dx are the same buffer
     buf = dres.cuda().clone()
-    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from gpu_ops import check, ptr, stream_ptr
     dg2 = torch.zeros(cols, device="cuda"); db2 = torch.zeros(cols, device="cuda")
     check(G.lib().bltvqg_layernorm_bwd(G.DT[dtype], ptr(dy.cuda()), ptr(x.cuda()), ptr(gamma.cuda()), ptr(mean), ptr(rstd), ptr(buf), ptr(buf),
                                        ptr(dg2), ptr(db2), rows, cols, stream_ptr()), "ln_bwd")
@@ -305,7 +305,7 @@ def test_attention_fwd_bwd(dtype, case, p):
 @pytest.mark.parametrize("V", [97, 8000])
 def test_cross_entropy_and_bow(dtype, V):
     import gpu_ops as G
-    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from gpu_ops import check, ptr, stream_ptr
     lib = G.lib()
     B, T = 6, 20
     M = B * T
@@ -346,7 +346,7 @@ def test_cross_entropy_and_bow(dtype, V):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_latent_and_mse(dtype):
     import gpu_ops as G
-    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from gpu_ops import check, ptr, stream_ptr
     from oracle.iq_oracle import gaussian_kld
     lib = G.lib()
     B, Z = 10, 64
@@ -384,7 +384,7 @@ def test_latent_and_mse(dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_embedding_gather_scatter(dtype):
     import gpu_ops as G
-    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from gpu_ops import check, ptr, stream_ptr
     lib = G.lib()
     V, E, rows, ld = 50, 20, 300, 32
     g = torch.Generator().manual_seed(9)
@@ -405,7 +405,7 @@ def test_embedding_gather_scatter(dtype):
 
 def test_adam_with_clip_matches_torch():
     import gpu_ops as G
-    from bltvqg_amd._lib import check, ptr, stream_ptr
+    from gpu_ops import check, ptr, stream_ptr
     lib = G.lib()
     n = 10007
     g = torch.Generator().manual_seed(10)

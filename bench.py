@@ -58,8 +58,13 @@ def cpu_baseline(cfg, phase2, batch, steps):
     import bltvqg_amd.synthetic as synthetic
     ns = SimpleNamespace(emb_dim=cfg["emb_dim"], hidden_dim=cfg["hidden_dim"], latent_dim=cfg["latent_dim"], pwffn_dim=cfg["pwffn_dim"],
                          num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], vocab_size=cfg["vocab_size"])
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))         # the GPU box gives a 1-GPU job a 16-core share; more threads only oversubscribe
     torch.set_num_threads(cores)
+    print("[bench] cpu baseline: %d threads (os.cpu_count() = %s)" % (cores, os.cpu_count()), file=sys.stderr, flush=True)
     state = synth_state(O.iq_spec(ns), seed=1)
     P = O.clone_params(state)
     names = O.trainable_names(P)
@@ -80,6 +85,7 @@ def cpu_baseline(cfg, phase2, batch, steps):
         opt.step()
         if i > 0:
             times.append(time.perf_counter() - t0)
+        print("[bench] cpu baseline step %d: %.2f s" % (i, time.perf_counter() - t0), file=sys.stderr, flush=True)
     t = sorted(times)[len(times) // 2]
     return dict(value=round(batch / t, 2), unit="pairs/s", cores=cores, kind="port",
                 sample="%d timed train steps (median) of the CPU oracle at batch %d, fp32, dropout off, same model config and synthetic inputs"
@@ -124,9 +130,11 @@ def main():
         step.run(d["images"], d["answers"], d["posteriors"], d["questions"], eps, phase2, seed=1000 + i,
                  kl_weight=0.5, lr=1e-4, max_norm=5.0)
 
+    print("[bench] rank %d: engine ready (workspace %.2f GB), warming up" % (rank, eng.workspace_bytes / 1e9), file=sys.stderr, flush=True)
     for i in range(a.warmup):
         one_step(i)
     torch.cuda.synchronize()
+    print("[bench] rank %d: warm-up done" % rank, file=sys.stderr, flush=True)
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -139,6 +147,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    print("[bench] rank %d: %d timed steps in %.3f s" % (rank, a.steps, dt), file=sys.stderr, flush=True)
     conv_ms, conv_launches, conv_flops = eng.profile_read()
     eng.profile_enable(False)
     if dist:

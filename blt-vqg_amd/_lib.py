@@ -35,11 +35,13 @@ class Config(ctypes.Structure):
 SIGNATURES = {
     "bltvqg_version": (I, []),
     "bltvqg_last_error_string": (S, []),
-    "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, P]),
+    "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv2d_stat_rows": (I, [I, I, I, I, I, I, I, I]),
-    "bltvqg_img_pack": (I, [I, P, P, I, I, I, I, I, P]),
-    "bltvqg_conv_pack_w": (I, [I, P, P, I, I, I, I, I, P]),
+    "bltvqg_img_pack": (I, [I, P, P, I, I, I, I, I, I, I, I, I, P]),
+    "bltvqg_conv_pack_w": (I, [I, P, P, I, I, I, I, I, I, P]),
+    "bltvqg_conv_stem": (I, [I, P, P, P, I, I, I, I, I, I, P, P, P]),
+    "bltvqg_conv_stem_stat_rows": (I, [I, I, I, I]),
     "bltvqg_layernorm_fwd": (I, [I, P, P, P, P, P, P, L, I, F, P]),
     "bltvqg_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, L, I, P]),
     "bltvqg_bn_scratch_doubles": (I, [I]),

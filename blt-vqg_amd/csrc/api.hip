@@ -8,11 +8,11 @@ extern "C" {
 
 int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, int ldb, int transB, void* C, int ldc, int M, int N, int K,
                 const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id, const void* maskY, int ldm, float mask_scale,
-                const void* R, int ldr, int accumulate, int out_f32, int force_tile, void* stream) {
+                const void* R, int ldr, int accumulate, int out_f32, int force_tile, int split_k, void* stream) {
     GemmArgs g;
     g.A = A; g.lda = lda; g.transA = transA; g.B = B; g.ldb = ldb; g.transB = transB; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id; g.maskY = maskY; g.ldm = ldm;
-    g.mask_scale = mask_scale; g.R = R; g.ldr = ldr; g.accumulate = accumulate; g.out_f32 = out_f32; g.force_tile = force_tile;
+    g.mask_scale = mask_scale; g.R = R; g.ldr = ldr; g.accumulate = accumulate; g.out_f32 = out_f32; g.force_tile = force_tile; g.split_k = split_k;
     return blt_gemm(dtype, g, (hipStream_t)stream);
 }
 
@@ -41,11 +41,33 @@ int bltvqg_conv2d_stat_rows(int N, int Hi, int Wi, int Cout, int KH, int KW, int
     return blt_gemm_stat_rows(g);
 }
 
-int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, void* stream) {
-    return blt_img_pack(dtype, nchw, nhwc, N, C, H, W, Cpad, (hipStream_t)stream);
+int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, int pad_top, int pad_left, int Hp, int Wp,
+                    void* stream) {
+    return blt_img_pack(dtype, nchw, nhwc, N, C, H, W, Cpad, pad_top, pad_left, Hp, Wp, (hipStream_t)stream);
 }
-int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, void* stream) {
-    return blt_conv_pack_w(dtype, w, out, Cout, Cin, KH, KW, Cpad, (hipStream_t)stream);
+int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad, void* stream) {
+    return blt_conv_pack_w(dtype, w, out, Cout, Cin, KH, KW, Cpad, KWpad, (hipStream_t)stream);
+}
+
+// 7x7 stride-2 pad-3 stem convolution on a zero-bordered NHWC4 image [N, Hp, Wp, 4] (Hp >= H+6, Wp >= W+7 and even) with
+// weights packed [Cout, 7, 8, 4]
+int bltvqg_conv_stem(int dtype, const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, int Cout, float* stat_sum,
+                     float* stat_sq, void* stream) {
+    BLT_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0, "conv_stem: bad sizes");
+    GemmArgs g;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    g.A = x_padded; g.B = w; g.C = y;
+    g.M = N * Ho * Wo; g.N = Cout; g.K = 224;
+    g.lda = 4; g.ldb = 224; g.ldc = Cout; g.is_conv = 2;
+    g.cg.Hi = Hp; g.cg.Wi = Wp; g.cg.Cin = 4; g.cg.cin_log2 = 2; g.cg.Ho = Ho; g.cg.Wo = Wo; g.cg.KH = 7; g.cg.KW = 8; g.cg.stride = 2; g.cg.pad = 0;
+    g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+    return blt_gemm(dtype, g, (hipStream_t)stream);
+}
+int bltvqg_conv_stem_stat_rows(int N, int H, int W, int Cout) {
+    GemmArgs g;
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    g.M = N * Ho * Wo; g.N = Cout; g.K = 224;
+    return blt_gemm_stat_rows(g);
 }
 
 int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,

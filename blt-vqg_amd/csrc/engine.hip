@@ -62,6 +62,7 @@ struct bltvqg_engine {
     int dt, es;                 // dtype, element size
     int B, H, F, Z, E, L, NH, V, Sa, Sp, T;
     int Ma, Mp, Mt, Mtot, Epad, ldV, dh;
+    int imgHp = 0, imgWp = 0;   // zero-bordered NHWC4 input image of the 7x7/2 stem
     std::vector<PInfo> tp, fp;
     std::map<std::string, int> ti, fi;
     int64_t tsize = 0, late_off = 0, fsize = 0, ws_bytes = 0;
@@ -211,7 +212,7 @@ struct bltvqg_engine {
             add_f(wn, cout, cin, k, k, 4);
             add_bn(bn, cout);
             ConvSpec cs;
-            cs.wname = wn; cs.bnname = bn; cs.Cin = cin; cs.CinPad = cin < 8 ? 8 : cin; cs.Cout = cout; cs.K = k;
+            cs.wname = wn; cs.bnname = bn; cs.Cin = cin; cs.CinPad = cin < 8 ? 4 : cin; cs.Cout = cout; cs.K = k;   // the stem (Cin = 3) runs on NHWC4
             cs.stride = s; cs.pad = p; cs.Hi = h; cs.Wi = w;
             cs.Ho = (h + 2 * p - k) / s + 1;
             cs.Wo = (w + 2 * p - k) / s + 1;
@@ -260,10 +261,10 @@ struct bltvqg_engine {
         stats = AF(8);
         eps_dev = AF((int64_t)B * Z);
         // CNN
-        img = AT((int64_t)B * c.image_h * c.image_w * 8);
+        img = AT((int64_t)B * imgHp * imgWp * 4);
         int64_t max_stat = 0;
         for (auto& cs : convs) {
-            cs.wpacked = AT((int64_t)cs.Cout * cs.K * cs.K * cs.CinPad);
+            cs.wpacked = AT((int64_t)cs.Cout * cs.K * (cs.Cin < 8 ? 8 : cs.K) * cs.CinPad);
             cs.scale = AF(cs.Cout); cs.shift = AF(cs.Cout);
             cs.out = AT((int64_t)B * cs.Ho * cs.Wo * cs.Cout);
             const int64_t M = (int64_t)B * cs.Ho * cs.Wo;
@@ -324,6 +325,12 @@ struct bltvqg_engine {
         V = c.vocab_size; Sa = c.len_context; Sp = c.len_posterior; T = c.len_target;
         Ma = B * Sa; Mp = B * Sp; Mt = B * T; Mtot = Ma + Mt + Mp;
         Epad = round_up(E, 32); ldV = round_up(V, 8); dh = H / NH;
+        {
+            const int ho = (c.image_h + 6 - 7) / 2 + 1, wo = (c.image_w + 6 - 7) / 2 + 1;
+            imgHp = c.image_h + 6 > 2 * (ho - 1) + 7 ? c.image_h + 6 : 2 * (ho - 1) + 7;
+            imgWp = c.image_w + 6 > 2 * (wo - 1) + 8 ? c.image_w + 6 : 2 * (wo - 1) + 8;
+            imgWp = (imgWp + 1) / 2 * 2;
+        }
         build_params();
         enc.prefix = "answer_encoder.encoder"; enc.id = 0; enc.S = Sa; enc.M = Ma;
         renc.prefix = "answer_encoder.r_encoder"; renc.id = 1; renc.S = Sp; renc.M = Mp;
@@ -371,7 +378,7 @@ struct bltvqg_engine {
     int wgrad(const void* dY, int ldy, const void* X, int ldx, const std::string& wname, const char* bias, int M, hipStream_t s) {
         const PInfo& p = tpi(wname);
         GemmArgs g = mk(dY, ldy, 1, X, ldx, 1, G(wname), p.dims[1], p.dims[0], p.dims[1], M);
-        g.out_f32 = 1;
+        g.out_f32 = 1; g.split_k = 32;
         int rc = blt_gemm(dt, g, s);
         if (rc) return rc;
         if (bias) rc = blt_colsum(dt, dY, ldy, M, p.dims[0], G(bias), 1, s);
@@ -468,11 +475,13 @@ struct bltvqg_engine {
     int conv_fwd(ConvSpec& cs, const void* x, hipStream_t s) {
         GemmArgs g;
         g.A = x; g.B = cs.wpacked; g.C = cs.out;
-        g.M = B * cs.Ho * cs.Wo; g.N = cs.Cout; g.K = cs.K * cs.K * cs.CinPad;
+        const bool stem = cs.Cin < 8;
+        g.M = B * cs.Ho * cs.Wo; g.N = cs.Cout; g.K = stem ? 224 : cs.K * cs.K * cs.CinPad;
         g.lda = cs.CinPad; g.ldb = g.K; g.ldc = cs.Cout;
-        g.is_conv = 1;
-        g.cg.Hi = cs.Hi; g.cg.Wi = cs.Wi; g.cg.Cin = cs.CinPad; g.cg.cin_log2 = ilog2(cs.CinPad); g.cg.Ho = cs.Ho; g.cg.Wo = cs.Wo;
-        g.cg.KH = cs.K; g.cg.KW = cs.K; g.cg.stride = cs.stride; g.cg.pad = cs.pad;
+        g.is_conv = stem ? 2 : 1;
+        g.cg.Hi = stem ? imgHp : cs.Hi; g.cg.Wi = stem ? imgWp : cs.Wi;
+        g.cg.Cin = cs.CinPad; g.cg.cin_log2 = ilog2(cs.CinPad); g.cg.Ho = cs.Ho; g.cg.Wo = cs.Wo;
+        g.cg.KH = cs.K; g.cg.KW = stem ? 8 : cs.K; g.cg.stride = cs.stride; g.cg.pad = stem ? 0 : cs.pad;
         g.stat_sum = stat_sum; g.stat_sq = stat_sq;
         if (prof_on) {
             if (prof_n == prof_a.size()) {
@@ -497,10 +506,10 @@ struct bltvqg_engine {
     int cnn_fwd(const float* images, hipStream_t s) {
         if (frozen_dirty) {
             for (auto& cs : convs)
-                RC(blt_conv_pack_w(dt, FZ(cs.wname), cs.wpacked, cs.Cout, cs.Cin, cs.K, cs.K, cs.CinPad, s));
+                RC(blt_conv_pack_w(dt, FZ(cs.wname), cs.wpacked, cs.Cout, cs.Cin, cs.K, cs.K, cs.CinPad, cs.Cin < 8 ? 8 : cs.K, s));
             frozen_dirty = false;
         }
-        RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 8, s));
+        RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 4, 3, 3, imgHp, imgWp, s));
         size_t ci = 0;
         ConvSpec& c1 = convs[ci++];
         RC(conv_fwd(c1, img, s));
@@ -661,7 +670,7 @@ struct bltvqg_engine {
                 {   // key/value projections of encoder_outputs: [2H,H] fused
                     const PInfo& pk = tpi(a2 + "key_linear.weight");
                     GemmArgs g = mk(gKV, 2 * H, 1, enc_out, H, 1, grad + pk.off, H, 2 * H, H, Ma);
-                    g.out_f32 = 1;
+                    g.out_f32 = 1; g.split_k = 32;
                     RC(blt_gemm(dt, g, s));
                     int ldw;
                     const void* w = W(a2 + "key_linear.weight", &ldw);
@@ -682,7 +691,7 @@ struct bltvqg_engine {
             {
                 const PInfo& pq = tpi(a1 + "query_linear.weight");
                 GemmArgs g = mk(gQKV, 3 * H, 1, y.xn1, H, 1, grad + pq.off, H, 3 * H, H, M);
-                g.out_f32 = 1;
+                g.out_f32 = 1; g.split_k = 32;
                 RC(blt_gemm(dt, g, s));
                 int ldw;
                 const void* w = W(a1 + "query_linear.weight", &ldw);
@@ -763,7 +772,7 @@ struct bltvqg_engine {
         {
             const PInfo& pw = tpi("embedding.1.weight");
             GemmArgs g = mk(dX_all, H, 1, emb_rows, Epad, 1, grad + pw.off, E, H, E, Memb);
-            g.out_f32 = 1;
+            g.out_f32 = 1; g.split_k = 32;
             RC(blt_gemm(dt, g, s));
             RC(blt_colsum(dt, dX_all, H, Memb, H, G("embedding.1.bias"), 1, s));
             int ldw;

@@ -3,12 +3,16 @@
 //
 //   * T = bf16: v_mfma_f32_16x16x32_bf16 (8 bf16 per lane per operand), fp32 accumulate.
 //   * T = f32 : v_mfma_f32_16x16x4_f32 (exact fp32 fma chain) — the parity mode.
-//   * 256 threads = 4 waves (2x2); block tile BMxBN in {128x128, 64x64}; K-tile = 128 bytes of K per row
+//   * 256 threads = 4 waves (2x2); block tile BMxBN in {128x128, 128x64, 64x64}; K-tile = 128 bytes of K per row
 //     (64 bf16 / 32 f32); double-buffered LDS, register-staged prefetch (global->VGPR issued before the
 //     MFMAs of the current tile, VGPR->LDS after them), one barrier per K-tile.
 //   * An operand keeps its GLOBAL orientation in LDS: k-contiguous operands are read with ds_read_b128
 //     (bf16) / ds_read_b32 (f32); m/n-contiguous ("transposed") operands are read with ds_read_b64_tr_b16
 //     (bf16, hardware transpose) / ds_read_b32 (f32).  No operand is ever transposed in HBM.
+//   * A-operand loaders: plain matrix, NHWC implicit-GEMM gather (3x3 / 1x1 convs), and the 7x7/2 stem conv on a
+//     zero-bordered NHWC4 image (no bounds checks, K = 7 rows x 8 pixels x 4 channels).
+//   * split-K (gridDim.y slices of the K loop, fp32 atomic accumulation) for weight-gradient GEMMs whose output has too
+//     few tiles to fill 256 CUs.
 //   * The accumulators go through LDS once so that the epilogue (bias, position table, ReLU, dropout,
 //     ReLU/dropout-backward mask, residual, accumulate, BN column statistics) runs on 8 consecutive columns per
 //     thread and stores 16 bytes per lane.
@@ -19,6 +23,8 @@
 
 namespace {
 
+enum { LD_PLAIN = 0, LD_CONV = 1, LD_STEM = 2 };
+
 template <typename T> struct Frag;
 template <> struct Frag<bf16> { typedef bf16x8 type; };
 template <> struct Frag<float> { typedef float type; };
@@ -27,21 +33,160 @@ __device__ __forceinline__ s16x4 lds_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
 }
 
-template <typename T, int BM, int BN, bool TA, bool TB, bool CONV>
+template <typename T, int BM_, int BN_, bool TA_, bool TB_, int LOADER_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, LOADER = LOADER_;
+    static constexpr bool TA = TA_, TB = TB_;
+    static constexpr int ES = sizeof(T);
+    static constexpr int CE = 16 / ES;           // elements per 16-byte chunk
+    static constexpr int BK = 128 / ES;          // K elements per tile (128 bytes per row)
+    static constexpr int KSTEP = (ES == 2) ? 32 : 4;
+    static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    static constexpr int SA = 144;               // row stride (bytes) of a k-contiguous LDS image: 128 + 16 pad
+    static constexpr int SAT = BM * ES + 16;     // row stride of an m-contiguous image [BK][BM]
+    static constexpr int SBT = BN * ES + 16;
+    static constexpr int A_BYTES = TA ? BK * SAT : BM * SA;
+    static constexpr int B_BYTES = TB ? BK * SBT : BN * SA;
+    static constexpr int STAGE = A_BYTES + B_BYTES;
+    static constexpr int CH_A = BM * 8 / 256, CH_B = BN * 8 / 256;
+    static constexpr int CS = BN + 4;            // fp32 C-tile row stride (floats)
+    static constexpr int LDS_BYTES = (2 * STAGE > BM * CS * 4) ? 2 * STAGE : BM * CS * 4;
+};
+
+// per-thread geometry of the rows a thread stages for the implicit-GEMM loaders
+template <int CH>
+struct ConvRows {
+    int base[CH], h0[CH], w0[CH];
+};
+
+template <typename C, typename T>
+__device__ __forceinline__ void load_a(const GemmArgs& p, const T* __restrict__ Ag, const ConvRows<C::CH_A>& cr, int m0, int k0, int tid,
+                                       uint4 (&ra)[C::CH_A]) {
+#pragma unroll
+    for (int i = 0; i < C::CH_A; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (C::LOADER == LD_CONV) {
+            const int k = k0 + (c & 7) * C::CE;
+            const int q = k >> p.cg.cin_log2, ci = k & (p.cg.Cin - 1);
+            const int r = q / p.cg.KW, s = q - r * p.cg.KW;
+            const int hi = cr.h0[i] + r, wi = cr.w0[i] + s;
+            const bool ok = (cr.base[i] >= 0) && (k < p.K) && ((unsigned)hi < (unsigned)p.cg.Hi) && ((unsigned)wi < (unsigned)p.cg.Wi);
+            const T* src = Ag + (((size_t)(cr.base[i] + hi * p.cg.Wi + wi)) << p.cg.cin_log2) + ci;
+            { uint4 v_ = make_uint4(0u, 0u, 0u, 0u); if (ok) v_ = *reinterpret_cast<const uint4*>(src); ra[i] = v_; }
+        } else if constexpr (C::LOADER == LD_STEM) {
+            // zero-bordered NHWC4 image: k = r*32 + pixel*4 + c ; every 16-byte chunk is in bounds and aligned
+            const int k = k0 + (c & 7) * C::CE;
+            const bool ok = (cr.base[i] >= 0) && (k < p.K);
+            const T* src = Ag + ((size_t)(cr.base[i] + (k >> 5) * p.cg.Wi + ((k & 31) >> 2)) << 2) + (k & 3);
+            { uint4 v_ = make_uint4(0u, 0u, 0u, 0u); if (ok) v_ = *reinterpret_cast<const uint4*>(src); ra[i] = v_; }
+        } else if constexpr (!C::TA) {
+            const int gm = m0 + (c >> 3), gk = k0 + (c & 7) * C::CE;
+            const bool ok = (gm < p.M) && (gk < p.K);
+            { uint4 v_ = make_uint4(0u, 0u, 0u, 0u); if (ok) v_ = *reinterpret_cast<const uint4*>(Ag + (size_t)gm * p.lda + gk); ra[i] = v_; }
+        } else {
+            constexpr int CPR = C::BM * C::ES / 16;
+            const int gk = k0 + c / CPR, gm = m0 + (c % CPR) * C::CE;
+            const bool ok = (gk < p.K) && (gm < p.M);
+            { uint4 v_ = make_uint4(0u, 0u, 0u, 0u); if (ok) v_ = *reinterpret_cast<const uint4*>(Ag + (size_t)gk * p.lda + gm); ra[i] = v_; }
+        }
+    }
+}
+
+template <typename C, typename T>
+__device__ __forceinline__ void load_b(const GemmArgs& p, const T* __restrict__ Bg, int n0, int k0, int tid, uint4 (&rb)[C::CH_B]) {
+#pragma unroll
+    for (int i = 0; i < C::CH_B; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (!C::TB) {
+            const int gn = n0 + (c >> 3), gk = k0 + (c & 7) * C::CE;
+            const bool ok = (gn < p.N) && (gk < p.K);
+            { uint4 v_ = make_uint4(0u, 0u, 0u, 0u); if (ok) v_ = *reinterpret_cast<const uint4*>(Bg + (size_t)gn * p.ldb + gk); rb[i] = v_; }
+        } else {
+            constexpr int CPR = C::BN * C::ES / 16;
+            const int gk = k0 + c / CPR, gn = n0 + (c % CPR) * C::CE;
+            const bool ok = (gk < p.K) && (gn < p.N);
+            { uint4 v_ = make_uint4(0u, 0u, 0u, 0u); if (ok) v_ = *reinterpret_cast<const uint4*>(Bg + (size_t)gk * p.ldb + gn); rb[i] = v_; }
+        }
+    }
+}
+
+template <typename C>
+__device__ __forceinline__ void store_ab(char* a_buf, char* b_buf, int tid, const uint4 (&ra)[C::CH_A], const uint4 (&rb)[C::CH_B]) {
+#pragma unroll
+    for (int i = 0; i < C::CH_A; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (!C::TA) {
+            *reinterpret_cast<uint4*>(a_buf + (c >> 3) * C::SA + (c & 7) * 16) = ra[i];
+        } else {
+            constexpr int CPR = C::BM * C::ES / 16;
+            *reinterpret_cast<uint4*>(a_buf + (c / CPR) * C::SAT + (c % CPR) * 16) = ra[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C::CH_B; ++i) {
+        const int c = tid + i * 256;
+        if constexpr (!C::TB) {
+            *reinterpret_cast<uint4*>(b_buf + (c >> 3) * C::SA + (c & 7) * 16) = rb[i];
+        } else {
+            constexpr int CPR = C::BN * C::ES / 16;
+            *reinterpret_cast<uint4*>(b_buf + (c / CPR) * C::SBT + (c % CPR) * 16) = rb[i];
+        }
+    }
+}
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+template <typename C, typename T>
+__device__ __forceinline__ void compute_tile(const char* a_buf, const char* b_buf, int wm, int wn, int l15, int lg, f32x4 (&acc)[C::TM][C::TN]) {
+#pragma unroll
+    for (int ks = 0; ks < C::BK / C::KSTEP; ++ks) {
+        typename Frag<T>::type af[C::TM], bfr[C::TN];
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i) {
+            const int r0 = wm * C::WM + i * 16;
+            if constexpr (C::ES == 2) {
+                if constexpr (!C::TA) {
+                    af[i] = *reinterpret_cast<const bf16x8*>(a_buf + (r0 + l15) * C::SA + ks * 64 + lg * 16);
+                } else {
+                    const char* q = a_buf + (ks * 32 + lg * 8 + (l15 >> 2)) * C::SAT + (r0 + (l15 & 3) * 4) * 2;
+                    const s16x4 lo = lds_tr16(q), hi = lds_tr16(q + 4 * C::SAT);
+                    af[i] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            } else {
+                if constexpr (!C::TA) af[i] = *reinterpret_cast<const float*>(a_buf + (r0 + l15) * C::SA + (ks * 4 + lg) * 4);
+                else af[i] = *reinterpret_cast<const float*>(a_buf + (ks * 4 + lg) * C::SAT + (r0 + l15) * 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) {
+            const int c0 = wn * C::WN + j * 16;
+            if constexpr (C::ES == 2) {
+                if constexpr (!C::TB) {
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(b_buf + (c0 + l15) * C::SA + ks * 64 + lg * 16);
+                } else {
+                    const char* q = b_buf + (ks * 32 + lg * 8 + (l15 >> 2)) * C::SBT + (c0 + (l15 & 3) * 4) * 2;
+                    const s16x4 lo = lds_tr16(q), hi = lds_tr16(q + 4 * C::SBT);
+                    bfr[j] = __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            } else {
+                if constexpr (!C::TB) bfr[j] = *reinterpret_cast<const float*>(b_buf + (c0 + l15) * C::SA + (ks * 4 + lg) * 4);
+                else bfr[j] = *reinterpret_cast<const float*>(b_buf + (ks * 4 + lg) * C::SBT + (c0 + l15) * 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) {
+                if constexpr (C::ES == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+    }
+}
+
+template <typename T, int BM, int BN, bool TA, bool TB, int LOADER>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-    constexpr int ES = sizeof(T);
-    constexpr int CE = 16 / ES;          // elements per 16-byte chunk
-    constexpr int BK = 128 / ES;         // K elements per tile (128 bytes per row)
-    constexpr int KSTEP = (ES == 2) ? 32 : 4;
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-    constexpr int SA = 144;              // row stride (bytes) of a k-contiguous LDS image: 128 + 16 pad
-    constexpr int SAT = BM * ES + 16;    // row stride of an m-contiguous image [BK][BM]
-    constexpr int SBT = BN * ES + 16;
-    constexpr int A_BYTES = TA ? BK * SAT : BM * SA;
-    constexpr int B_BYTES = TB ? BK * SBT : BN * SA;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int CH_A = BM * 8 / 256, CH_B = BN * 8 / 256;
-    constexpr int CS = BN + 4;           // fp32 C-tile row stride (floats)
+    typedef Cfg<T, BM, BN, TA, TB, LOADER> C;
+    constexpr int ES = C::ES, CE = C::CE, BK = C::BK, CS = C::CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,173 +197,68 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const T* __restrict__ Ag = (const T*)p.A;
     const T* __restrict__ Bg = (const T*)p.B;
 
-    // ---- per-thread staging geometry ------------------------------------------------------------
-    int cv_base[CH_A], cv_h0[CH_A], cv_w0[CH_A];
-    if constexpr (CONV) {
+    ConvRows<C::CH_A> cr;
+    if constexpr (LOADER != LD_PLAIN) {
 #pragma unroll
-        for (int i = 0; i < CH_A; ++i) {
-            const int row = (tid + i * 256) >> 3;
-            const int gm = m0 + row;
+        for (int i = 0; i < C::CH_A; ++i) {
+            const int gm = m0 + ((tid + i * 256) >> 3);
             const int hw = p.cg.Ho * p.cg.Wo;
             const int n = gm / hw, rem = gm - n * hw;
             const int ho = rem / p.cg.Wo, wo = rem - ho * p.cg.Wo;
-            cv_base[i] = (gm < p.M) ? n * p.cg.Hi * p.cg.Wi : -1;
-            cv_h0[i] = ho * p.cg.stride - p.cg.pad;
-            cv_w0[i] = wo * p.cg.stride - p.cg.pad;
+            if constexpr (LOADER == LD_CONV) {
+                cr.base[i] = (gm < p.M) ? n * p.cg.Hi * p.cg.Wi : -1;
+                cr.h0[i] = ho * p.cg.stride - p.cg.pad;
+                cr.w0[i] = wo * p.cg.stride - p.cg.pad;
+            } else {   // stem: Hi/Wi are the PADDED image dims; the border already holds the conv padding
+                cr.base[i] = (gm < p.M) ? (n * p.cg.Hi + ho * p.cg.stride) * p.cg.Wi + wo * p.cg.stride : -1;
+                cr.h0[i] = 0; cr.w0[i] = 0;
+            }
         }
     }
-    uint4 ra[CH_A], rb[CH_B];
-    const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < CH_A; ++i) {
-            const int c = tid + i * 256;
-            if constexpr (CONV) {
-                const int cc = c & 7;
-                const int k = k0 + cc * CE;
-                const int q = k >> p.cg.cin_log2, ci = k & (p.cg.Cin - 1);
-                const int r = q / p.cg.KW, s = q - r * p.cg.KW;
-                const int hi = cv_h0[i] + r, wi = cv_w0[i] + s;
-                const bool ok = (cv_base[i] >= 0) && (k < p.K) && ((unsigned)hi < (unsigned)p.cg.Hi) &&
-                                ((unsigned)wi < (unsigned)p.cg.Wi);
-                const T* src = Ag + (((size_t)(cv_base[i] + hi * p.cg.Wi + wi)) << p.cg.cin_log2) + ci;
-                ra[i] = ok ? *reinterpret_cast<const uint4*>(src) : zero4;
-            } else if constexpr (!TA) {
-                const int row = c >> 3, cc = c & 7;
-                const int gm = m0 + row, gk = k0 + cc * CE;
-                const bool ok = (gm < p.M) && (gk < p.K);
-                ra[i] = ok ? *reinterpret_cast<const uint4*>(Ag + (size_t)gm * p.lda + gk) : zero4;
-            } else {
-                constexpr int CPR = BM * ES / 16;
-                const int kr = c / CPR, cc = c % CPR;
-                const int gk = k0 + kr, gm = m0 + cc * CE;
-                const bool ok = (gk < p.K) && (gm < p.M);
-                ra[i] = ok ? *reinterpret_cast<const uint4*>(Ag + (size_t)gk * p.lda + gm) : zero4;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CH_B; ++i) {
-            const int c = tid + i * 256;
-            if constexpr (!TB) {
-                const int row = c >> 3, cc = c & 7;
-                const int gn = n0 + row, gk = k0 + cc * CE;
-                const bool ok = (gn < p.N) && (gk < p.K);
-                rb[i] = ok ? *reinterpret_cast<const uint4*>(Bg + (size_t)gn * p.ldb + gk) : zero4;
-            } else {
-                constexpr int CPR = BN * ES / 16;
-                const int kr = c / CPR, cc = c % CPR;
-                const int gk = k0 + kr, gn = n0 + cc * CE;
-                const bool ok = (gk < p.K) && (gn < p.N);
-                rb[i] = ok ? *reinterpret_cast<const uint4*>(Bg + (size_t)gk * p.ldb + gn) : zero4;
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-        char* a_buf = smem + buf * STAGE;
-        char* b_buf = a_buf + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < CH_A; ++i) {
-            const int c = tid + i * 256;
-            if constexpr (!TA) {
-                *reinterpret_cast<uint4*>(a_buf + (c >> 3) * SA + (c & 7) * 16) = ra[i];
-            } else {
-                constexpr int CPR = BM * ES / 16;
-                *reinterpret_cast<uint4*>(a_buf + (c / CPR) * SAT + (c % CPR) * 16) = ra[i];
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < CH_B; ++i) {
-            const int c = tid + i * 256;
-            if constexpr (!TB) {
-                *reinterpret_cast<uint4*>(b_buf + (c >> 3) * SA + (c & 7) * 16) = rb[i];
-            } else {
-                constexpr int CPR = BN * ES / 16;
-                *reinterpret_cast<uint4*>(b_buf + (c / CPR) * SBT + (c % CPR) * 16) = rb[i];
-            }
-        }
-    };
+    // split-K: gridDim.y slices of the K-tile range
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int per = (nk_total + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = (int)blockIdx.y * per;
+    const int kt1 = (kt0 + per < nk_total) ? kt0 + per : nk_total;
 
-    f32x4 acc[TM][TN];
+    f32x4 acc[C::TM][C::TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int l15 = lane & 15, lg = lane >> 4;
-    auto compute = [&](int buf) {
-        const char* a_buf = smem + buf * STAGE;
-        const char* b_buf = a_buf + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < BK / KSTEP; ++ks) {
-            typename Frag<T>::type af[TM], bfr[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int r0 = wm * WM + i * 16;
-                if constexpr (ES == 2) {
-                    if constexpr (!TA) {
-                        af[i] = *reinterpret_cast<const bf16x8*>(a_buf + (r0 + l15) * SA + ks * 64 + lg * 16);
-                    } else {
-                        const char* q = a_buf + (ks * 32 + lg * 8 + (l15 >> 2)) * SAT + (r0 + (l15 & 3) * 4) * 2;
-                        s16x4 lo = lds_tr16(q), hi = lds_tr16(q + 4 * SAT);
-                        typedef __attribute__((ext_vector_type(8))) short s16x8;
-                        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        af[i] = __builtin_bit_cast(bf16x8, v);
-                    }
-                } else {
-                    if constexpr (!TA) af[i] = *reinterpret_cast<const float*>(a_buf + (r0 + l15) * SA + (ks * 4 + lg) * 4);
-                    else af[i] = *reinterpret_cast<const float*>(a_buf + (ks * 4 + lg) * SAT + (r0 + l15) * 4);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int c0 = wn * WN + j * 16;
-                if constexpr (ES == 2) {
-                    if constexpr (!TB) {
-                        bfr[j] = *reinterpret_cast<const bf16x8*>(b_buf + (c0 + l15) * SA + ks * 64 + lg * 16);
-                    } else {
-                        const char* q = b_buf + (ks * 32 + lg * 8 + (l15 >> 2)) * SBT + (c0 + (l15 & 3) * 4) * 2;
-                        s16x4 lo = lds_tr16(q), hi = lds_tr16(q + 4 * SBT);
-                        typedef __attribute__((ext_vector_type(8))) short s16x8;
-                        s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        bfr[j] = __builtin_bit_cast(bf16x8, v);
-                    }
-                } else {
-                    if constexpr (!TB) bfr[j] = *reinterpret_cast<const float*>(b_buf + (c0 + l15) * SA + (ks * 4 + lg) * 4);
-                    else bfr[j] = *reinterpret_cast<const float*>(b_buf + (ks * 4 + lg) * SBT + (c0 + l15) * 4);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (ES == 2) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                }
-        }
-    };
 
-    // ---- main loop ------------------------------------------------------------------------------
-    const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-        compute(kt & 1);
-        if (kt + 1 < nk) store_tiles((kt + 1) & 1);
+    if (kt0 < kt1) {
+        uint4 ra[C::CH_A], rb[C::CH_B];
+        load_a<C, T>(p, Ag, cr, m0, kt0 * BK, tid, ra);
+        load_b<C, T>(p, Bg, n0, kt0 * BK, tid, rb);
+        store_ab<C>(smem, smem + C::A_BYTES, tid, ra, rb);
         __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            char* a_cur = smem + cur * C::STAGE;
+            char* a_nxt = smem + (cur ^ 1) * C::STAGE;
+            const bool more = kt + 1 < kt1;
+            if (more) {
+                load_a<C, T>(p, Ag, cr, m0, (kt + 1) * BK, tid, ra);
+                load_b<C, T>(p, Bg, n0, (kt + 1) * BK, tid, rb);
+            }
+            compute_tile<C, T>(a_cur, a_cur + C::A_BYTES, wm, wn, l15, lg, acc);
+            if (more) store_ab<C>(a_nxt, a_nxt + C::A_BYTES, tid, ra, rb);
+            __syncthreads();
+        }
     }
 
     // ---- accumulators -> LDS (fp32 C tile) ---------------------------------------------------------
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < C::TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < C::TN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                Cs[(wm * WM + i * 16 + lg * 4 + r) * CS + wn * WN + j * 16 + l15] = acc[i][j][r];
+                Cs[(wm * C::WM + i * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[i][j][r];
     __syncthreads();
 
     // ---- per-column statistics of the raw result (BatchNorm2d batch statistics, encoder_cnn.py:33) --------
@@ -239,10 +279,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 
     // ---- epilogue: 8 consecutive columns per thread --------------------------------------------------
+    constexpr int GPR = BN / 8;
+    if (gridDim.y > 1) {
+        // split-K partial: fp32 atomic accumulation into a zero-initialised (or accumulating) C; no other epilogue terms
+        float* Cg = (float*)p.C;
+        for (int g = tid; g < BM * GPR; g += 256) {
+            const int row = g / GPR, cgp = g % GPR;
+            const int m = m0 + row, n = n0 + cgp * 8;
+            if (m >= p.M || n >= p.N) continue;
+            const int nv = (p.N - n < 8) ? (p.N - n) : 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (e < nv) atomicAdd(Cg + (size_t)m * p.ldc + n + e, Cs[row * CS + cgp * 8 + e] * p.alpha);
+        }
+        return;
+    }
     const uint32_t thresh = dropout_threshold(p.drop_p);
     const float keep_scale = (p.drop_p > 0.f) ? 1.f / (1.f - p.drop_p) : 1.f;
     const int drop_ld = (p.N + 7) & ~7;
-    constexpr int GPR = BN / 8;
     for (int g = tid; g < BM * GPR; g += 256) {
         const int row = g / GPR, cgp = g % GPR;
         const int m = m0 + row, n = n0 + cgp * 8;
@@ -273,11 +327,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
         if (p.drop_p > 0.f) {
             const uint64_t e0 = (uint64_t)m * (uint64_t)drop_ld + (uint64_t)n;
-            uint32_t w[8];
-            dropout_words(p.seed, p.stream_id, e0 >> 2, w);
-            dropout_words(p.seed, p.stream_id, (e0 >> 2) + 1, w + 4);
+            uint32_t w0[4], w1[4];
+            dropout_words(p.seed, p.stream_id, e0 >> 2, w0);
+            dropout_words(p.seed, p.stream_id, (e0 >> 2) + 1, w1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (w[e] >= thresh) ? v[e] * keep_scale : 0.f;
+            for (int e = 0; e < 4; ++e) {
+                v[e] = (w0[e] >= thresh) ? v[e] * keep_scale : 0.f;
+                v[e + 4] = (w1[e] >= thresh) ? v[e + 4] * keep_scale : 0.f;
+            }
         }
         const bool full = (nv == 8);
         if (p.maskY != nullptr) {
@@ -344,47 +401,82 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <typename T, int BM, int BN, bool TA, bool TB, bool CONV>
-int launch(const GemmArgs& a, hipStream_t stream) {
-    constexpr int ES = sizeof(T);
-    constexpr int BK = 128 / ES;
-    constexpr int A_BYTES = TA ? BK * (BM * ES + 16) : BM * 144;
-    constexpr int B_BYTES = TB ? BK * (BN * ES + 16) : BN * 144;
-    constexpr int STAGE2 = 2 * (A_BYTES + B_BYTES);
-    constexpr int CBYTES = BM * (BN + 4) * 4;
-    constexpr int LDS = STAGE2 > CBYTES ? STAGE2 : CBYTES;
+template <typename T, int BM, int BN, bool TA, bool TB, int LOADER>
+int launch(const GemmArgs& a, int splits, hipStream_t stream) {
+    typedef Cfg<T, BM, BN, TA, TB, LOADER> C;
     static bool attr_set = false;
-    auto kern = gemm_kernel<T, BM, BN, TA, TB, CONV>;
+    auto kern = gemm_kernel<T, BM, BN, TA, TB, LOADER>;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-            blt_set_error("gemm: hipFuncSetAttribute(%d) failed", LDS);
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+            blt_set_error("gemm: hipFuncSetAttribute(%d) failed", C::LDS_BYTES);
             return BLT_ERR_HIP;
         }
         attr_set = true;
     }
     const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
-    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(256), LDS, stream, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), C::LDS_BYTES, stream, a);
     return blt_check_launch("gemm");
 }
 
-template <typename T, int BT>
-int dispatch_layout(const GemmArgs& a, hipStream_t s) {
-    if (a.is_conv) return launch<T, BT, BT, false, false, true>(a, s);
-    if (!a.transA && !a.transB) return launch<T, BT, BT, false, false, false>(a, s);
-    if (!a.transA && a.transB) return launch<T, BT, BT, false, true, false>(a, s);
-    if (a.transA && a.transB) return launch<T, BT, BT, true, true, false>(a, s);
-    return launch<T, BT, BT, true, false, false>(a, s);
+template <typename T, int BM, int BN>
+int dispatch_layout(const GemmArgs& a, int splits, hipStream_t s) {
+    if (a.is_conv == 2) return launch<T, BM, BN, false, false, LD_STEM>(a, splits, s);
+    if (a.is_conv) return launch<T, BM, BN, false, false, LD_CONV>(a, splits, s);
+    if (!a.transA && !a.transB) return launch<T, BM, BN, false, false, LD_PLAIN>(a, splits, s);
+    if (!a.transA && a.transB) return launch<T, BM, BN, false, true, LD_PLAIN>(a, splits, s);
+    if (a.transA && a.transB) return launch<T, BM, BN, true, true, LD_PLAIN>(a, splits, s);
+    return launch<T, BM, BN, true, false, LD_PLAIN>(a, splits, s);
+}
+
+template <typename T>
+int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) {
+    if (bm == 128 && bn == 128) return dispatch_layout<T, 128, 128>(a, splits, s);
+    if (bm == 128 && bn == 64) return dispatch_layout<T, 128, 64>(a, splits, s);
+    return dispatch_layout<T, 64, 64>(a, splits, s);
 }
 
 }  // namespace
 
-int blt_gemm_tile(const GemmArgs& a) {
-    if (a.force_tile == 64 || a.force_tile == 128) return a.force_tile;
+// tile heuristic: 128-wide tiles once they fill the chip; a 64-column tile when N <= 64 (Cout = 64 convolutions)
+void blt_gemm_tile2(const GemmArgs& a, int* bm, int* bn) {
+    if (a.force_tile == 64) { *bm = 64; *bn = 64; return; }
+    if (a.force_tile == 128) { *bm = 128; *bn = 128; return; }
+    if (a.force_tile == 12864) { *bm = 128; *bn = 64; return; }
+    if (a.N <= 64) {
+        const long t = cdiv(a.M, 128);
+        if (t >= 192) { *bm = 128; *bn = 64; return; }
+        *bm = 64; *bn = 64;
+        return;
+    }
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-    return (t128 >= 192) ? 128 : 64;
+    if (t128 >= 192) { *bm = 128; *bn = 128; return; }
+    *bm = 64; *bn = 64;
+}
+
+int blt_gemm_tile(const GemmArgs& a) {
+    int bm, bn;
+    blt_gemm_tile2(a, &bm, &bn);
+    return bm;
 }
 
 int blt_gemm_stat_rows(const GemmArgs& a) { return 2 * cdiv(a.M, blt_gemm_tile(a)); }
+
+// split-K only for the fp32-accumulating weight-gradient form (both operands token-major, fp32 output, no epilogue terms)
+int blt_gemm_splits(const GemmArgs& a, int dtype) {
+    if (a.split_k <= 0) return 1;
+    if (!(a.transA && a.transB) || !(a.out_f32 || dtype == BLT_F32)) return 1;
+    if (a.bias || a.relu || a.drop_p > 0.f || a.maskY || a.C2 || a.R || a.rowtab || a.stat_sum) return 1;
+    int bm, bn;
+    blt_gemm_tile2(a, &bm, &bn);
+    const long tiles = (long)cdiv(a.M, bm) * cdiv(a.N, bn);
+    const int bk = (dtype == BLT_BF16) ? 64 : 32;
+    const int nk = cdiv(a.K, bk);
+    long s = (tiles >= 256) ? 1 : (384 / tiles);
+    if (s > nk / 2) s = nk / 2;
+    if (s > a.split_k) s = a.split_k;
+    if (s < 1) s = 1;
+    return (int)s;
+}
 
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "gemm: bad dtype %d", dtype);
@@ -393,11 +485,16 @@ int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
     const int ce = (dtype == BLT_BF16) ? 8 : 4;
     BLT_REQUIRE(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0 && ((uintptr_t)a.C % 16) == 0,
                 "gemm: operands must be 16-byte aligned");
-    BLT_REQUIRE(a.lda % ce == 0 && a.ldb % ce == 0, "gemm: lda=%d / ldb=%d must be multiples of %d elements", a.lda, a.ldb, ce);
-    if (a.is_conv) {
+    BLT_REQUIRE((a.is_conv == 2 || a.lda % ce == 0) && a.ldb % ce == 0, "gemm: lda=%d / ldb=%d must be multiples of %d elements", a.lda, a.ldb, ce);
+    if (a.is_conv == 1) {
         BLT_REQUIRE(!a.transA && !a.transB, "gemm: conv loader is NT only");
         BLT_REQUIRE((1 << a.cg.cin_log2) == a.cg.Cin && a.cg.Cin % ce == 0, "gemm: conv Cin=%d must be a power of two >= %d", a.cg.Cin, ce);
         BLT_REQUIRE(a.K == a.cg.KH * a.cg.KW * a.cg.Cin, "gemm: conv K mismatch");
+        BLT_REQUIRE(a.M % (a.cg.Ho * a.cg.Wo) == 0, "gemm: conv M must be N*Ho*Wo");
+    } else if (a.is_conv == 2) {
+        BLT_REQUIRE(!a.transA && !a.transB, "gemm: stem loader is NT only");
+        BLT_REQUIRE(a.K == 224 && a.cg.Cin == 4 && a.cg.stride == 2 && (a.cg.Wi % 2) == 0, "gemm: stem loader needs K=7*8*4, stride 2, even padded width");
+        BLT_REQUIRE(a.cg.Hi >= 2 * (a.cg.Ho - 1) + 7 && a.cg.Wi >= 2 * (a.cg.Wo - 1) + 8, "gemm: stem image border too small");
         BLT_REQUIRE(a.M % (a.cg.Ho * a.cg.Wo) == 0, "gemm: conv M must be N*Ho*Wo");
     } else {
         if (!a.transA) BLT_REQUIRE(a.lda >= ((a.K + ce - 1) / ce) * ce, "gemm: lda=%d too small for K=%d", a.lda, a.K);
@@ -408,7 +505,9 @@ int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
     BLT_REQUIRE(a.ldc >= a.N, "gemm: ldc=%d < N=%d", a.ldc, a.N);
     BLT_REQUIRE(a.drop_p >= 0.f && a.drop_p < 1.f, "gemm: bad dropout p");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
-    const int bt = blt_gemm_tile(a);
-    if (dtype == BLT_BF16) return bt == 128 ? dispatch_layout<bf16, 128>(a, stream) : dispatch_layout<bf16, 64>(a, stream);
-    return bt == 128 ? dispatch_layout<float, 128>(a, stream) : dispatch_layout<float, 64>(a, stream);
+    int bm, bn;
+    blt_gemm_tile2(a, &bm, &bn);
+    const int splits = blt_gemm_splits(a, dtype);
+    if (dtype == BLT_BF16) return dispatch_tile<bf16>(a, bm, bn, splits, stream);
+    return dispatch_tile<float>(a, bm, bn, splits, stream);
 }

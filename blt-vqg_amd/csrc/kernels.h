@@ -40,13 +40,15 @@ struct GemmArgs {
     int accumulate = 0;
     float* stat_sum = nullptr;   // [2*tiles_m, N] per-half-tile column sums of the raw accumulators
     float* stat_sq = nullptr;
-    int is_conv = 0;
+    int is_conv = 0;             // 1 = NHWC implicit-GEMM gather, 2 = 7x7/2 stem on a zero-bordered NHWC4 image (cg.Hi/Wi = padded dims)
+    int split_k = 0;             // max K-splits (fp32 atomic accumulation) for the weight-gradient form; 0 = off
     ConvGeom cg = {};
     int force_tile = 0;          // 0 = heuristic, 64 or 128
 };
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
 int blt_gemm_tile(const GemmArgs& a);
+int blt_gemm_splits(const GemmArgs& a, int dtype);
 
 // ---- normalisation -----------------------------------------------------------------
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
@@ -113,8 +115,11 @@ int blt_colsum(int dtype, const void* x, int ld, long M, int N, float* out, int 
 int blt_cast_pad(const float* src, int rows, int cols, void* dst, int ld, int dtype, hipStream_t s);
 int blt_cast_rows(int dtype_src, const void* src, int lds_, int dtype_dst, void* dst, int ldd, long rows, int cols,
                   hipStream_t s);
-int blt_img_pack(int dtype, const float* nchw, void* nhwc8, int N, int C, int H, int W, int Cpad, hipStream_t s);
-int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, hipStream_t s);
+// NCHW fp32 -> NHWC [N, Hp, Wp, Cpad] with the image at (pad_top, pad_left) and zeros elsewhere
+int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, int pad_top, int pad_left, int Hp, int Wp,
+                 hipStream_t s);
+// [Cout, Cin, KH, KW] fp32 -> [Cout, KH, KWpad, Cpad] (zeros in the padding)
+int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad, hipStream_t s);
 int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long rows, int cols, hipStream_t s);
 
 // ---- losses ------------------------------------------------------------------------------------

@@ -142,31 +142,33 @@ __global__ void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __res
     }
 }
 
-// NCHW fp32 image -> NHWC with C padded to Cpad (zeros)
+// NCHW fp32 image -> NHWC [N, Hp, Wp, Cpad]: image placed at (pt, pl), zeros in the border and in the padded channels
 template <typename T>
-__global__ void img_pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H, int W, int Cpad) {
-    const long total = (long)N * H * W * Cpad;
+__global__ void img_pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H, int W, int Cpad, int pt, int pl,
+                                int Hp, int Wp) {
+    const long total = (long)N * Hp * Wp * Cpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % Cpad);
         long t = i / Cpad;
-        const int w = (int)(t % W); t /= W;
-        const int h = (int)(t % H);
-        const long n = t / H;
-        dst[i] = from_f32<T>(c < C ? src[((n * C + c) * H + h) * W + w] : 0.f);
+        const int w = (int)(t % Wp) - pl; t /= Wp;
+        const int h = (int)(t % Hp) - pt;
+        const long n = t / Hp;
+        const bool ok = c < C && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        dst[i] = from_f32<T>(ok ? src[((n * C + c) * H + h) * W + w] : 0.f);
     }
 }
 
-// conv weight [Cout, Cin, KH, KW] fp32 -> [Cout, KH, KW, Cpad] T (k index = (r*KW + s)*Cpad + c)
+// conv weight [Cout, Cin, KH, KW] fp32 -> [Cout, KH, KWpad, Cpad] T (k index = (r*KWpad + s)*Cpad + c)
 template <typename T>
-__global__ void conv_pack_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH, int KW, int Cpad) {
-    const long total = (long)Cout * KH * KW * Cpad;
+__global__ void conv_pack_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad) {
+    const long total = (long)Cout * KH * KWpad * Cpad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % Cpad);
         long t = i / Cpad;
-        const int s = (int)(t % KW); t /= KW;
+        const int s = (int)(t % KWpad); t /= KWpad;
         const int r = (int)(t % KH);
         const long o = t / KH;
-        out[i] = from_f32<T>(c < Cin ? w[((o * Cin + c) * KH + r) * KW + s] : 0.f);
+        out[i] = from_f32<T>((c < Cin && s < KW) ? w[((o * Cin + c) * KH + r) * KW + s] : 0.f);
     }
 }
 
@@ -444,21 +446,21 @@ int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long ro
     return cast_rows_impl(dtype, src, lds_, dtype, dst, ldd, rows, cols, cols, s);
 }
 
-int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, hipStream_t s) {
+int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, int pt, int pl, int Hp, int Wp, hipStream_t s) {
     CHECK_DTYPE(dtype, "img_pack");
-    BLT_REQUIRE(nchw && nhwc && N > 0 && C > 0 && C <= Cpad && H > 0 && W > 0, "img_pack: bad args");
-    const long n = (long)N * H * W * Cpad;
-    if (dtype == BLT_F32) hipLaunchKernelGGL(img_pack_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (float*)nhwc, N, C, H, W, Cpad);
-    else hipLaunchKernelGGL(img_pack_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (bf16*)nhwc, N, C, H, W, Cpad);
+    BLT_REQUIRE(nchw && nhwc && N > 0 && C > 0 && C <= Cpad && H > 0 && W > 0 && pt >= 0 && pl >= 0 && Hp >= H + pt && Wp >= W + pl, "img_pack: bad args");
+    const long n = (long)N * Hp * Wp * Cpad;
+    if (dtype == BLT_F32) hipLaunchKernelGGL(img_pack_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (float*)nhwc, N, C, H, W, Cpad, pt, pl, Hp, Wp);
+    else hipLaunchKernelGGL(img_pack_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (bf16*)nhwc, N, C, H, W, Cpad, pt, pl, Hp, Wp);
     return blt_check_launch("img_pack");
 }
 
-int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, hipStream_t s) {
+int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad, hipStream_t s) {
     CHECK_DTYPE(dtype, "conv_pack_w");
-    BLT_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cin <= Cpad, "conv_pack_w: bad args");
-    const long n = (long)Cout * KH * KW * Cpad;
-    if (dtype == BLT_F32) hipLaunchKernelGGL(conv_pack_w_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, w, (float*)out, Cout, Cin, KH, KW, Cpad);
-    else hipLaunchKernelGGL(conv_pack_w_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, w, (bf16*)out, Cout, Cin, KH, KW, Cpad);
+    BLT_REQUIRE(w && out && Cout > 0 && Cin > 0 && Cin <= Cpad && KWpad >= KW, "conv_pack_w: bad args");
+    const long n = (long)Cout * KH * KWpad * Cpad;
+    if (dtype == BLT_F32) hipLaunchKernelGGL(conv_pack_w_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, w, (float*)out, Cout, Cin, KH, KW, Cpad, KWpad);
+    else hipLaunchKernelGGL(conv_pack_w_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, w, (bf16*)out, Cout, Cin, KH, KW, Cpad, KWpad);
     return blt_check_launch("conv_pack_w");
 }
 

@@ -41,19 +41,29 @@ const char* bltvqg_last_error_string(void);
 
 /* C[M,N] = epilogue(sum_k A^[m,k] * B^[n,k]).  transA/transB: 0 = k-contiguous storage, 1 = m/n-contiguous storage.
  * Optional epilogue terms (NULL / 0 to disable), applied in this order: +bias[n] (fp32), ReLU, dropout(p, seed, stream_id),
- * *(maskY != 0)*mask_scale, +R[m,n], +old C (accumulate).  out_f32: store C as fp32 even when dtype is bf16. */
+ * *(maskY != 0)*mask_scale, +R[m,n], +old C (accumulate).  out_f32: store C as fp32 even when dtype is bf16.
+ * force_tile: 0 = heuristic, 64 / 128 / 12864 (= 128x64).  split_k > 0 allows up to that many K-slices for the weight-gradient
+ * form (transA = transB = 1, fp32 output, no epilogue terms): partial tiles are ADDED to C with fp32 atomics. */
 int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, int ldb, int transB, void* C, int ldc,
                 int M, int N, int K, const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
                 const void* maskY, int ldm, float mask_scale, const void* R, int ldr, int accumulate, int out_f32,
-                int force_tile, void* stream);
+                int force_tile, int split_k, void* stream);
 
 /* NHWC implicit-GEMM convolution y[N,Ho,Wo,Cout] = conv(x[N,Hi,Wi,Cin], w[Cout,KH,KW,Cin]); Cin a power of two >= 8 (bf16)
  * / 4 (fp32).  stat_sum/stat_sq (optional): per-half-tile column partial sums, bltvqg_conv2d_stat_rows() rows of Cout. */
 int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
                   int stride, int pad, float* stat_sum, float* stat_sq, void* stream);
 int bltvqg_conv2d_stat_rows(int N, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad);
-int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, void* stream);
-int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, void* stream);
+/* NCHW fp32 -> NHWC [N,Hp,Wp,Cpad] with the image at (pad_top, pad_left) and zeros elsewhere */
+int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, int pad_top, int pad_left, int Hp,
+                    int Wp, void* stream);
+/* [Cout,Cin,KH,KW] fp32 -> [Cout,KH,KWpad,Cpad] */
+int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad, void* stream);
+/* ResNet stem: 7x7 stride-2 pad-3 conv of a zero-bordered NHWC4 image [N,Hp,Wp,4] (image at (3,3), Wp even, Wp >= W+7) with weights
+ * packed [Cout,7,8,4]; y [N,Ho,Wo,Cout] */
+int bltvqg_conv_stem(int dtype, const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, int Cout,
+                     float* stat_sum, float* stat_sq, void* stream);
+int bltvqg_conv_stem_stat_rows(int N, int H, int W, int Cout);
 
 int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                          int64_t rows, int cols, float eps, void* stream);

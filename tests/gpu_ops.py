@@ -28,7 +28,7 @@ def lib():
 
 
 def gemm(A, B, M, N, K, transA=False, transB=False, bias=None, relu=False, drop_p=0.0, seed=0, stream_id=0, maskY=None,
-         mask_scale=1.0, R=None, C=None, accumulate=False, out_f32=False, force_tile=0, ldc=None):
+         mask_scale=1.0, R=None, C=None, accumulate=False, out_f32=False, force_tile=0, ldc=None, split_k=0):
     dt = DT[A.dtype]
     out_dtype = torch.float32 if (out_f32 or dt == 0) else torch.bfloat16
     if C is None:
@@ -39,7 +39,7 @@ def gemm(A, B, M, N, K, transA=False, transB=False, bias=None, relu=False, drop_
     check(lib().bltvqg_gemm(dt, ptr(A), A.stride(0), int(transA), ptr(B), B.stride(0), int(transB), ptr(C), ldc, M, N, K, ptr(bias),
                             int(relu), float(drop_p), int(seed), int(stream_id), ptr(maskY), 0 if maskY is None else maskY.stride(0),
                             float(mask_scale), ptr(R), 0 if R is None else R.stride(0), int(accumulate), int(out_f32), int(force_tile),
-                            stream_ptr()), "gemm")
+                            int(split_k), stream_ptr()), "gemm")
     return C
 
 
@@ -58,17 +58,33 @@ def conv2d(x_nhwc, w_packed, N, Hi, Wi, Cin, Cout, K, stride, pad, stats=False):
     return y, ssum, ssq
 
 
-def img_pack(images, dtype, cpad=8):
+def img_pack(images, dtype, cpad=8, pad_top=0, pad_left=0, Hp=None, Wp=None):
     N, C, H, W = images.shape
-    out = torch.empty(N, H, W, cpad, dtype=dtype, device=images.device)
-    check(lib().bltvqg_img_pack(DT[dtype], ptr(images), ptr(out), N, C, H, W, cpad, stream_ptr()), "img_pack")
+    Hp, Wp = Hp or H, Wp or W
+    out = torch.empty(N, Hp, Wp, cpad, dtype=dtype, device=images.device)
+    check(lib().bltvqg_img_pack(DT[dtype], ptr(images), ptr(out), N, C, H, W, cpad, pad_top, pad_left, Hp, Wp, stream_ptr()), "img_pack")
     return out
 
 
-def conv_pack_w(w, dtype, cpad):
+def conv_stem(x_padded, w_packed, N, H, W, Cout, stats=False):
+    dt = DT[x_padded.dtype]
+    Hp, Wp = x_padded.shape[1], x_padded.shape[2]
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.zeros(N, Ho, Wo, Cout, dtype=x_padded.dtype, device=x_padded.device)
+    ssum = ssq = None
+    if stats:
+        rows = lib().bltvqg_conv_stem_stat_rows(N, H, W, Cout)
+        ssum = torch.zeros(rows, Cout, dtype=torch.float32, device=y.device)
+        ssq = torch.zeros(rows, Cout, dtype=torch.float32, device=y.device)
+    check(lib().bltvqg_conv_stem(dt, ptr(x_padded), ptr(w_packed), ptr(y), N, H, W, Hp, Wp, Cout, ptr(ssum), ptr(ssq), stream_ptr()), "conv_stem")
+    return y, ssum, ssq
+
+
+def conv_pack_w(w, dtype, cpad, kwpad=None):
     Cout, Cin, KH, KW = w.shape
-    out = torch.empty(Cout, KH, KW, cpad, dtype=dtype, device=w.device)
-    check(lib().bltvqg_conv_pack_w(DT[dtype], ptr(w), ptr(out), Cout, Cin, KH, KW, cpad, stream_ptr()), "conv_pack_w")
+    kwpad = kwpad or KW
+    out = torch.empty(Cout, KH, kwpad, cpad, dtype=dtype, device=w.device)
+    check(lib().bltvqg_conv_pack_w(DT[dtype], ptr(w), ptr(out), Cout, Cin, KH, KW, cpad, kwpad, stream_ptr()), "conv_pack_w")
     return out
 
 

@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu():
     assert lib.bltvqg_version() >= 100
     rc = lib.bltvqg_layernorm_fwd(0, None, None, None, None, None, None, 4, 12, 1e-5, None)
     assert rc < 0 and b"layernorm_fwd" in lib.bltvqg_last_error_string()
-    rc = lib.bltvqg_gemm(7, None, 0, 0, None, 0, 0, None, 0, 1, 1, 1, None, 0, 0.0, 0, 0, None, 0, 1.0, None, 0, 0, 0, 0, None)
+    rc = lib.bltvqg_gemm(7, None, 0, 0, None, 0, 0, None, 0, 1, 1, 1, None, 0, 0.0, 0, 0, None, 0, 1.0, None, 0, 0, 0, 0, 0, None)
     assert rc < 0 and b"dtype" in lib.bltvqg_last_error_string()
     with pytest.raises(_lib.HipError):
         _lib.check(rc, "gemm")

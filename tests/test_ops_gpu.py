@@ -24,7 +24,7 @@ def _cuda(*ts):
 
 # --------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile", [64, 128])
+@pytest.mark.parametrize("tile", [64, 128, 12864])
 @pytest.mark.parametrize("layout", ["NT", "NN", "TT", "TN"])
 @pytest.mark.parametrize("shape", [(128, 128, 128), (100, 97, 72), (257, 40, 300), (64, 520, 64), (33, 8, 8)])
 def test_gemm_exact_integer(dtype, tile, layout, shape):
@@ -82,6 +82,24 @@ def test_gemm_epilogue_order(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(256, 256, 2560), (96, 300, 1000), (512, 64, 333)])
+def test_gemm_split_k_weight_gradient(dtype, shape):
+    """dW[N,K] += dY[M,N]^T X[M,K] with the token dimension split over workgroups (fp32 atomics): exact on integers."""
+    import gpu_ops as G
+    Nout, Kin, Mtok = shape
+    ce = 8 if dtype == torch.bfloat16 else 4
+    pad = lambda n: (n + ce - 1) // ce * ce           # noqa: E731
+    g = torch.Generator().manual_seed(Mtok)
+    dY = torch.zeros(Mtok, pad(Nout)); dY[:, :Nout] = _ints((Mtok, Nout), -2, 2, g, torch.float32)
+    X = torch.zeros(Mtok, pad(Kin)); X[:, :Kin] = _ints((Mtok, Kin), -2, 2, g, torch.float32)
+    C0 = _ints((Nout, Kin), -3, 3, g, torch.float32)
+    C = C0.clone().cuda()
+    G.gemm(dY.to(dtype).cuda(), X.to(dtype).cuda(), Nout, Kin, Mtok, transA=True, transB=True, out_f32=True, C=C, split_k=32)
+    ref = dY[:, :Nout].double().t() @ X[:, :Kin].double() + C0.double()
+    assert torch.equal(C.cpu().double(), ref)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_random_accuracy(dtype):
     import gpu_ops as G
     M, N, K = 512, 384, 512
@@ -121,10 +139,17 @@ def test_conv2d_exact_integer_and_stats(dtype, geom):
     x = _ints((N, cin, Hi, Wi), -2, 2, g, torch.float32)
     w = _ints((cout, cin, k, k), -1, 1, g, torch.float32)
     ref = F.conv2d(x.double(), w.double(), None, stride, pad).permute(0, 2, 3, 1).contiguous()
-    cpad = max(cin, 8)
-    xp = G.img_pack(x.cuda(), dtype, cpad)
-    wp = G.conv_pack_w(w.cuda(), dtype, cpad)
-    y, ssum, ssq = G.conv2d(xp, wp, N, Hi, Wi, cpad, cout, k, stride, pad, stats=True)
+    if cin == 3:      # ResNet stem: zero-bordered NHWC4 image, weights packed [Cout, 7, 8, 4]
+        Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+        Hp = max(Hi + 6, 2 * (Ho - 1) + 7)
+        Wp = (max(Wi + 6, 2 * (Wo - 1) + 8) + 1) // 2 * 2
+        xp = G.img_pack(x.cuda(), dtype, 4, 3, 3, Hp, Wp)
+        wp = G.conv_pack_w(w.cuda(), dtype, 4, 8)
+        y, ssum, ssq = G.conv_stem(xp, wp, N, Hi, Wi, cout, stats=True)
+    else:
+        xp = G.img_pack(x.cuda(), dtype, cin)
+        wp = G.conv_pack_w(w.cuda(), dtype, cin)
+        y, ssum, ssq = G.conv2d(xp, wp, N, Hi, Wi, cin, cout, k, stride, pad, stats=True)
     torch.cuda.synchronize()
     got = y.float().cpu().double()
     assert got.shape == ref.shape

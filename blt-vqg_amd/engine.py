@@ -76,14 +76,20 @@ class StepEngine(object):
         return out
 
     # ------------------------------------------------------------------------------------------------
-    def allocate(self):
-        """Allocates the flat buffers + workspace on the device and binds them."""
+    def allocate(self, share_from=None):
+        """Allocates the flat buffers + workspace on the device and binds them.  `share_from`: another engine of the same
+        model (different batch shape) whose parameter / gradient / optimiser buffers are reused."""
         dev = self.device
-        self.flat_train = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
-        self.adam_m = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
-        self.adam_v = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
-        self.flat_frozen = torch.zeros(self.frozen_size, dtype=torch.float32, device=dev)
+        if share_from is not None:
+            assert share_from.train_size == self.train_size and share_from.frozen_size == self.frozen_size
+            self.flat_train, self.flat_grad = share_from.flat_train, share_from.flat_grad
+            self.adam_m, self.adam_v, self.flat_frozen = share_from.adam_m, share_from.adam_v, share_from.flat_frozen
+        else:
+            self.flat_train = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+            self.flat_grad = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+            self.adam_m = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+            self.adam_v = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
+            self.flat_frozen = torch.zeros(self.frozen_size, dtype=torch.float32, device=dev)
         self.workspace = torch.empty(self.workspace_bytes + 256, dtype=torch.uint8, device=dev)
         self._bind()
 

@@ -1,0 +1,246 @@
+"""`models.IQ` drop-in: same constructor, `forward` 4-tuple, `switch_GVT_train_mode` and `state_dict` key set as the reference
+(models/iq.py:22-152), with every operator underneath running in libbltvqg_hip.so through the train-step engine.
+
+The module tree only HOLDS parameters (as views into the engine's flat fp32 buffers, under the reference's names, aliases
+included); there is no PyTorch compute path and no CPU fallback: `forward` on a machine without the HIP library / a GPU raises.
+"""
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .engine import StepEngine, make_config
+from .trainer import init_reference_style
+
+
+class _Node(nn.Module):
+    """Pure container (a node of the reference's module tree)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("this module only holds parameters; compute runs in the HIP engine via IQ.forward")
+
+
+def _attach(root, name, tensor, kind):
+    parts = name.split(".")
+    node = root
+    for p in parts[:-1]:
+        if p not in node._modules:
+            node.add_module(p, _Node())
+        node = node._modules[p]
+    leaf = parts[-1]
+    if kind == "param":
+        node.register_parameter(leaf, nn.Parameter(tensor, requires_grad=True))
+    elif kind == "frozen":
+        node.register_parameter(leaf, nn.Parameter(tensor, requires_grad=False))
+    else:
+        node.register_buffer(leaf, tensor)
+
+
+def _is_buffer(name):
+    return name.endswith("running_mean") or name.endswith("running_var")
+
+
+def _bn_prefixes(frozen_names):
+    return sorted({n[: -len(".running_mean")] for n in frozen_names if n.endswith(".running_mean")})
+
+
+class _IQFunction(torch.autograd.Function):
+    """One autograd node for the whole model: forward = engine forward, backward = engine backward from output gradients."""
+
+    @staticmethod
+    def forward(ctx, model, images, answers, response, target, eps, *params):
+        eng = model._engine_for(images, answers, response, target)
+        phase2 = bool(model.latent_transformer)
+        model._step_seed += 1
+        eng.forward(images.contiguous().float(), answers.contiguous(), response.contiguous(), target.contiguous(),
+                    None if eps is None else eps.contiguous().float(), phase2, model._base_seed + model._step_seed)
+        ctx.eng, ctx.phase2, ctx.names = eng, phase2, model._train_names
+        output = eng.read(0)
+        feats, recon = eng.read(2), eng.read(3)
+        if phase2:
+            z_logit = eng.read(1)
+            kld = eng.read(4)[2].clone()
+        else:
+            z_logit = torch.zeros(0, device=images.device)
+            kld = torch.zeros((), device=images.device)
+        return output, z_logit, kld, feats, recon
+
+    @staticmethod
+    def backward(ctx, d_out, d_zl, d_kld, d_feats, d_recon):
+        eng = ctx.eng
+        f = lambda t: None if t is None else t.contiguous().float()   # noqa: E731
+        eng.backward_external(f(d_out), f(d_zl) if ctx.phase2 else None, float(d_kld) if (ctx.phase2 and d_kld is not None) else 0.0,
+                              f(d_feats), f(d_recon))
+        grads = []
+        for n in ctx.names:
+            info = eng.train_info[n]
+            grads.append(eng.grad_view(n).clone() if (ctx.phase2 or not info.late) else None)
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+class IQ(nn.Module):
+    """Information-maximising VQG model (reference models/iq.py:22).  `args` is the reference's namespace: emb_dim, hidden_dim,
+    latent_dim, pwffn_dim, num_layers, num_heads, device, emb_file, root_dir (+ optional: precision in {"bf16","fp32"},
+    attention_dropout, relu_dropout, resnet_weights = path of a torchvision resnet18 state dict)."""
+
+    def __init__(self, latent_transformer, vocab, args, num_att_layers=2):
+        super().__init__()
+        self.vocab = vocab
+        self.vocab_size = len(vocab.word2idx)
+        self.latent_transformer = latent_transformer
+        self.args = args
+        if num_att_layers != 2:
+            raise ValueError("image_reconstructor is the reference's 2-layer MLP (iq.py:46-48)")
+        self._dtype = _lib.F32 if getattr(args, "precision", "bf16") in ("fp32", "f32", 32) else _lib.BF16
+        self._engines = {}
+        self._primary = None
+        self._base_seed = int(getattr(args, "seed", 0)) * 1000003
+        self._step_seed = 0
+        self.eps_generator = None      # optional torch.Generator for the latent noise (transformer_layers.py:45)
+        # A shape-less probe engine gives the canonical parameter list; parameters start on the CPU like the reference's.
+        probe = self._make_engine(1, 5, 21, 20, 224, 224, allocate=False)
+        self._train_names = list(probe.train_info.keys())
+        self._train_info, self._frozen_info = probe.train_info, probe.frozen_info
+        flat_t = torch.zeros(probe.train_size)
+        flat_f = torch.zeros(probe.frozen_size)
+        self._install(flat_t, flat_f)
+        init_reference_style(SimpleNamespace(train_info=probe.train_info, frozen_info=probe.frozen_info, device=torch.device("cpu"),
+                                             view=self._cpu_view, lib=SimpleNamespace(bltvqg_engine_invalidate_frozen=lambda h: None), h=None),
+                             seed=int(getattr(args, "seed", 0)), resnet_state=self._resnet_state(args))
+        if getattr(args, "emb_file", None):
+            self._load_embeddings(args)
+
+    # ---- construction helpers -----------------------------------------------------------------------------------
+    def _make_engine(self, B, Sa, Sp, T, h, w, allocate=True, device="cuda"):
+        a = self.args
+        cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size, Sa, Sp, T,
+                          (h, w), self._dtype, float(getattr(a, "attention_dropout", 0.1)), float(getattr(a, "relu_dropout", 0.1)),
+                          float(getattr(a, "kl_ceiling", 0.5)), float(getattr(a, "aux_ceiling", 1.0)),
+                          float(getattr(a, "image_recon_lambda", 0.1)))
+        e = StepEngine(cfg, device if allocate else "cpu")
+        return e
+
+    def _cpu_view(self, name, which=None):
+        info = self._train_info.get(name) if which in (None, 0) and name in self._train_info else self._frozen_info[name]
+        flat = self._flat_train if (which in (None, 0) and name in self._train_info) else self._flat_frozen
+        return flat[info.offset:info.offset + info.numel].view(info.shape)
+
+    def _install(self, flat_t, flat_f):
+        """Creates the module tree (once) as views into the given flat buffers; later calls only re-point `.data`, so that
+        Parameter objects (and any optimizer holding them) stay valid."""
+        self._flat_train, self._flat_frozen = flat_t, flat_f
+        built = "embedding" in self._modules
+
+        def views():
+            for name, info in self._train_info.items():
+                yield name, flat_t[info.offset:info.offset + info.numel].view(info.shape), "param"
+            for name, info in self._frozen_info.items():
+                yield name, flat_f[info.offset:info.offset + info.numel].view(info.shape), ("buffer" if _is_buffer(name) else "frozen")
+
+        if built:
+            for name, v, kind in views():
+                (self.get_buffer(name) if kind == "buffer" else self.get_parameter(name)).data = v
+            for pre in _bn_prefixes(self._frozen_info.keys()):
+                b = self.get_buffer(pre + ".num_batches_tracked")
+                b.data = b.data.to(flat_t.device)
+            return
+        for name, v, kind in views():
+            _attach(self, name, v, kind)
+        for pre in _bn_prefixes(self._frozen_info.keys()):
+            _attach(self, pre + ".num_batches_tracked", torch.zeros((), dtype=torch.long, device=flat_t.device), "buffer")
+        # aliases of the reference tree (iq.py:32,41,43; encoder_transformer.py:8-10; decoder_transformer.py:9)
+        self.answer_encoder.add_module("embedding", self.embedding)
+        self.answer_encoder.add_module("latent_layer", self.latent_layer)
+        self.decoder.add_module("embedding", self.embedding)
+
+    @staticmethod
+    def _resnet_state(args):
+        path = getattr(args, "resnet_weights", None)
+        if not path:
+            return None
+        return torch.load(path, map_location="cpu", weights_only=True)
+
+    def _load_embeddings(self, args):
+        """GloVe-style text file, reference iq.py:60-71."""
+        import os
+        path = os.path.join(getattr(args, "root_dir", "."), args.emb_file)
+        if not os.path.exists(path):
+            return
+        w = self._cpu_view("embedding.0.weight") if self._flat_train.device.type == "cpu" else None
+        if w is None:
+            return
+        with open(path) as fh:
+            for line in fh:
+                sp = line.split()
+                if len(sp) == args.emb_dim + 1 and sp[0] in self.vocab.word2idx:
+                    w[self.vocab.word2idx[sp[0]]] = torch.tensor([float(x) for x in sp[1:]])
+
+    # ---- reference API -------------------------------------------------------------------------------------------
+    def switch_GVT_train_mode(self, new_mode):
+        """reference iq.py:51-54."""
+        self.latent_transformer = new_mode
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        for e in self._engines.values():
+            e.lib.bltvqg_engine_invalidate_frozen(e.h)
+        return r
+
+    def _aliased(self):
+        """True when the parameters still live inside the primary engine's flat buffers (False after .to()/.cuda()/.float())."""
+        e = self._primary
+        first, last = self._train_names[0], self._train_names[-1]
+        for n in (first, last):
+            if self.get_parameter(n).data_ptr() != e.flat_train.data_ptr() + 4 * e.train_info[n].offset:
+                return False
+        return True
+
+    def _engine_for(self, images, answers, response, target):
+        if not images.is_cuda:
+            raise RuntimeError("IQ.forward runs on MI355X only (libbltvqg_hip.so); there is no CPU fallback. Move the batch to the GPU.")
+        key = (images.shape[0], answers.shape[1], response.shape[1], target.shape[1], images.shape[2], images.shape[3], images.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._make_engine(*key[:6], device=images.device)
+            if self._primary is None:
+                eng.allocate()
+                self._primary = eng
+                self._adopt(eng)
+            else:
+                eng.allocate(share_from=self._primary)
+            self._engines[key] = eng
+        if not self._aliased():
+            self._adopt(self._primary)
+        return eng
+
+    def _adopt(self, eng):
+        """Copies the current parameter values into the engine's flat device buffers and re-points the module tree at them."""
+        with torch.no_grad():
+            eng.load_state({k: v.detach() for k, v in self.state_dict().items()})
+        self._install(eng.flat_train, eng.flat_frozen)
+        for e in self._engines.values():
+            e.lib.bltvqg_engine_invalidate_frozen(e.h)
+
+    def forward(self, images, answers, response, target, eps=None):
+        """reference iq.py:82-114.  Returns (output (B,T,V), z_logit (B,V) | None, kld | None, (image_features, reconstructed))."""
+        if self.latent_transformer and eps is None:
+            eps = torch.randn(images.shape[0], self.args.latent_dim, device=images.device, generator=self.eps_generator)
+        params = [self.get_parameter(n) for n in self._train_names]
+        output, z_logit, kld, feats, recon = _IQFunction.apply(self, images, answers, response, target, eps, *params)
+        if self.training:
+            with torch.no_grad():
+                for pre in _bn_prefixes(self._frozen_info.keys()):
+                    self.get_buffer(pre + ".num_batches_tracked").add_(1)
+        if not self.latent_transformer:
+            return output, None, None, (feats, recon)
+        return output, z_logit, kld, (feats, recon)
+
+    def decode_greedy(self, images, answers, max_decode_length=50):
+        raise NotImplementedError("greedy decoding (reference iq.py:117-152) is the next scope row (SURVEY §8f N1); "
+                                  "this build covers the train step")
+
+    # ---- fused train-step access (used by TrainIQ.fused_training_step and bench.py) ---------------------------------
+    def engine(self, images, answers, response, target):
+        return self._engine_for(images, answers, response, target)

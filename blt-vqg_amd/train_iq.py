@@ -1,0 +1,242 @@
+"""`train_iq.TrainIQ` drop-in (reference train_iq.py:28-261): same constructor, `forward(batch)`, `calculate_losses` 7-tuple,
+`training_step`, `custom_optimizer` (Noam), `configure_optimizers` (Adam), attributes `iter`, `kliter`, `latent_transformer`.
+
+pytorch_lightning is not a dependency: when it is importable TrainIQ subclasses pl.LightningModule (so pl.Trainer can drive
+`training_step`), otherwise torch.nn.Module, and `fit()` below is a minimal trainer loop.  Two ways to run a step:
+  * `training_step(batch, idx)`  — the reference contract: returns the loss tensor; autograd backward runs the HIP backward
+    through `IQ.forward`'s autograd node; clip / optimizer are the caller's (Lightning's) job;
+  * `fused_training_step(batch)` — forward + losses + backward + clip 5 + Adam entirely inside the HIP engine (what bench.py
+    measures); no autograd graph, no per-step host synchronisation.
+"""
+import argparse
+import math
+import os
+from types import SimpleNamespace
+
+import torch
+from torch import nn
+
+from .iq import IQ
+from .trainer import DataParallelStep, kl_weight, noam_lr
+
+try:  # pragma: no cover - not installed in this image
+    import pytorch_lightning as pl
+    _Base = pl.LightningModule
+except Exception:  # noqa: BLE001
+    pl = None
+    _Base = nn.Module
+
+
+class TrainIQ(_Base):
+    def __init__(self, vocab, args):
+        super().__init__()
+        self.latent_transformer = False
+        self.vocab = vocab
+        self.args = args
+        self.hp_string = "{}_{}_{}_{}_{}_{}_{}_{}_{}_{}. {}".format(
+            getattr(args, "input_mode", "ans"), args.emb_dim, "True", args.hidden_dim, args.latent_dim, args.pwffn_dim, args.num_layers,
+            args.num_heads, getattr(args, "lr", 3e-5), getattr(args, "batch_size", 128), getattr(args, "print_note", ""))
+        self.iter = 0
+        self.kliter = 0
+        self.logged = {}
+        self.model = IQ(self.latent_transformer, vocab, args)
+        pad = vocab.word2idx[vocab.SYM_PAD] if hasattr(vocab, "SYM_PAD") else 0
+        self.criterion = nn.CrossEntropyLoss(ignore_index=pad)
+        self.image_recon_criterion = nn.MSELoss()
+        self._optimizer = None
+        self._dp = None
+
+    # ---- reference surface ------------------------------------------------------------------------------------------
+    def _device(self):
+        d = getattr(self.args, "device", "cuda")
+        return torch.device(d) if not isinstance(d, torch.device) else d
+
+    def _unpack(self, batch):
+        # dict order = reference collate_fn (utils/data_loader.py:175); the reference hard-codes .cuda() (train_iq.py:69,114),
+        # routed through args.device here
+        dev = self._device()
+        images, questions, posteriors = batch["images"].to(dev), batch["questions"].to(dev), batch["posteriors"].to(dev)
+        mode = getattr(self.args, "input_mode", "ans")
+        context = batch["answers"].to(dev) if mode == "ans" else batch["answer_types_for_input"].to(dev)
+        return images, context, posteriors, questions
+
+    def forward(self, batch):
+        images, context, posteriors, questions = self._unpack(batch)
+        eps = batch["eps"].to(images.device) if (isinstance(batch, dict) and "eps" in batch and self.latent_transformer) else None
+        output, z, kld_loss, image_recon = self.model(images, context, posteriors, questions, eps=eps)
+        return output, z, kld_loss, image_recon
+
+    def calculate_losses(self, output, image_recon, kld_loss, z_logit, target):
+        """reference train_iq.py:81-103 (same 7-tuple; the five .item() host syncs are the reference's)."""
+        loss_rec = self.criterion(output.reshape(-1, output.size(-1)), target.reshape(-1))
+        loss_img = self.image_recon_criterion(image_recon[0], image_recon[1])
+        if not self.latent_transformer:
+            kld_loss = torch.tensor([0])
+            loss = loss_rec + self.args.image_recon_lambda * loss_img
+            elbo = loss_rec
+            aux = 0
+        else:
+            z_rep = z_logit.unsqueeze(1).expand(-1, output.size(1), -1)
+            loss_aux = self.criterion(z_rep.reshape(-1, z_rep.size(-1)), target.reshape(-1))
+            w = kl_weight(self.kliter, self.args.full_kl_step)
+            aux = loss_aux.item()
+            elbo = loss_rec + kld_loss
+            loss = loss_rec + self.args.kl_ceiling * w * kld_loss + self.args.aux_ceiling * loss_aux + self.args.image_recon_lambda * loss_img
+        return loss, loss_rec.item(), loss_img.item(), math.exp(min(loss_rec.item(), 100)), kld_loss.item(), aux, elbo.item()
+
+    def _phase_switch(self):
+        if self.iter == self.args.num_pretraining_steps:          # train_iq.py:108-111
+            self.latent_transformer = True
+            self.model.switch_GVT_train_mode(True)
+
+    def log(self, name, value, *a, **k):
+        if pl is not None:  # pragma: no cover
+            return super().log(name, value, *a, **k)
+        self.logged[name] = value
+
+    def training_step(self, batch, batch_idx=0):
+        self._phase_switch()
+        output, z_logit, kld_loss, image_recon = self(batch)
+        target = batch["questions"].to(output.device)
+        loss, loss_rec, loss_img, ppl, kld, aux, elbo = self.calculate_losses(output, image_recon, kld_loss, z_logit, target)
+        if self.latent_transformer:
+            self.kliter += 1
+        for k, v in (("train loss", loss), ("train rec loss", loss_rec), ("image recon loss", loss_img), ("perplexity", ppl),
+                     ("kld loss", kld), ("aux loss", aux), ("elbo", elbo)):
+            self.log(k, v)
+        self.custom_optimizer(self.iter)
+        self.iter += 1
+        return loss
+
+    def custom_optimizer(self, step, warmup_steps=4000):
+        """Noam schedule written into the optimizer (reference train_iq.py:252-257)."""
+        lr = noam_lr(step, self.args.hidden_dim, warmup_steps)
+        self.current_lr = lr
+        opt = None
+        if pl is not None and getattr(self, "trainer", None) is not None:  # pragma: no cover
+            opt = self.trainer.lightning_optimizers[0]
+        elif self._optimizer is not None:
+            opt = self._optimizer
+        if opt is not None:
+            opt.param_groups[0]["lr"] = lr
+        return lr
+
+    def configure_optimizers(self):
+        self._optimizer = torch.optim.Adam(self.parameters(), lr=getattr(self.args, "lr", 3e-5))
+        return self._optimizer
+
+    # ---- fused path ----------------------------------------------------------------------------------------------------
+    def fused_training_step(self, batch, dist=None):
+        """One full reference training step inside the HIP engine.  Returns nothing; `last_stats()` syncs and reads the losses."""
+        self._phase_switch()
+        images, context, posteriors, questions = self._unpack(batch)
+        eng = self.model.engine(images, context, posteriors, questions)
+        if self._dp is None or self._dp.e is not eng:
+            self._dp = DataParallelStep(eng, dist)
+        phase2 = self.latent_transformer
+        eps = None
+        if phase2:
+            eps = batch["eps"].to(images.device) if "eps" in batch else torch.randn(images.shape[0], self.args.latent_dim, device=images.device)
+        w = kl_weight(self.kliter, self.args.full_kl_step) if phase2 else 0.0
+        self.model._step_seed += 1
+        self._dp.run(images.contiguous().float(), context.contiguous(), posteriors.contiguous(), questions.contiguous(), eps, phase2,
+                     self.model._base_seed + self.model._step_seed, w, noam_lr(self.iter, self.args.hidden_dim), 5.0)
+        self._last_engine, self._last_w = eng, w
+        if phase2:
+            self.kliter += 1
+        self.iter += 1
+
+    def last_stats(self):
+        st = self._last_engine.stats()
+        st["loss"] = st["rec"] + self.args.image_recon_lambda * st["img"] + (
+            self.args.kl_ceiling * self._last_w * st["kld"] + self.args.aux_ceiling * st["aux"] if self.latent_transformer else 0.0)
+        st["ppl"] = math.exp(min(st["rec"], 100))
+        return st
+
+    def fit(self, loader, max_steps, log_every=100, dist=None):
+        """Minimal stand-in for pl.Trainer(max_steps=..., gradient_clip_val=5).fit (reference train_iq.py:372-374)."""
+        step = 0
+        while step < max_steps:
+            for batch in loader:
+                self.fused_training_step(batch, dist)
+                step += 1
+                if log_every and step % log_every == 0:
+                    print("step %d %s" % (step, {k: round(v, 4) for k, v in self.last_stats().items()}), flush=True)
+                if step >= max_steps:
+                    break
+
+
+def build_parser():
+    """CLI flags and defaults of the reference (train_iq.py:313-351) + precision."""
+    p = argparse.ArgumentParser()
+    p.add_argument("--emb_dim", type=int, default=300)
+    p.add_argument("--hidden_dim", type=int, default=300)
+    p.add_argument("--latent_dim", type=int, default=300)
+    p.add_argument("--pwffn_dim", type=int, default=600)
+    p.add_argument("--num_layers", type=int, default=4)
+    p.add_argument("--num_heads", type=int, default=4)
+    p.add_argument("--lr", type=float, default=3e-5)
+    p.add_argument("--num_pretraining_steps", type=float, default=12000)
+    p.add_argument("--total_training_steps", type=int, default=35000)
+    p.add_argument("--full_kl_step", type=int, default=15000)
+    p.add_argument("--kl_ceiling", type=float, default=0.5)
+    p.add_argument("--aux_ceiling", type=float, default=1.0)
+    p.add_argument("--image_recon_lambda", type=float, default=0.1)
+    p.add_argument("--batch_size", type=int, default=128)
+    p.add_argument("--emb_file", type=str, default="vectors/glove.6B.300d.txt")
+    p.add_argument("--dataset", type=str, default="data/processed/iq_dataset.hdf5")
+    p.add_argument("--val_dataset", type=str, default="data/processed/iq_val_dataset.hdf5")
+    p.add_argument("--vocab", type=str, default="vocab.pkl")
+    p.add_argument("--use_gpu", type=bool, default=True)
+    p.add_argument("--num_gpus", type=int, default=1)
+    p.add_argument("--print_note", type=str, default="")
+    p.add_argument("--input_mode", type=str, default="ans")
+    p.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp32"])
+    p.add_argument("--synthetic", action="store_true", help="train on seeded synthetic batches (no dataset in this environment)")
+    return p
+
+
+class SyntheticVocabulary(object):
+    """Reserved ids of utils/train_utils.py:18-37 + `n` synthetic words."""
+    SYM_PAD, SYM_SOQ, SYM_SOR, SYM_EOS, SYM_UNK, SYM_POS = "<pad>", "<start>", "<resp>", "<end>", "<unk>", "<pos>"
+
+    def __init__(self, size=8000):
+        self.word2idx, self.idx2word = {}, {}
+        for w in (self.SYM_PAD, self.SYM_SOQ, self.SYM_SOR, self.SYM_EOS, self.SYM_UNK, self.SYM_POS):
+            self.add_word(w)
+        i = 0
+        while len(self.word2idx) < size:
+            self.add_word("w%d" % i)
+            i += 1
+
+    def add_word(self, w):
+        if w not in self.word2idx:
+            self.idx2word[len(self.word2idx)] = w
+            self.word2idx[w] = len(self.word2idx)
+
+    def __len__(self):
+        return len(self.word2idx)
+
+
+def main(argv=None):
+    from . import synthetic
+    args = build_parser().parse_args(argv)
+    args.device = torch.device("cuda" if torch.cuda.is_available() and args.use_gpu else "cpu")
+    args.root_dir = os.getcwd()
+    if not args.synthetic:
+        raise SystemExit("only --synthetic batches are available here (the HDF5 loader is scope row N2, SURVEY §8f)")
+    if not os.path.exists(os.path.join(args.root_dir, args.emb_file)):
+        args.emb_file = None
+    vocab = SyntheticVocabulary(8000)
+    model = TrainIQ(vocab, args).to(args.device)
+
+    def loader():
+        i = 0
+        while True:
+            yield synthetic.make_batch(args.batch_size, len(vocab), args.latent_dim, seed=1234 + i)
+            i += 1
+    model.fit(loader(), args.total_training_steps)
+
+
+if __name__ == "__main__":
+    main()

@@ -230,6 +230,10 @@ def main():
                     if c["full"] or k.startswith("encoder_cnn.bn.") or k.startswith("encoder_cnn.cnn.bn1."):
                         out["p1.buf." + k] = v.numpy()
             # the train-mode forward updated BN running stats inside the model; full_state is reloaded each run
+        if name == "small":
+            # state_dict schema of the reference model (260 keys at L=2, aliases included) for tests/test_host_api.py
+            with open(os.path.join(HERE, "state_keys_small.txt"), "w") as fh:
+                fh.write("\n".join(model.state_dict().keys()) + "\n")
         path = os.path.join(HERE, "%s.npz" % name)
         np.savez_compressed(path, **out)
         print(name, "->", path, "%.1f KB" % (os.path.getsize(path) / 1024))

@@ -1,0 +1,121 @@
+"""GPU tests of the drop-in Python surface: models.IQ.forward under torch autograd (the reference contract: the caller computes
+the losses with torch criteria and calls backward) and TrainIQ.training_step / fused_training_step, against the CPU oracle."""
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, oracle_run, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _args(cfg, **kw):
+    a = SimpleNamespace(emb_dim=cfg.emb_dim, hidden_dim=cfg.hidden_dim, latent_dim=cfg.latent_dim, pwffn_dim=cfg.pwffn_dim,
+                        num_layers=cfg.num_layers, num_heads=cfg.num_heads, device="cuda", emb_file=None, root_dir=".", lr=3e-5,
+                        num_pretraining_steps=12000, full_kl_step=15000, kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1,
+                        batch_size=4, input_mode="ans", print_note="", precision="fp32", attention_dropout=0.0, relu_dropout=0.0)
+    a.__dict__.update(kw)
+    return a
+
+
+def _full_state(model, state):
+    full = {}
+    for k in model.state_dict():
+        base = k
+        for alias in ("answer_encoder.embedding.", "decoder.embedding."):
+            if k.startswith(alias):
+                base = "embedding." + k[len(alias):]
+        if k.startswith("answer_encoder.latent_layer."):
+            base = k[len("answer_encoder."):]
+        full[k] = state[base]
+    return full
+
+
+@pytest.mark.parametrize("phase2", [False, True])
+def test_iq_forward_autograd_matches_reference(phase2):
+    """The reference flow: model(...) -> torch criteria -> loss.backward() -> .grad on the nn.Parameters."""
+    from models import IQ
+    from train_iq import SyntheticVocabulary, TrainIQ
+    from oracle import iq_oracle as O
+    z, cfg, state, batch = load_golden("tiny")
+    tag = "p2" if phase2 else "p1"
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")                     # reference flow: TrainIQ(vocab, args).to(device)  (train_iq.py:371)
+    opt = t.configure_optimizers()       # created BEFORE the first forward, like Lightning does
+    if phase2:
+        t.latent_transformer = True
+        t.model.switch_GVT_train_mode(True)
+        t.kliter = int(z[tag + ".kliter"])
+    b = {k: v.cuda() for k, v in batch.items()}
+    output, z_logit, kld, recon = t(b)
+    assert output.shape == (4, 20, cfg.vocab_size) and (z_logit is None) == (not phase2)
+    assert rel_err(output.detach().cpu(), z[tag + ".output"]) < 2e-4
+    assert np.array_equal(output.argmax(-1).cpu().numpy().astype(np.int32), z[tag + ".argmax"])
+    loss, rec, img, ppl, kl, aux, elbo = t.calculate_losses(output, recon, kld, z_logit, b["questions"])
+    assert abs(float(loss) - float(z[tag + ".loss"])) < 1e-3
+    assert abs(rec - float(z[tag + ".loss_rec"])) < 1e-4 and abs(img - float(z[tag + ".loss_img"])) < 1e-4
+    loss.backward()
+    sd_params = dict(t.model.named_parameters())
+    n = 0
+    for k in z.files:
+        if not k.startswith(tag + ".grad."):
+            continue
+        name = k[len(tag) + 6:]
+        ref = torch.from_numpy(z[k])
+        if name == "encoder_cnn.cnn.fc.bias" or float(ref.abs().max()) < 1e-7:
+            continue
+        g = sd_params[name].grad
+        assert g is not None, name
+        assert rel_err(g.cpu(), ref) < 3e-3, (name, rel_err(g.cpu(), ref))
+        n += 1
+    assert n > 40
+    if not phase2:      # unused parameters keep grad None, exactly like the reference
+        assert sd_params["decoder.z_classifier.weight"].grad is None
+        assert sd_params["answer_encoder.r_encoder.layer_norm.weight"].grad is None
+    # the optimizer created before the first forward still owns the live parameters
+    before = sd_params["decoder.output.weight"].detach().clone()
+    for gparam in opt.param_groups:
+        gparam["lr"] = 1e-3
+    opt.step()
+    assert not torch.equal(before, sd_params["decoder.output.weight"].detach())
+    assert int(t.model.state_dict()["encoder_cnn.bn.num_batches_tracked"]) == 1
+
+
+def test_fused_training_steps_match_oracle():
+    """TrainIQ.fused_training_step (everything in the HIP engine) over the phase switch vs the oracle's Adam run."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    from oracle import iq_oracle as O
+    import bltvqg_amd.synthetic as synthetic
+    z, cfg, state, _ = load_golden("tiny")
+    B, hw = 4, 64
+    batches = [synthetic.make_batch(B, cfg.vocab_size, cfg.latent_dim, seed=300 + i, image_hw=hw) for i in range(3)]
+    hp = O.default_hp(num_pretraining_steps=101)
+    final, logs = O.train_steps(state, cfg, batches, hp, start_iter=100)
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg, num_pretraining_steps=101))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")
+    t.iter = 100
+    for i, b in enumerate(batches):
+        t.fused_training_step(b)
+        st = t.last_stats()
+        assert abs(st["rec"] - logs[i]["rec"]) < 1e-3 and abs(st["loss"] - logs[i]["loss"]) < 2e-3, (i, st, logs[i])
+        assert abs(st["grad_norm"] - logs[i]["grad_norm"]) < 2e-3 * logs[i]["grad_norm"]
+    assert t.latent_transformer is True and t.kliter == 2 and t.iter == 103
+    w = t.model.state_dict()["decoder.output.weight"].cpu()
+    assert rel_err(w - state["decoder.output.weight"], final["decoder.output.weight"] - state["decoder.output.weight"]) < 0.1
+
+
+def test_batch_shape_change_shares_parameters():
+    """A second batch size gets its own engine workspace but the same flat parameter / optimiser buffers."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    import bltvqg_amd.synthetic as synthetic
+    z, cfg, state, _ = load_golden("tiny")
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg)).to("cuda")
+    t.fused_training_step(synthetic.make_batch(4, cfg.vocab_size, cfg.latent_dim, seed=1, image_hw=64))
+    t.fused_training_step(synthetic.make_batch(2, cfg.vocab_size, cfg.latent_dim, seed=2, image_hw=64))
+    e = list(t.model._engines.values())
+    assert len(e) == 2 and e[0].flat_train.data_ptr() == e[1].flat_train.data_ptr()
+    assert np.isfinite(t.last_stats()["loss"])

@@ -1,0 +1,124 @@
+"""CPU-side checks of the host mirror of the reference interface (models.IQ / train_iq.TrainIQ): state_dict schema,
+construction-time invariants, schedules, CLI defaults, and that the product path refuses to run without the HIP engine."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+from oracle import iq_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _args(**kw):
+    a = SimpleNamespace(emb_dim=300, hidden_dim=256, latent_dim=256, pwffn_dim=512, num_layers=2, num_heads=4, device="cpu", emb_file=None,
+                        root_dir=".", lr=3e-5, num_pretraining_steps=12000, full_kl_step=15000, kl_ceiling=0.5, aux_ceiling=1.0,
+                        image_recon_lambda=0.1, batch_size=128, input_mode="ans", print_note="")
+    a.__dict__.update(kw)
+    return a
+
+
+def test_state_dict_keys_match_reference_schema():
+    """The 260-entry key set (aliases included) the reference model produces at L=2 (fixture written by make_golden.py)."""
+    from models import IQ
+    from train_iq import SyntheticVocabulary
+    m = IQ(False, SyntheticVocabulary(8000), _args())
+    want = [l.strip() for l in open(os.path.join(GOLDEN, "state_keys_small.txt")) if l.strip()]
+    got = list(m.state_dict().keys())
+    assert len(want) == 260
+    assert set(got) == set(want), (set(got) ^ set(want))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    spec = O.iq_spec(SimpleNamespace(emb_dim=300, hidden_dim=256, latent_dim=256, pwffn_dim=512, num_layers=2, num_heads=4, vocab_size=8000))
+    for k, s in spec.items():
+        assert shapes[k] == tuple(s), k
+    # aliases share storage (iq.py:32,41,43)
+    sd = m.state_dict()
+    assert sd["embedding.0.weight"].data_ptr() == sd["decoder.embedding.0.weight"].data_ptr() == sd["answer_encoder.embedding.0.weight"].data_ptr()
+    assert sd["latent_layer.mean_logvar_prior.0.weight"].data_ptr() == sd["answer_encoder.latent_layer.mean_logvar_prior.0.weight"].data_ptr()
+    n_train = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    n_frozen = sum(p.numel() for p in m.parameters() if not p.requires_grad)
+    assert n_train == 12177792 and n_frozen == 11176512
+    assert all(not p.requires_grad for n, p in m.named_parameters() if n.startswith("encoder_cnn.cnn.") and ".fc." not in n)
+
+
+def test_load_state_dict_round_trip_and_init_statistics():
+    from models import IQ
+    from train_iq import SyntheticVocabulary
+    z, cfg, state, batch = load_golden("tiny")
+    a = _args(emb_dim=cfg.emb_dim, hidden_dim=cfg.hidden_dim, latent_dim=cfg.latent_dim, pwffn_dim=cfg.pwffn_dim, num_layers=cfg.num_layers,
+              num_heads=cfg.num_heads)
+    m = IQ(False, SyntheticVocabulary(cfg.vocab_size), a)
+    # reference initialisers (distribution level)
+    assert float(m.state_dict()["encoder_cnn.cnn.fc.bias"].abs().max()) == 0.0
+    assert abs(float(m.state_dict()["embedding.0.weight"].std()) - 0.01) < 2e-3
+    assert float(m.state_dict()["embedding.0.weight"][0].abs().sum()) > 0          # <pad> row is NOT zero (iq.py:73)
+    w = m.state_dict()["decoder.output.weight"]
+    assert float(w.abs().max()) <= 1.0 / np.sqrt(cfg.hidden_dim) + 1e-6
+    full = dict(m.state_dict())
+    for k in full:
+        base = k
+        for alias in ("answer_encoder.embedding.", "decoder.embedding."):
+            if k.startswith(alias):
+                base = "embedding." + k[len(alias):]
+        if k.startswith("answer_encoder.latent_layer."):
+            base = k[len("answer_encoder."):]
+        full[k] = state[base]
+    m.load_state_dict(full)
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, full[k].to(v.dtype)), k
+    # parameters are views of ONE flat buffer (the all-reduce / Adam unit)
+    p0 = m.get_parameter("decoder.output.weight")
+    assert p0.data_ptr() == m._flat_train.data_ptr()
+
+
+def test_product_path_has_no_cpu_fallback():
+    from models import IQ
+    from train_iq import SyntheticVocabulary, TrainIQ
+    a = _args(hidden_dim=64, latent_dim=64, pwffn_dim=128, emb_dim=20, num_layers=1)
+    t = TrainIQ(SyntheticVocabulary(97), a)
+    import bltvqg_amd.synthetic as synthetic
+    b = synthetic.make_batch(2, 97, 64, image_hw=64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        t(b)
+    assert isinstance(t.model, IQ) and t.iter == 0 and t.kliter == 0 and t.latent_transformer is False
+    src = open(os.path.join(os.path.dirname(GOLDEN), "..", "blt-vqg_amd", "iq.py")).read() + \
+        open(os.path.join(os.path.dirname(GOLDEN), "..", "blt-vqg_amd", "engine.py")).read() + \
+        open(os.path.join(os.path.dirname(GOLDEN), "..", "blt-vqg_amd", "train_iq.py")).read() + \
+        open(os.path.join(os.path.dirname(GOLDEN), "..", "blt-vqg_amd", "trainer.py")).read()
+    assert "oracle" not in src            # the product never imports the checker
+
+
+def test_schedules_match_oracle():
+    from bltvqg_amd.trainer import kl_weight, noam_lr
+    for s in (0, 1, 3999, 4000, 4001, 35000):
+        assert abs(noam_lr(s, 256) - O.noam_lr(s, 256)) < 1e-15
+    for k in (0, 7500, 15000, 20000):
+        assert abs(kl_weight(k, 15000) - O.kl_weight(k, 15000)) < 1e-15
+    assert noam_lr(0, 300) == 0.0
+
+
+def test_cli_defaults_match_reference():
+    from train_iq import build_parser
+    d = vars(build_parser().parse_args([]))
+    want = dict(emb_dim=300, hidden_dim=300, latent_dim=300, pwffn_dim=600, num_layers=4, num_heads=4, lr=3e-5, num_pretraining_steps=12000,
+                total_training_steps=35000, full_kl_step=15000, kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1, batch_size=128,
+                emb_file="vectors/glove.6B.300d.txt", dataset="data/processed/iq_dataset.hdf5", val_dataset="data/processed/iq_val_dataset.hdf5",
+                vocab="vocab.pkl", use_gpu=True, num_gpus=1, print_note="", input_mode="ans")
+    for k, v in want.items():
+        assert d[k] == v, k
+
+
+def test_phase_switch_and_counters():
+    from train_iq import SyntheticVocabulary, TrainIQ
+    a = _args(hidden_dim=64, latent_dim=64, pwffn_dim=128, emb_dim=20, num_layers=1, num_pretraining_steps=3)
+    t = TrainIQ(SyntheticVocabulary(97), a)
+    t.iter = 2
+    t._phase_switch()
+    assert t.latent_transformer is False
+    t.iter = 3
+    t._phase_switch()
+    assert t.latent_transformer is True and t.model.latent_transformer is True
+    assert t.custom_optimizer(4000) == pytest.approx(O.noam_lr(4000, 64))

@@ -93,7 +93,7 @@ int bltvqg_bn_relu_maxpool(int dtype, const void* x, const float* scale, const f
     return blt_bn_relu_maxpool(dtype, x, scale, shift, y, N, Hi, Wi, C, (hipStream_t)stream);
 }
 int bltvqg_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, void* stream) {
-    return blt_avgpool(dtype, x, y, N, HW, C, (hipStream_t)stream);
+    return blt_avgpool(dtype, x, y, N, HW, C, 0, (hipStream_t)stream);
 }
 int bltvqg_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, float* running_mean,
                     float* running_var, int B, int C, float eps, float momentum, void* stream) {

@@ -82,7 +82,8 @@ struct bltvqg_engine {
     int *ids_all, *pos_all, *tgt_shift, *tgt32, *ctx32, *post32;
     float* counters;
     float* stats;               // 8 floats
-    void *img, *pool0, *pooled, *featpre, *feats;
+    void *img, *pool0, *feats;
+    float *pooled, *featpre, *feats32, *dfeats32, *dfeatpre32;   // the CNN head (avg-pool -> fc -> BatchNorm1d) stays in fp32
     float *bn1_mean, *bn1_rstd;
     std::vector<ConvSpec> convs;
     float *stat_sum, *stat_sq;
@@ -277,8 +278,9 @@ struct bltvqg_engine {
             const int ph = (convs[0].Ho + 2 - 3) / 2 + 1, pw = (convs[0].Wo + 2 - 3) / 2 + 1;
             pool0 = AT((int64_t)B * ph * pw * 64);
         }
-        pooled = AT((int64_t)B * 512);
-        featpre = AT((int64_t)B * H); feats = AT((int64_t)B * H);
+        pooled = AF((int64_t)B * 512);
+        featpre = AF((int64_t)B * H); feats32 = AF((int64_t)B * H); dfeats32 = AF((int64_t)B * H); dfeatpre32 = AF((int64_t)B * H);
+        feats = AT((int64_t)B * H);
         bn1_mean = AF(H); bn1_rstd = AF(H);
         // embedding
         emb_rows = AT((int64_t)Mtot * Epad);
@@ -537,10 +539,18 @@ struct bltvqg_engine {
                 x = cb.out;
                 cin = cout;
             }
-        RC(blt_avgpool(dt, x, pooled, B, convs.back().Ho * convs.back().Wo, 512, s));
-        RC(blt_gemm(dt, lin(pooled, 512, "encoder_cnn.cnn.fc.weight", "encoder_cnn.cnn.fc.bias", featpre, H, B), s));
-        return blt_bn1d_fwd(dt, featpre, P("encoder_cnn.bn.weight"), P("encoder_cnn.bn.bias"), feats, bn1_mean, bn1_rstd,
-                            FZ("encoder_cnn.bn.running_mean"), FZ("encoder_cnn.bn.running_var"), B, H, 1e-5f, 0.01f, s);
+        // Head in fp32 (exact-fp32 MFMA on the fp32 master weights): BatchNorm1d removes the common mode of the pooled feature
+        // across the batch, so bf16 rounding of these tiny [B,512]/[B,H] tensors would be amplified into the image feature.
+        RC(blt_avgpool(dt, x, pooled, B, convs.back().Ho * convs.back().Wo, 512, 1, s));
+        {
+            const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
+            GemmArgs g = mk(pooled, 512, 0, train + pw.off, 512, 0, featpre, H, B, H, 512);
+            g.bias = P("encoder_cnn.cnn.fc.bias");
+            RC(blt_gemm(BLT_F32, g, s));
+        }
+        RC(blt_bn1d_fwd(BLT_F32, featpre, P("encoder_cnn.bn.weight"), P("encoder_cnn.bn.bias"), feats32, bn1_mean, bn1_rstd,
+                        FZ("encoder_cnn.bn.running_mean"), FZ("encoder_cnn.bn.running_var"), B, H, 1e-5f, 0.01f, s));
+        return blt_cast_rows(BLT_F32, feats32, H, dt, feats, H, B, H, s);
     }
 
     int mlp3_fwd(const std::string& net, const void* x, int din, void* h1, void* h2, void* out, hipStream_t s) {
@@ -781,9 +791,15 @@ struct bltvqg_engine {
             RC(blt_embed_scatter(dt, dE, Epad, ids_all, G("embedding.0.weight"), Memb, E, 0, s));
         }
         // ---- CNN head: BatchNorm1d -> fc (the backbone itself is frozen, encoder_cnn.py:18-19) ----
-        RC(blt_bn1d_bwd(dt, d_feats, featpre, P("encoder_cnn.bn.weight"), bn1_mean, bn1_rstd, g_b1, G("encoder_cnn.bn.weight"),
+        RC(blt_cast_rows(dt, d_feats, H, BLT_F32, dfeats32, H, B, H, s));
+        RC(blt_bn1d_bwd(BLT_F32, dfeats32, featpre, P("encoder_cnn.bn.weight"), bn1_mean, bn1_rstd, dfeatpre32, G("encoder_cnn.bn.weight"),
                         G("encoder_cnn.bn.bias"), B, H, s));
-        RC(wgrad(g_b1, H, pooled, 512, "encoder_cnn.cnn.fc.weight", "encoder_cnn.cnn.fc.bias", B, s));
+        {
+            const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
+            GemmArgs g = mk(dfeatpre32, H, 1, pooled, 512, 1, grad + pw.off, 512, H, 512, B);
+            RC(blt_gemm(BLT_F32, g, s));
+            RC(blt_colsum(BLT_F32, dfeatpre32, H, B, H, G("encoder_cnn.cnn.fc.bias"), 1, s));
+        }
         if (bucket_ev[1]) (void)hipEventRecord(bucket_ev[1], s);
         if (bucket_ev[2]) (void)hipEventRecord(bucket_ev[2], s);
         last_bwd_phase2 = phase2;
@@ -955,14 +971,19 @@ int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
     switch (what) {
         case 0: return blt_cast_rows(e->dt, e->logits, e->ldV, BLT_F32, dst, e->V, e->Mt, e->V, s);
         case 1: return blt_cast_rows(e->dt, e->zlogit, e->ldV, BLT_F32, dst, e->V, e->B, e->V, s);
-        case 2: return blt_cast_rows(e->dt, e->feats, e->H, BLT_F32, dst, e->H, e->B, e->H, s);
+        case 2: return blt_cast_rows(BLT_F32, e->feats32, e->H, BLT_F32, dst, e->H, e->B, e->H, s);
         case 3: return blt_cast_rows(e->dt, e->recon, e->H, BLT_F32, dst, e->H, e->B, e->H, s);
         case 4:
             if (hipMemcpyAsync(dst, e->stats, 8 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return BLT_ERR_HIP;
             return hipMemcpyAsync(dst + 5, e->counters, sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? BLT_OK : BLT_ERR_HIP;
         case 5: return blt_cast_rows(e->dt, e->enc.out, e->H, BLT_F32, dst, e->H, e->Ma, e->H, s);
         case 6: return blt_cast_rows(e->dt, e->dec.out, e->H, BLT_F32, dst, e->H, e->Mt, e->H, s);
-        default: blt_set_error("engine_read: unknown item %d", what); return BLT_ERR_ARG;
+        default:
+            if (what >= 100 && what < 100 + (int)e->convs.size()) {      // debug: conv stage outputs (NHWC), after their in-place BatchNorm
+                const ConvSpec& cs = e->convs[what - 100];
+                return blt_cast_rows(e->dt, cs.out, cs.Cout, BLT_F32, dst, cs.Cout, (long)e->B * cs.Ho * cs.Wo, cs.Cout, s);
+            }
+            blt_set_error("engine_read: unknown item %d", what); return BLT_ERR_ARG;
     }
 }
 

@@ -68,7 +68,7 @@ int blt_bn_apply(int dtype, const void* x, const float* scale, const float* shif
 // y[n,ho,wo,c] = max 3x3/2 pad1 of relu(x*scale+shift)
 int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
                         int C, hipStream_t s);
-int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, hipStream_t s);
+int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, int out_f32, hipStream_t s);
 // BatchNorm1d over the batch (train mode); saves mean / rstd; updates running stats (unbiased var)
 int blt_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                  float* running_mean, float* running_var, int B, int C, float eps, float momentum, hipStream_t s);

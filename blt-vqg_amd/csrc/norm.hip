@@ -242,8 +242,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
     }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int HW, int C) {
+template <typename T, typename TO>
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, TO* __restrict__ y, int N, int HW, int C) {
     const int cpr = C >> 3;
     const long total = (long)N * cpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T
         const float inv = 1.f / (float)HW;
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] *= inv;
-        Vec8<T>::store(y + n * C + cc * 8, a);
+        Vec8<TO>::store(y + n * C + cc * 8, a);
     }
 }
 
@@ -389,12 +389,12 @@ int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const floa
     return blt_check_launch("bn_relu_maxpool");
 }
 
-int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, hipStream_t s) {
+int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, int out_f32, hipStream_t s) {
     BLT_REQUIRE(x && y && C % 8 == 0 && N > 0 && HW > 0, "avgpool: bad args");
     const long n = (long)N * (C / 8);
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL(avgpool_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, (float*)y, N, HW, C),
-               hipLaunchKernelGGL(avgpool_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, HW, C));
+    if (dtype == BLT_F32) hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, (float*)y, N, HW, C);
+    else if (out_f32) hipLaunchKernelGGL((avgpool_kernel<bf16, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (float*)y, N, HW, C);
+    else hipLaunchKernelGGL((avgpool_kernel<bf16, bf16>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, HW, C);
     return blt_check_launch("avgpool");
 }
 

@@ -14,7 +14,13 @@ T_Q, S_POST, S_ANS, S_CAT = 20, 21, 5, 3
 def make_batch(batch_size, vocab_size, latent_dim, seed=1234, image_hw=224, first_word=6):
     g = torch.Generator().manual_seed(int(seed))
     B, V = batch_size, vocab_size
-    images = torch.randn(B, 3, image_hw, image_hw, generator=g)
+    # image-like statistics: per-sample colour offset + a smooth low-frequency pattern + pixel noise, so that samples differ from
+    # each other the way normalised photographs do (pure i.i.d. noise makes every sample's pooled feature nearly identical, which
+    # BatchNorm1d over the batch then amplifies into a rounding-noise test)
+    coarse = torch.randn(B, 3, max(image_hw // 16, 2), max(image_hw // 16, 2), generator=g)
+    images = torch.nn.functional.interpolate(coarse, size=(image_hw, image_hw), mode="bilinear", align_corners=False)
+    images = images + 0.5 * torch.randn(B, 3, 1, 1, generator=g) + 0.5 * torch.randn(B, 3, image_hw, image_hw, generator=g)
+    images = images.contiguous()
     questions = torch.zeros(B, T_Q, dtype=torch.long)
     posteriors = torch.zeros(B, S_POST, dtype=torch.long)
     answers = torch.zeros(B, S_ANS, dtype=torch.long)

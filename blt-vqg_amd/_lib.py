@@ -35,6 +35,7 @@ class Config(ctypes.Structure):
 SIGNATURES = {
     "bltvqg_version": (I, []),
     "bltvqg_last_error_string": (S, []),
+    "bltvqg_debug_set": (None, [I, I]),
     "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv2d_stat_rows": (I, [I, I, I, I, I, I, I, I]),

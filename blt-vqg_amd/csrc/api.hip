@@ -6,6 +6,8 @@ static inline int ilog2i(int x) { int l = 0; while ((1 << l) < x) ++l; return l;
 
 extern "C" {
 
+void bltvqg_debug_set(int key, int value) { blt_debug_set(key, value); }
+
 int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, int ldb, int transB, void* C, int ldc, int M, int N, int K,
                 const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id, const void* maskY, int ldm, float mask_scale,
                 const void* R, int ldr, int accumulate, int out_f32, int force_tile, int split_k, void* stream) {

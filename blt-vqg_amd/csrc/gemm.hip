@@ -183,84 +183,10 @@ __device__ __forceinline__ void compute_tile(const char* a_buf, const char* b_bu
     }
 }
 
-template <typename T, int BM, int BN, bool TA, bool TB, int LOADER>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-    typedef Cfg<T, BM, BN, TA, TB, LOADER> C;
-    constexpr int ES = C::ES, CE = C::CE, BK = C::BK, CS = C::CS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const T* __restrict__ Ag = (const T*)p.A;
-    const T* __restrict__ Bg = (const T*)p.B;
-
-    ConvRows<C::CH_A> cr;
-    if constexpr (LOADER != LD_PLAIN) {
-#pragma unroll
-        for (int i = 0; i < C::CH_A; ++i) {
-            const int gm = m0 + ((tid + i * 256) >> 3);
-            const int hw = p.cg.Ho * p.cg.Wo;
-            const int n = gm / hw, rem = gm - n * hw;
-            const int ho = rem / p.cg.Wo, wo = rem - ho * p.cg.Wo;
-            if constexpr (LOADER == LD_CONV) {
-                cr.base[i] = (gm < p.M) ? n * p.cg.Hi * p.cg.Wi : -1;
-                cr.h0[i] = ho * p.cg.stride - p.cg.pad;
-                cr.w0[i] = wo * p.cg.stride - p.cg.pad;
-            } else {   // stem: Hi/Wi are the PADDED image dims; the border already holds the conv padding
-                cr.base[i] = (gm < p.M) ? (n * p.cg.Hi + ho * p.cg.stride) * p.cg.Wi + wo * p.cg.stride : -1;
-                cr.h0[i] = 0; cr.w0[i] = 0;
-            }
-        }
-    }
-
-    // split-K: gridDim.y slices of the K-tile range
-    const int nk_total = (p.K + BK - 1) / BK;
-    const int per = (nk_total + (int)gridDim.y - 1) / (int)gridDim.y;
-    const int kt0 = (int)blockIdx.y * per;
-    const int kt1 = (kt0 + per < nk_total) ? kt0 + per : nk_total;
-
-    f32x4 acc[C::TM][C::TN];
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int l15 = lane & 15, lg = lane >> 4;
-
-    if (kt0 < kt1) {
-        uint4 ra[C::CH_A], rb[C::CH_B];
-        load_a<C, T>(p, Ag, cr, m0, kt0 * BK, tid, ra);
-        load_b<C, T>(p, Bg, n0, kt0 * BK, tid, rb);
-        store_ab<C>(smem, smem + C::A_BYTES, tid, ra, rb);
-        __syncthreads();
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int cur = (kt - kt0) & 1;
-            char* a_cur = smem + cur * C::STAGE;
-            char* a_nxt = smem + (cur ^ 1) * C::STAGE;
-            const bool more = kt + 1 < kt1;
-            if (more) {
-                load_a<C, T>(p, Ag, cr, m0, (kt + 1) * BK, tid, ra);
-                load_b<C, T>(p, Bg, n0, (kt + 1) * BK, tid, rb);
-            }
-            compute_tile<C, T>(a_cur, a_cur + C::A_BYTES, wm, wn, l15, lg, acc);
-            if (more) store_ab<C>(a_nxt, a_nxt + C::A_BYTES, tid, ra, rb);
-            __syncthreads();
-        }
-    }
-
-    // ---- accumulators -> LDS (fp32 C tile) ---------------------------------------------------------
-    float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < C::TM; ++i)
-#pragma unroll
-        for (int j = 0; j < C::TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Cs[(wm * C::WM + i * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[i][j][r];
-    __syncthreads();
-
+// Epilogue shared by the GEMM kernels: Cs is the block's fp32 result tile in LDS (row stride BN + 4 floats).
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* Cs, int tile_m, int m0, int n0, int tid) {
+    constexpr int ES = sizeof(T), CE = 16 / ES, CS = BN + 4;
     // ---- per-column statistics of the raw result (BatchNorm2d batch statistics, encoder_cnn.py:33) --------
     if (p.stat_sum != nullptr) {
         for (int c = tid; c < BN * 2; c += 256) {
@@ -402,6 +328,282 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 }
 
 template <typename T, int BM, int BN, bool TA, bool TB, int LOADER>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    typedef Cfg<T, BM, BN, TA, TB, LOADER> C;
+    constexpr int ES = C::ES, CE = C::CE, BK = C::BK, CS = C::CS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const T* __restrict__ Ag = (const T*)p.A;
+    const T* __restrict__ Bg = (const T*)p.B;
+
+    ConvRows<C::CH_A> cr;
+    if constexpr (LOADER != LD_PLAIN) {
+#pragma unroll
+        for (int i = 0; i < C::CH_A; ++i) {
+            const int gm = m0 + ((tid + i * 256) >> 3);
+            const int hw = p.cg.Ho * p.cg.Wo;
+            const int n = gm / hw, rem = gm - n * hw;
+            const int ho = rem / p.cg.Wo, wo = rem - ho * p.cg.Wo;
+            if constexpr (LOADER == LD_CONV) {
+                cr.base[i] = (gm < p.M) ? n * p.cg.Hi * p.cg.Wi : -1;
+                cr.h0[i] = ho * p.cg.stride - p.cg.pad;
+                cr.w0[i] = wo * p.cg.stride - p.cg.pad;
+            } else {   // stem: Hi/Wi are the PADDED image dims; the border already holds the conv padding
+                cr.base[i] = (gm < p.M) ? (n * p.cg.Hi + ho * p.cg.stride) * p.cg.Wi + wo * p.cg.stride : -1;
+                cr.h0[i] = 0; cr.w0[i] = 0;
+            }
+        }
+    }
+
+    // split-K: gridDim.y slices of the K-tile range
+    const int nk_total = (p.K + BK - 1) / BK;
+    const int per = (nk_total + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int kt0 = (int)blockIdx.y * per;
+    const int kt1 = (kt0 + per < nk_total) ? kt0 + per : nk_total;
+
+    f32x4 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    if (kt0 < kt1) {
+        uint4 ra[C::CH_A], rb[C::CH_B];
+        load_a<C, T>(p, Ag, cr, m0, kt0 * BK, tid, ra);
+        load_b<C, T>(p, Bg, n0, kt0 * BK, tid, rb);
+        store_ab<C>(smem, smem + C::A_BYTES, tid, ra, rb);
+        __syncthreads();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int cur = (kt - kt0) & 1;
+            char* a_cur = smem + cur * C::STAGE;
+            char* a_nxt = smem + (cur ^ 1) * C::STAGE;
+            const bool more = kt + 1 < kt1;
+            if (more) {
+                load_a<C, T>(p, Ag, cr, m0, (kt + 1) * BK, tid, ra);
+                load_b<C, T>(p, Bg, n0, (kt + 1) * BK, tid, rb);
+            }
+            compute_tile<C, T>(a_cur, a_cur + C::A_BYTES, wm, wn, l15, lg, acc);
+            if (more) store_ab<C>(a_nxt, a_nxt + C::A_BYTES, tid, ra, rb);
+            __syncthreads();
+        }
+    }
+
+    // ---- accumulators -> LDS (fp32 C tile) ---------------------------------------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wm * C::WM + i * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+
+    gemm_epilogue<T, BM, BN>(p, Cs, tile_m, m0, n0, tid);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16, both operands k-contiguous (Linear forward, implicit-GEMM conv, stem): LDS-DMA ring.
+//   * global_load_lds_dwordx4 writes each operand tile straight into LDS (no VGPR staging, no ds_write); the LDS image is
+//     lane-linear (unpadded 128-byte rows), bank conflicts are removed by an XOR swizzle applied on the SOURCE chunk index
+//     (slot s of row r holds global chunk s ^ (r & 7)) and again on the ds_read_b128 address;
+//   * NST = 3 stage ring, two K-tiles in flight across the barrier: counted s_waitcnt vmcnt(N) + raw s_barrier, one barrier
+//     per K-tile; out-of-range chunks (M/N/K tails, conv padding) are fetched from a 16-byte zero page.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint4 g_zero_page[1];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int LOADER>
+struct DmaCfg {
+    static constexpr int NST = 3;
+    static constexpr int BK = 64;
+    static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    static constexpr int CH_A = BM * 8 / 256, CH_B = BN * 8 / 256;      // DMA instructions per wave per tile
+    static constexpr int CS = BN + 4;
+    static constexpr int LDS_BYTES = (NST * STAGE > BM * CS * 4) ? NST * STAGE : BM * CS * 4;
+};
+
+template <int BM, int BN, int LOADER>
+__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
+    typedef DmaCfg<BM, BN, LOADER> C;
+    constexpr int BK = C::BK, CS = C::CS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: it addresses the LDS-DMA destination
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16* __restrict__ Ag = (const bf16*)p.A;
+    const bf16* __restrict__ Bg = (const bf16*)p.B;
+    const void* zero = (const void*)g_zero_page;
+
+    // DMA instruction j of this wave covers LDS chunks c = (j*4 + wave)*64 + lane: row = c >> 3, slot = c & 7, and fetches
+    // global chunk gc = slot ^ (row & 7) of that row.  Everything that does not depend on the K-tile is hoisted here, so that
+    // one DMA costs a 64-bit add, the bounds test and a select per K-tile (the per-tile (r, s, c0) of a conv tap is scalar).
+    long a_off[C::CH_A];          // element offset of the lane's chunk at k0 = 0 (tap (0,0) for convs); < 0 = row out of range
+    int a_gk[C::CH_A];            // k offset of the chunk inside a K-tile (gc * 8)
+    int a_h0[C::CH_A], a_w0[C::CH_A];
+#pragma unroll
+    for (int j = 0; j < C::CH_A; ++j) {
+        const int c = (j * 4 + wave) * 64 + lane;
+        const int row = c >> 3, gc = (c & 7) ^ (row & 7);
+        const int gm = m0 + row;
+        a_gk[j] = gc * 8;
+        a_h0[j] = 0; a_w0[j] = 0;
+        if constexpr (LOADER == LD_PLAIN) {
+            a_off[j] = (gm < p.M) ? (long)gm * p.lda + gc * 8 : -1;
+        } else {
+            const int hw = p.cg.Ho * p.cg.Wo;
+            const int n = gm / hw, rem = gm - n * hw;
+            const int ho = rem / p.cg.Wo, wo = rem - ho * p.cg.Wo;
+            if constexpr (LOADER == LD_CONV) {
+                a_h0[j] = ho * p.cg.stride - p.cg.pad;
+                a_w0[j] = wo * p.cg.stride - p.cg.pad;
+                a_off[j] = (gm < p.M) ? (((long)n * p.cg.Hi + a_h0[j]) * p.cg.Wi + a_w0[j]) * p.cg.Cin + gc * 8 : -(1L << 40);
+            } else {   // stem: k = r*32 + pixel*4 + c on the zero-bordered NHWC4 image; a K-tile spans two filter rows
+                a_off[j] = (gm < p.M) ? ((((long)n * p.cg.Hi + ho * 2 + (gc >> 2)) * p.cg.Wi + wo * 2 + (gc & 3) * 2) << 2) : -1;
+            }
+        }
+    }
+    long b_off[C::CH_B];
+    int b_gk[C::CH_B];
+#pragma unroll
+    for (int j = 0; j < C::CH_B; ++j) {
+        const int c = (j * 4 + wave) * 64 + lane;
+        const int row = c >> 3, gc = (c & 7) ^ (row & 7);
+        const int gn = n0 + row;
+        b_gk[j] = gc * 8;
+        b_off[j] = (gn < p.N) ? (long)gn * p.ldb + gc * 8 : -1;
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* a_st = smem + stage * C::STAGE;
+        char* b_st = a_st + C::A_BYTES;
+        const int k0 = kt * BK;
+        // scalar (wave-uniform) part of the A address for this K-tile
+        long a_koff = k0;
+        int tap_r = 0, tap_s = 0;
+        if constexpr (LOADER == LD_CONV) {       // Cin % 64 == 0: the whole K-tile lies inside one filter tap (r, s)
+            const int q = k0 >> p.cg.cin_log2, c0 = k0 & (p.cg.Cin - 1);
+            tap_r = q / p.cg.KW;
+            tap_s = q - tap_r * p.cg.KW;
+            a_koff = ((long)tap_r * p.cg.Wi + tap_s) * p.cg.Cin + c0;
+        } else if constexpr (LOADER == LD_STEM) {
+            a_koff = ((long)(2 * kt) * p.cg.Wi) << 2;
+        }
+#pragma unroll
+        for (int j = 0; j < C::CH_A; ++j) {
+            bool ok = (k0 + a_gk[j] < p.K);
+            if constexpr (LOADER == LD_CONV) {
+                ok = ok && (a_off[j] > -(1L << 39)) && ((unsigned)(a_h0[j] + tap_r) < (unsigned)p.cg.Hi) &&
+                     ((unsigned)(a_w0[j] + tap_s) < (unsigned)p.cg.Wi);
+            } else {
+                ok = ok && (a_off[j] >= 0);
+            }
+            const void* src = ok ? (const void*)(Ag + a_off[j] + a_koff) : zero;
+            dma16(src, a_st + (j * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < C::CH_B; ++j) {
+            const bool ok = (b_off[j] >= 0) && (k0 + b_gk[j] < p.K);
+            const void* src = ok ? (const void*)(Bg + b_off[j] + k0) : zero;
+            dma16(src, b_st + (j * 4 + wave) * 1024);
+        }
+    };
+
+    f32x4 acc[C::TM][C::TN];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lg = lane >> 4;
+
+    const int nk = (p.K + BK - 1) / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<C::CH_A + C::CH_B>();      // tile kt landed (this wave's part); tile kt+1 may still fly
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                          // every wave's part of tile kt landed; stage (kt+2)%3 is free
+        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % C::NST);
+        const char* a_st = smem + (kt % C::NST) * C::STAGE;
+        const char* b_st = a_st + C::A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[C::TM], bfr[C::TN];
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) {
+                const int r = wm * C::WM + i * 16 + l15;
+                af[i] = *reinterpret_cast<const bf16x8*>(a_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) {
+                const int r = wn * C::WN + j * 16 + l15;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();          // all MFMA reads of the ring are done before the C tile overwrites it
+
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                Cs[(wm * C::WM + i * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+    gemm_epilogue<bf16, BM, BN>(p, Cs, tile_m, m0, n0, tid);
+}
+
+template <int BM, int BN, int LOADER>
+int launch_dma(const GemmArgs& a, hipStream_t stream) {
+    typedef DmaCfg<BM, BN, LOADER> C;
+    static bool attr_set = false;
+    auto kern = gemm_dma_kernel<BM, BN, LOADER>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
+            blt_set_error("gemm: hipFuncSetAttribute(%d) failed", C::LDS_BYTES);
+            return BLT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles, 1), dim3(256), C::LDS_BYTES, stream, a);
+    return blt_check_launch("gemm_dma");
+}
+
+template <int BM, int BN>
+int dispatch_dma(const GemmArgs& a, hipStream_t s) {
+    if (a.is_conv == 2) return launch_dma<BM, BN, LD_STEM>(a, s);
+    if (a.is_conv) return launch_dma<BM, BN, LD_CONV>(a, s);
+    return launch_dma<BM, BN, LD_PLAIN>(a, s);
+}
+
+template <typename T, int BM, int BN, bool TA, bool TB, int LOADER>
 int launch(const GemmArgs& a, int splits, hipStream_t stream) {
     typedef Cfg<T, BM, BN, TA, TB, LOADER> C;
     static bool attr_set = false;
@@ -437,6 +639,10 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 
 }  // namespace
 
+// process-wide tuning switches for A/B benchmarking (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile
+static int g_debug[4] = {0, 0, 0, 0};
+void blt_debug_set(int key, int value) { if (key >= 0 && key < 4) g_debug[key] = value; }
+
 // tile heuristic: 128-wide tiles once they fill the chip; a 64-column tile when N <= 64 (Cout = 64 convolutions)
 void blt_gemm_tile2(const GemmArgs& a, int* bm, int* bn) {
     if (a.force_tile == 64) { *bm = 64; *bn = 64; return; }
@@ -453,7 +659,9 @@ void blt_gemm_tile2(const GemmArgs& a, int* bm, int* bn) {
     *bm = 64; *bn = 64;
 }
 
-int blt_gemm_tile(const GemmArgs& a) {
+int blt_gemm_tile(const GemmArgs& a_in) {
+    GemmArgs a = a_in;
+    if (g_debug[1] && !a.force_tile) a.force_tile = g_debug[1];
     int bm, bn;
     blt_gemm_tile2(a, &bm, &bn);
     return bm;
@@ -478,7 +686,10 @@ int blt_gemm_splits(const GemmArgs& a, int dtype) {
     return (int)s;
 }
 
-int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
+int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    if (g_debug[0]) a.no_dma = 1;
+    if (g_debug[1] && !a.force_tile) a.force_tile = g_debug[1];
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "gemm: bad dtype %d", dtype);
     BLT_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
     BLT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -508,6 +719,12 @@ int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream) {
     int bm, bn;
     blt_gemm_tile2(a, &bm, &bn);
     const int splits = blt_gemm_splits(a, dtype);
+    const bool dma_ok = (a.is_conv != 1) || (a.cg.Cin % 64 == 0);      // the DMA conv loader wants one filter tap per K-tile
+    if (dtype == BLT_BF16 && !a.transA && !a.transB && splits == 1 && !a.no_dma && dma_ok) {
+        if (bm == 128 && bn == 128) return dispatch_dma<128, 128>(a, stream);
+        if (bm == 128 && bn == 64) return dispatch_dma<128, 64>(a, stream);
+        return dispatch_dma<64, 64>(a, stream);
+    }
     if (dtype == BLT_BF16) return dispatch_tile<bf16>(a, bm, bn, splits, stream);
     return dispatch_tile<float>(a, bm, bn, splits, stream);
 }

@@ -41,6 +41,7 @@ struct GemmArgs {
     float* stat_sum = nullptr;   // [2*tiles_m, N] per-half-tile column sums of the raw accumulators
     float* stat_sq = nullptr;
     int is_conv = 0;             // 1 = NHWC implicit-GEMM gather, 2 = 7x7/2 stem on a zero-bordered NHWC4 image (cg.Hi/Wi = padded dims)
+    int no_dma = 0;              // 1 = force the register-staged kernel (A/B testing of the LDS-DMA ring)
     int split_k = 0;             // max K-splits (fp32 atomic accumulation) for the weight-gradient form; 0 = off
     ConvGeom cg = {};
     int force_tile = 0;          // 0 = heuristic, 64 or 128
@@ -48,6 +49,7 @@ struct GemmArgs {
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
 int blt_gemm_tile(const GemmArgs& a);
+void blt_debug_set(int key, int value);
 int blt_gemm_splits(const GemmArgs& a, int dtype);
 
 // ---- normalisation -----------------------------------------------------------------

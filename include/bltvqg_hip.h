@@ -36,6 +36,8 @@ extern "C" {
 
 int bltvqg_version(void);
 const char* bltvqg_last_error_string(void);
+/* tuning switches for A/B benchmarks: key 0 = disable the LDS-DMA GEMM ring (value 1), key 1 = force a GEMM tile (64/128/12864) */
+void bltvqg_debug_set(int key, int value);
 
 /* ---------------- operator-level entry points ---------------- */
 

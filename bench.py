@@ -103,8 +103,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BLT_FORCE_DIST") == "1":      # BLT_FORCE_DIST: rehearse the RCCL path with one rank
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import bltvqg_amd.synthetic as synthetic
@@ -120,8 +122,9 @@ def main():
     eng = StepEngine(c, dev)
     eng.allocate()
     init_reference_style(eng, seed=0)                      # same weights on every rank
-    step = DataParallelStep(eng, dist if world > 1 else None)
-    batch = synthetic.make_batch(B, cfg["vocab_size"], cfg["latent_dim"], seed=1234 + rank)
+    step = DataParallelStep(eng, dist)
+    from bltvqg_amd.trainer import shard_seed
+    batch = synthetic.make_batch(B, cfg["vocab_size"], cfg["latent_dim"], seed=shard_seed(1234, rank))
     d = {k: v.to(dev) for k, v in batch.items() if k in ("images", "answers", "posteriors", "questions")}
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
 

@@ -68,6 +68,26 @@ def init_reference_style(eng, seed=0, resnet_state=None):
     eng.lib.bltvqg_engine_invalidate_frozen(eng.h)
 
 
+def active_buckets(buckets, phase2):
+    """Gradient buckets that carry gradients in this phase: the phase-2-only bucket is skipped before the switch."""
+    return [(i, off, n) for i, (off, n, late) in enumerate(buckets) if phase2 or not late]
+
+
+def allreduce_bucket(dist, flat_grad, off, n):
+    """Mean of one contiguous gradient bucket across ranks, in place (RCCL has AVG; gloo — used by the CPU tests — only SUM)."""
+    view = flat_grad[off:off + n]
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(view, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(view, op=dist.ReduceOp.SUM)
+        view.div_(dist.get_world_size())
+
+
+def shard_seed(base_seed, rank):
+    """Each rank draws its own shard of the global batch (weak scaling: per-GPU batch fixed)."""
+    return int(base_seed) + int(rank)
+
+
 class DataParallelStep(object):
     """forward -> fused losses + backward -> (overlapped gradient all-reduce) -> clip + Adam."""
 
@@ -84,12 +104,10 @@ class DataParallelStep(object):
     def reduce_gradients(self, phase2):
         e, dist = self.e, self.dist
         main = torch.cuda.current_stream(e.device)
-        for i, (off, n, late) in enumerate(self.buckets):
-            if late and not phase2:
-                continue          # these parameters receive no gradient before the phase switch
-            e.bucket_wait(i, self.comm)
+        for i, off, n in active_buckets(self.buckets, phase2):
+            e.bucket_wait(i, self.comm)          # the side stream waits for the engine's "bucket i is final" event
             with torch.cuda.stream(self.comm):
-                dist.all_reduce(e.flat_grad[off:off + n], op=dist.ReduceOp.AVG)
+                allreduce_bucket(dist, e.flat_grad, off, n)
         main.wait_stream(self.comm)
 
     def run(self, images, context, posterior, target, eps, phase2, seed, kl_weight, lr, max_norm=5.0):

@@ -11,13 +11,57 @@
 
 namespace {
 
+// head slice [Tn, d] of a packed projection -> fp32 LDS rows of d+1 floats; 16-byte global loads when the layout allows
 template <typename T>
-__device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int b, int Tn, int h, int d, float* dst,
-                                          int lane) {
+__device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int b, int Tn, int h, int d, float* dst, int lane) {
     const int dp = d + 1;
+    if ((d & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)src) & 15) == 0) {
+        const int d8 = d >> 3;
+        for (int idx = lane; idx < Tn * d8; idx += 64) {
+            const int i = idx / d8, c = (idx - i * d8) * 8;
+            float v[8];
+            Vec8<T>::load(src + (size_t)(b * Tn + i) * ld + h * d + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dst[i * dp + c + e] = v[e];
+        }
+        return;
+    }
     for (int idx = lane; idx < Tn * d; idx += 64) {
         const int i = idx / d, c = idx - i * d;
         dst[i * dp + c] = to_f32(src[(size_t)(b * Tn + i) * ld + h * d + c]);
+    }
+}
+
+// out[i, c] = sum_j W[i or j][...] * X[j][c] written as 8 consecutive columns per lane (16-byte stores when possible).
+// TRANS = false: out[i,c] = sum_j Wt[i*tp + j] * X[j*dp + c]   (rows of W);  TRANS = true: out[j,c] = sum_i Wt[i*tp + j] * X[i*dp + c]
+template <typename T, bool TRANS>
+__device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, int nJ, const float* X, int dp, int d, float scale,
+                                             T* __restrict__ out, int ld, int b, int h, int lane) {
+    const int nOut = TRANS ? nJ : nI, nRed = TRANS ? nI : nJ;
+    const bool vec = (d & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)out) & 15) == 0;
+    if (vec) {
+        const int d8 = d >> 3;
+        for (int idx = lane; idx < nOut * d8; idx += 64) {
+            const int o = idx / d8, c = (idx - o * d8) * 8;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+            for (int r = 0; r < nRed; ++r) {
+                const float w = TRANS ? Wt[r * tp + o] : Wt[o * tp + r];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += w * X[r * dp + c + e];
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] *= scale;
+            Vec8<T>::store(out + (size_t)(b * nOut + o) * ld + h * d + c, acc);
+        }
+        return;
+    }
+    for (int idx = lane; idx < nOut * d; idx += 64) {
+        const int o = idx / d, c = idx - o * d;
+        float acc = 0.f;
+        for (int r = 0; r < nRed; ++r) acc += (TRANS ? Wt[r * tp + o] : Wt[o * tp + r]) * X[r * dp + c];
+        out[(size_t)(b * nOut + o) * ld + h * d + c] = from_f32<T>(acc * scale);
     }
 }
 
@@ -74,13 +118,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
         }
         __syncthreads();
     }
-    T* O = (T*)a.O;
-    for (int idx = lane; idx < a.Tq * a.d; idx += 64) {
-        const int i = idx / a.d, c = idx - i * a.d;
-        float acc = 0.f;
-        for (int j = 0; j < a.Tk; ++j) acc += Pn[i * tp + j] * Vs[j * dp + c];
-        O[(size_t)(b * a.Tq + i) * a.ldo + h * a.d + c] = from_f32<T>(acc);
-    }
+    matmul_store<T, false>(Pn, tp, a.Tq, a.Tk, Vs, dp, a.d, 1.f, (T*)a.O, a.ldo, b, h, lane);
 }
 
 template <typename T>
@@ -125,25 +163,9 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnArgs a) {
         }
     }
     __syncthreads();
-    T* dQ = (T*)a.dQ;
-    T* dK = (T*)a.dK;
-    T* dV = (T*)a.dV;
-    for (int idx = lane; idx < a.Tq * a.d; idx += 64) {
-        const int i = idx / a.d, c = idx - i * a.d;
-        float acc = 0.f;
-        for (int j = 0; j < a.Tk; ++j) acc += dS[i * tp + j] * Ks[j * dp + c];
-        dQ[(size_t)(b * a.Tq + i) * a.lddq + h * a.d + c] = from_f32<T>(acc);
-    }
-    for (int idx = lane; idx < a.Tk * a.d; idx += 64) {
-        const int j = idx / a.d, c = idx - j * a.d;
-        float ak = 0.f, av = 0.f;
-        for (int i = 0; i < a.Tq; ++i) {
-            ak += dS[i * tp + j] * Qs[i * dp + c];
-            av += Pd[i * tp + j] * dOs[i * dp + c];
-        }
-        dK[(size_t)(b * a.Tk + j) * a.lddk + h * a.d + c] = from_f32<T>(ak);
-        dV[(size_t)(b * a.Tk + j) * a.lddv + h * a.d + c] = from_f32<T>(av);
-    }
+    matmul_store<T, false>(dS, tp, a.Tq, a.Tk, Ks, dp, a.d, 1.f, (T*)a.dQ, a.lddq, b, h, lane);      // dQ = dS K
+    matmul_store<T, true>(dS, tp, a.Tq, a.Tk, Qs, dp, a.d, 1.f, (T*)a.dK, a.lddk, b, h, lane);       // dK = dS^T Q
+    matmul_store<T, true>(Pd, tp, a.Tq, a.Tk, dOs, dp, a.d, 1.f, (T*)a.dV, a.lddv, b, h, lane);      // dV = Pd^T dO
 }
 
 int check(const AttnArgs& a, bool bwd) {

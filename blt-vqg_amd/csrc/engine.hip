@@ -44,6 +44,7 @@ struct Stack {
     std::string prefix;   // e.g. "answer_encoder.encoder"
     bool dec = false;
     int id = 0;           // dropout stream namespace
+    int scr = 0;          // gradient scratch set used by this stack's backward
     int S = 0, M = 0;
     const int* key_ids = nullptr;
     void* x_in = nullptr;
@@ -94,9 +95,19 @@ struct bltvqg_engine {
     void *r_in, *hrec, *recon;
     float* eps_dev;
     // gradient scratch
-    void *gA, *gB, *gC, *gF, *gQKV, *gKV, *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
+    void *sA[2], *sB[2], *sC[2], *sF[2], *sQKV[2];   // gradient scratch sets: [0] main stream, [1] posterior-encoder stream
+    void *gKV, *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
     void *g_b1, *g_b2, *g_b3, *g_b4, *g_cat, *g_mq;   // small [B, *] scratch
     hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+    // side streams: independent sub-graphs (CNN | posterior encoder | context encoder) run concurrently so that their small
+    // launches (40-160 workgroups each) fill the 256 CUs together; fork/join with events (capturable into a hipGraph)
+    hipStream_t side[2] = {nullptr, nullptr};
+    hipEvent_t fj[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool use_streams = true;
+    int fork(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+        if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) { blt_set_error("engine: stream fork/join failed"); return BLT_ERR_HIP; }
+        return BLT_OK;
+    }
     // optional in-stream timing of the dominant kernel (implicit-GEMM conv): one event pair per launch
     bool prof_on = false;
     std::vector<hipEvent_t> prof_a, prof_b;
@@ -311,7 +322,7 @@ struct bltvqg_engine {
         r_in = AT((int64_t)B * H); hrec = AT((int64_t)B * F); recon = AT((int64_t)B * H);
         // gradient scratch
         const int64_t Mmax = (Mp > Mt ? Mp : Mt);
-        gA = AT(Mmax * H); gB = AT(Mmax * H); gC = AT(Mmax * H); gF = AT(Mmax * F); gQKV = AT(Mmax * 3 * H);
+        for (int k = 0; k < 2; ++k) { sA[k] = AT(Mmax * H); sB[k] = AT(Mmax * H); sC[k] = AT(Mmax * H); sF[k] = AT(Mmax * F); sQKV[k] = AT(Mmax * 3 * H); }
         gKV = AT((int64_t)Ma * 2 * H);
         d_enc = AT((int64_t)Ma * H); d_renc = AT((int64_t)Mp * H);
         dX_all = AT((int64_t)Mtot * H); dE = AT((int64_t)Mtot * Epad);
@@ -335,7 +346,7 @@ struct bltvqg_engine {
         }
         build_params();
         enc.prefix = "answer_encoder.encoder"; enc.id = 0; enc.S = Sa; enc.M = Ma;
-        renc.prefix = "answer_encoder.r_encoder"; renc.id = 1; renc.S = Sp; renc.M = Mp;
+        renc.prefix = "answer_encoder.r_encoder"; renc.id = 1; renc.scr = 1; renc.S = Sp; renc.M = Mp;
         dec.prefix = "decoder.decoder"; dec.id = 2; dec.S = T; dec.M = Mt; dec.dec = true;
         ws_bytes = layout(nullptr);
     }
@@ -591,23 +602,29 @@ struct bltvqg_engine {
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
                            tgt32, ctx32, post32, counters, s));
-        RC(cnn_fwd(images, s));
+        // three independent sub-graphs until the image feature is injected: CNN (main) | embedding + posterior encoder (side 0) |
+        // context encoder (side 1)
+        hipStream_t s0 = use_streams ? side[0] : s, s1 = use_streams ? side[1] : s;
+        if (use_streams) RC(fork(s, s0, fj[0]));
         // shared embedding over the three token streams at once (iq.py:72-78): gather -> Linear(E,H) + bias + timing signal
-        RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Mtot, E, Epad, s));
+        RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Mtot, E, Epad, s0));
         {
             int ldw;
             const void* w = W("embedding.1.weight", &ldw);
             GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Mtot, H, E);
             g.bias = P("embedding.1.bias");
             g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
-            RC(blt_gemm(dt, g, s));
+            RC(blt_gemm(dt, g, s0));
         }
         enc.x_in = X_all; enc.key_ids = ctx32;
         dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = tgt_shift;
         renc.x_in = (char*)X_all + (size_t)(Ma + Mt) * H * es; renc.key_ids = post32;
+        if (use_streams) RC(fork(s0, s1, fj[1]));
+        RC(stack_fwd(enc, nullptr, nullptr, s1));
         // the reference runs r_encoder in both phases (encoder_transformer.py:23-25)
-        RC(stack_fwd(renc, nullptr, nullptr, s));
-        RC(stack_fwd(enc, nullptr, nullptr, s));
+        RC(stack_fwd(renc, nullptr, nullptr, s0));
+        RC(cnn_fwd(images, s));
+        if (use_streams) { RC(fork(s0, s, fj[2])); RC(fork(s1, s, fj[3])); }
         RC(blt_rows_add(dt, enc.out, (long)Sa * H, feats, H, nullptr, 0, B, H, 1, s));   // encoder_outputs[:,0] += image_features
         if (phase2) {
             if (hipMemcpyAsync(eps_dev, eps, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -647,7 +664,8 @@ struct bltvqg_engine {
     // backward pieces.  `dx` holds the gradient w.r.t. the layer OUTPUT on entry and w.r.t. its INPUT on exit.
     // ---------------------------------------------------------------------------------------------
     int ffn_bwd(const std::string& fp_, const void* xn, const void* xres, const float* m, const float* r, const std::string& ln,
-                Layer& y, void* dx, int M, hipStream_t s) {
+                Layer& y, void* dx, int M, int k, hipStream_t s) {
+        void *gA = sA[k], *gB = sB[k], *gF = sF[k];
         const float ks = (c.relu_dropout > 0.f) ? 1.f / (1.f - c.relu_dropout) : 1.f;
         RC(blt_mask_scale(dt, dx, y.y2, gA, (long)M * H, ks, s));
         RC(wgrad(gA, H, y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), M, s));
@@ -661,6 +679,7 @@ struct bltvqg_engine {
 
     int stack_bwd(Stack& st, void* dx, const void* enc_out, const int* src_ids, hipStream_t s) {
         const int M = st.M, S = st.S;
+        void *gA = sA[st.scr], *gB = sB[st.scr], *gC = sC[st.scr], *gQKV = sQKV[st.scr];
         for (int l = L - 1; l >= 0; --l) {
             Layer& y = st.layers[l];
             const void* x = (l == 0) ? st.x_in : st.layers[l - 1].x2;
@@ -668,7 +687,7 @@ struct bltvqg_engine {
             const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
             const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
             if (st.dec) {
-                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, dx, M, s));
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, dx, M, st.scr, s));
                 // encoder-decoder attention
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
                 RC(wgrad(dx, H, y.ctx2, H, a2 + "output_linear.weight", nullptr, M, s));
@@ -691,7 +710,7 @@ struct bltvqg_engine {
                 const std::string ln2 = lp + "layer_norm_mha_enc";
                 RC(blt_layernorm_bwd(dt, gC, y.x1, P(ln2 + ".weight"), y.m2, y.r2, dx, dx, G(ln2 + ".weight"), G(ln2 + ".bias"), M, H, s));
             } else {
-                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, dx, M, s));
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, dx, M, st.scr, s));
             }
             // self attention
             RC(wgrad(dx, H, y.ctx, H, a1 + "output_linear.weight", nullptr, M, s));
@@ -717,6 +736,7 @@ struct bltvqg_engine {
     int backward_core(float kld_g, hipStream_t s) {
         // ---- vocabulary projection + decoder ----
         RC(wgrad(logits, ldV, dec.out, H, "decoder.output.weight", "decoder.output.bias", Mt, s));
+        void* gA = sA[0];
         RC(blt_gemm(dt, dgrad(logits, ldV, "decoder.output.weight", gA, H, Mt), s));
         void* dxT = (char*)dX_all + (size_t)Ma * H * es;
         {
@@ -759,25 +779,28 @@ struct bltvqg_engine {
         }
         // encoder_outputs[:,0] += image_features
         RC(blt_rows_add(dt, d_feats, H, d_enc, (long)Sa * H, nullptr, 0, B, H, 1, s));
-        // ---- context encoder ----
+        int Memb = Ma + Mt;
+        hipStream_t s0 = (use_streams && phase2) ? side[0] : s;
+        if (phase2) {
+            // ---- posterior encoder (side stream, own scratch set): only row 0 of its output carries gradient ----
+            if (s0 != s) RC(fork(s, s0, fj[4]));
+            if (hipMemsetAsync(d_renc, 0, (size_t)Mp * H * es, s0) != hipSuccess) { blt_set_error("backward: memset failed"); return BLT_ERR_HIP; }
+            RC(blt_rows_add(dt, d_renc, (long)Sp * H, g_cat, 2 * H, nullptr, 0, B, H, 0, s0));
+            void* dxP = (char*)dX_all + (size_t)(Ma + Mt) * H * es;
+            const void* xL = renc.layers[L - 1].x2;
+            RC(blt_layernorm_bwd(dt, d_renc, xL, P("answer_encoder.r_encoder.layer_norm.weight"), renc.mF, renc.rF, nullptr, dxP,
+                                 G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s0));
+            RC(stack_bwd(renc, dxP, nullptr, nullptr, s0));
+            Memb = Mtot;
+        }
+        // ---- context encoder (main stream) ----
         {
             const void* xL = enc.layers[L - 1].x2;
             RC(blt_layernorm_bwd(dt, d_enc, xL, P("answer_encoder.encoder.layer_norm.weight"), enc.mF, enc.rF, nullptr, dX_all,
                                  G("answer_encoder.encoder.layer_norm.weight"), G("answer_encoder.encoder.layer_norm.bias"), Ma, H, s));
         }
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
-        int Memb = Ma + Mt;
-        if (phase2) {
-            // ---- posterior encoder: only row 0 of its output carries gradient (x_p = r_encoder_outputs[:,0]) ----
-            if (hipMemsetAsync(d_renc, 0, (size_t)Mp * H * es, s) != hipSuccess) { blt_set_error("backward: memset failed"); return BLT_ERR_HIP; }
-            RC(blt_rows_add(dt, d_renc, (long)Sp * H, g_cat, 2 * H, nullptr, 0, B, H, 0, s));
-            void* dxP = (char*)dX_all + (size_t)(Ma + Mt) * H * es;
-            const void* xL = renc.layers[L - 1].x2;
-            RC(blt_layernorm_bwd(dt, d_renc, xL, P("answer_encoder.r_encoder.layer_norm.weight"), renc.mF, renc.rF, nullptr, dxP,
-                                 G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s));
-            RC(stack_bwd(renc, dxP, nullptr, nullptr, s));
-            Memb = Mtot;
-        }
+        if (s0 != s) RC(fork(s0, s, fj[5]));
         // ---- shared embedding (rows of the streams that received gradient) ----
         {
             const PInfo& pw = tpi("embedding.1.weight");
@@ -882,6 +905,8 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
 void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (!e) return;
     for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
+    for (int i = 0; i < 6; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
+    for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
     for (size_t i = 0; i < e->prof_a.size(); ++i) { (void)hipEventDestroy(e->prof_a[i]); (void)hipEventDestroy(e->prof_b[i]); }
     delete e;
 }
@@ -935,6 +960,16 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
     for (int i = 0; i < 3; ++i)
         if (!e->bucket_ev[i] && hipEventCreateWithFlags(&e->bucket_ev[i], hipEventDisableTiming) != hipSuccess) {
             blt_set_error("engine_bind: event creation failed");
+            return BLT_ERR_HIP;
+        }
+    for (int i = 0; i < 6; ++i)
+        if (!e->fj[i] && hipEventCreateWithFlags(&e->fj[i], hipEventDisableTiming) != hipSuccess) {
+            blt_set_error("engine_bind: event creation failed");
+            return BLT_ERR_HIP;
+        }
+    for (int i = 0; i < 2; ++i)
+        if (!e->side[i] && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) {
+            blt_set_error("engine_bind: stream creation failed");
             return BLT_ERR_HIP;
         }
     e->bound = true; e->frozen_dirty = true; e->fwd_done = false;

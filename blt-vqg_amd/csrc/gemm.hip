@@ -208,15 +208,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* Cs
     constexpr int GPR = BN / 8;
     if (gridDim.y > 1) {
         // split-K partial: fp32 atomic accumulation into a zero-initialised (or accumulating) C; no other epilogue terms
+        // consecutive lanes add consecutive floats: every atomic wave-instruction covers one contiguous 256-byte segment
         float* Cg = (float*)p.C;
-        for (int g = tid; g < BM * GPR; g += 256) {
-            const int row = g / GPR, cgp = g % GPR;
-            const int m = m0 + row, n = n0 + cgp * 8;
-            if (m >= p.M || n >= p.N) continue;
-            const int nv = (p.N - n < 8) ? (p.N - n) : 8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (e < nv) atomicAdd(Cg + (size_t)m * p.ldc + n + e, Cs[row * CS + cgp * 8 + e] * p.alpha);
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int row = idx / BN, col = idx % BN;
+            const int m = m0 + row, n = n0 + col;
+            if (m < p.M && n < p.N) atomicAdd(Cg + (size_t)m * p.ldc + n, Cs[row * CS + col] * p.alpha);
         }
         return;
     }

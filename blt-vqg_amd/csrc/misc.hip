@@ -45,23 +45,17 @@ __global__ void prep_tokens_kernel(const long long* __restrict__ ctx, const long
         }
     }
     if (blockIdx.x == 0) {
-        // per-sample non-pad counts (T <= 64 keeps this trivial)
+        // per-sample and total non-pad target counts (exact small integers in fp32; block reduction, deterministic)
+        __shared__ float red[16];
+        float mine = 0.f;
         for (int b = threadIdx.x; b < B; b += blockDim.x) {
             int c = 0;
             for (int t = 0; t < T; ++t) c += (tgt[b * T + t] != 0);
             counters[1 + b] = (float)c;
+            mine += (float)c;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            // serial, deterministic; B <= a few thousand
-            float c = 0.f;
-            for (int b = 0; b < B; ++b) {
-                int cb = 0;
-                for (int t = 0; t < T; ++t) cb += (tgt[b * T + t] != 0);
-                c += (float)cb;
-            }
-            counters[0] = c;
-        }
+        const float total_cnt = block_sum(mine, red);
+        if (threadIdx.x == 0) counters[0] = total_cnt;
     }
 }
 
@@ -412,8 +406,8 @@ int blt_colsum(int dtype, const void* x, int ld, long M, int N, float* out, int 
     if (!accumulate) {
         if (hipMemsetAsync(out, 0, sizeof(float) * (size_t)N, s) != hipSuccess) { blt_set_error("colsum: memset failed"); return BLT_ERR_HIP; }
     }
-    int gy = (int)((M + 255) / 256);
-    if (gy > 64) gy = 64;
+    int gy = (int)((M + 31) / 32);      // ~8 rows per thread: the loop is latency-bound, not bandwidth-bound
+    if (gy > 256) gy = 256;
     if (gy < 1) gy = 1;
     if (dtype == BLT_F32) hipLaunchKernelGGL(colsum_kernel<float>, dim3(cdiv(N, 64), gy), dim3(256), 0, s, (const float*)x, ld, M, N, out);
     else hipLaunchKernelGGL(colsum_kernel<bf16>, dim3(cdiv(N, 64), gy), dim3(256), 0, s, (const bf16*)x, ld, M, N, out);

@@ -160,14 +160,19 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     }
 }
 
-__global__ void bn_finish_kernel(const double* __restrict__ tmp, int S, int C, double count, const float* __restrict__ gamma,
-                                 const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
-                                 float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
-                                 float* __restrict__ save_mean, float* __restrict__ save_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict__ tmp, int S, int C, double count, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, float momentum, float* __restrict__ rmean,
+                                                        float* __restrict__ rvar, float* __restrict__ scale, float* __restrict__ shift,
+                                                        float* __restrict__ save_mean, float* __restrict__ save_var) {
+    // block = 8 channels x 32 slice-lanes: the S (= 32) partial sums of a channel are loaded in parallel and shuffled together
+    const int sl = threadIdx.x & 31;
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5);
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) { a += tmp[((size_t)s * 2) * C + c]; b += tmp[((size_t)s * 2 + 1) * C + c]; }
+    if (c < C)
+        for (int s = sl; s < S; s += 32) { a += tmp[((size_t)s * 2) * C + c]; b += tmp[((size_t)s * 2 + 1) * C + c]; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { a += __shfl_xor(a, o, 32); b += __shfl_xor(b, o, 32); }
+    if (c >= C || sl != 0) return;
     const double mu = a / count;
     double var = b / count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -265,48 +270,66 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T
     }
 }
 
-// BatchNorm1d over the batch dimension: one thread per column (coalesced across columns).
+// BatchNorm1d over the batch dimension: block = 64 columns x 4 row-lanes (coalesced across columns), LDS reduction.
 template <typename T>
-__global__ void bn1d_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
-                                float* __restrict__ rvar, int B, int C, float eps, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void bn1d_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
+                                                       float* __restrict__ rmean, float* __restrict__ rvar, int B, int C, float eps, float momentum) {
+    __shared__ float sh[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const bool ok = c < C;
     float s = 0.f;
-    for (int b = 0; b < B; ++b) s += to_f32(x[(long)b * C + c]);
-    const float mu = s / (float)B;
+    if (ok) for (int b = ry; b < B; b += 4) s += to_f32(x[(long)b * C + c]);
+    sh[ry][cx] = s;
+    __syncthreads();
+    const float mu = (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) / (float)B;
+    __syncthreads();
     float q = 0.f;
-    for (int b = 0; b < B; ++b) { const float d = to_f32(x[(long)b * C + c]) - mu; q += d * d; }
-    const float var = q / (float)B;
+    if (ok) for (int b = ry; b < B; b += 4) { const float d = to_f32(x[(long)b * C + c]) - mu; q += d * d; }
+    sh[ry][cx] = q;
+    __syncthreads();
+    const float var = (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) / (float)B;
     const float rs = rsqrtf(var + eps);
-    mean[c] = mu;
-    rstd[c] = rs;
+    if (!ok) return;
     const float g = gamma[c], be = beta[c];
-    for (int b = 0; b < B; ++b) y[(long)b * C + c] = from_f32<T>((to_f32(x[(long)b * C + c]) - mu) * rs * g + be);
-    if (rmean) {
-        const float unb = B > 1 ? var * (float)B / (float)(B - 1) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    for (int b = ry; b < B; b += 4) y[(long)b * C + c] = from_f32<T>((to_f32(x[(long)b * C + c]) - mu) * rs * g + be);
+    if (ry == 0) {
+        mean[c] = mu;
+        rstd[c] = rs;
+        if (rmean) {
+            const float unb = B > 1 ? var * (float)B / (float)(B - 1) : var;
+            rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+            rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        }
     }
 }
 
 template <typename T>
-__global__ void bn1d_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
-                                const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float mu = mean[c], rs = rstd[c], g = gamma[c];
+__global__ __launch_bounds__(256) void bn1d_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
+                                                       float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
+    __shared__ float sh[2][4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const bool ok = c < C;
+    const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f, g = ok ? gamma[c] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float d = to_f32(dy[(long)b * C + c]);
-        s1 += d;
-        s2 += d * (to_f32(x[(long)b * C + c]) - mu) * rs;
-    }
-    dgamma[c] = s2;
-    dbeta[c] = s1;
+    if (ok)
+        for (int b = ry; b < B; b += 4) {
+            const float d = to_f32(dy[(long)b * C + c]);
+            s1 += d;
+            s2 += d * (to_f32(x[(long)b * C + c]) - mu) * rs;
+        }
+    sh[0][ry][cx] = s1;
+    sh[1][ry][cx] = s2;
+    __syncthreads();
+    s1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
+    s2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+    if (!ok) return;
+    if (ry == 0) { dgamma[c] = s2; dbeta[c] = s1; }
     const float inv = 1.f / (float)B;
-    for (int b = 0; b < B; ++b) {
+    for (int b = ry; b < B; b += 4) {
         const float d = to_f32(dy[(long)b * C + c]);
         const float xh = (to_f32(x[(long)b * C + c]) - mu) * rs;
         dx[(long)b * C + c] = from_f32<T>(g * rs * (d - s1 * inv - xh * s2 * inv));
@@ -345,8 +368,9 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_bwd: bad dtype");
     BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_bwd: bad cols=%d", cols);
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
-    int grid = cdiv(rows, 4);
-    if (grid > 512) grid = 512;
+    int grid = cdiv(rows, 16);     // ~4 rows per wave: fewer per-block reductions / float atomics for dgamma, dbeta
+    if (grid > 256) grid = 256;
+    if (grid < 1) grid = 1;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols),
                hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols));
@@ -363,7 +387,7 @@ int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long
     BLT_REQUIRE(nparts > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
     BLT_REQUIRE(((uintptr_t)scratch % 8) == 0, "bn_finalize: scratch must be 8-byte aligned");
     hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 64), BN_SLICES), dim3(256), 0, s, psum, psq, nparts, C, scratch);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, (const double*)scratch, BN_SLICES, C, (double)count, gamma, beta, eps,
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, (const double*)scratch, BN_SLICES, C, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, scale, shift, save_mean, save_var);
     return blt_check_launch("bn_finalize");
 }
@@ -402,8 +426,8 @@ int blt_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta
                  float* running_mean, float* running_var, int B, int C, float eps, float momentum, hipStream_t s) {
     BLT_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0, "bn1d_fwd: bad args");
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn1d_fwd_kernel<float>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum),
-               hipLaunchKernelGGL(bn1d_fwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum));
+               hipLaunchKernelGGL(bn1d_fwd_kernel<float>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum),
+               hipLaunchKernelGGL(bn1d_fwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum));
     return blt_check_launch("bn1d_fwd");
 }
 
@@ -411,7 +435,7 @@ int blt_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma, c
                  void* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t s) {
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && B > 0 && C > 0, "bn1d_bwd: bad args");
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn1d_bwd_kernel<float>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, B, C),
-               hipLaunchKernelGGL(bn1d_bwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(64), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, B, C));
+               hipLaunchKernelGGL(bn1d_bwd_kernel<float>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, B, C),
+               hipLaunchKernelGGL(bn1d_bwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, B, C));
     return blt_check_launch("bn1d_bwd");
 }

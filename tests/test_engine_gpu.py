@@ -203,14 +203,15 @@ def test_engine_train_steps_match_oracle_adam():
         it = start + i
         phase2 = it >= hp.num_pretraining_steps
         kl_w = O.kl_weight(kliter, hp.full_kl_step)
-        _run(e, b, phase2, kl_w)
+        r = _run(e, b, phase2, kl_w)
         if phase2:
             kliter += 1
         lr = O.noam_lr(it, cfg.hidden_dim)
         lr_sum += lr
         e.optimizer_step(lr, 5.0)
         st = e.stats()
-        assert abs(st["rec"] - logs[i]["rec"]) < 1e-3, (i, st, logs[i])
+        assert abs(st["rec"] - logs[i]["rec"]) < 1e-3, "step %d rec %.6f vs %.6f (first read %.6f) %s" % (
+            i, st["rec"], logs[i]["rec"], r["stats"]["rec"], str(st))
         assert abs(st["grad_norm"] - logs[i]["grad_norm"]) < 2e-3 * logs[i]["grad_norm"], (i, st["grad_norm"], logs[i]["grad_norm"])
     # Adam normalises every gradient element to O(1), so an element whose true gradient is below fp32 rounding noise can
     # move by +-lr per step in either implementation: compare the UPDATE in aggregate, and bound every element by sum(lr).

@@ -191,9 +191,11 @@ __global__ __launch_bounds__(256) void ce_kernel(T* __restrict__ logits, int ld,
     for (int v = threadIdx.x; v < V; v += blockDim.x) s += __expf(to_f32(x[v]) - m);
     s = block_sum(s, red);
     const float lse = m + __logf(s);
-    const float xt = to_f32(x[tgt]);
+    // The target logit must be consumed BEFORE the barrier: the gradient pass below overwrites the row in place, and a plain
+    // load that only thread 0 needs may legally be sunk past __syncthreads() into the `if`, where it races with the thread that
+    // writes x[tgt] (seen as an occasional wrong loss for tgt = 1, same wave as thread 0; gradients were never affected).
+    if (threadIdx.x == 0) atomicAdd(loss_out, (lse - to_f32(x[tgt])) * inv_count);
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_out, (lse - xt) * inv_count);
     if (write_grad) {
         const float g = gscale * inv_count;
         for (int v = threadIdx.x; v < ld; v += blockDim.x) {

@@ -118,19 +118,23 @@ __host__ __device__ __forceinline__ void philox4x32(uint32_t k0, uint32_t k1, ui
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// 4 random words for elements [4*q, 4*q+3] of dropout site `stream`
+// Dropout addressing: one Philox call serves the 8 elements [8*q, 8*q+7] of dropout site `stream`; element e uses the 16-bit
+// lane (e & 7) of the 128 random bits and is kept when that lane >= round(p * 65536).
 __host__ __device__ __forceinline__ void dropout_words(uint64_t seed, uint32_t stream, uint64_t q, uint32_t* out) {
     philox4x32((uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)q, (uint32_t)(q >> 32), stream, 0x6b657970u, out);
 }
 __host__ __device__ __forceinline__ uint32_t dropout_threshold(float p) {
-    double t = (double)p * 4294967296.0;
+    double t = (double)p * 65536.0 + 0.5;
     if (t < 0) t = 0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    if (t > 65535.0) t = 65535.0;
     return (uint32_t)t;
+}
+__host__ __device__ __forceinline__ uint32_t dropout_lane(const uint32_t* w, int lane8) {
+    return (w[lane8 >> 1] >> ((lane8 & 1) * 16)) & 0xFFFFu;
 }
 // keep decision for a single element index e
 __host__ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t stream, uint64_t e, uint32_t thresh) {
     uint32_t w[4];
-    dropout_words(seed, stream, e >> 2, w);
-    return w[e & 3] >= thresh;
+    dropout_words(seed, stream, e >> 3, w);
+    return dropout_lane(w, (int)(e & 7)) >= thresh;
 }

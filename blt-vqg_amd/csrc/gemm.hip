@@ -183,10 +183,33 @@ __device__ __forceinline__ void compute_tile(const char* a_buf, const char* b_bu
     }
 }
 
+// 8 consecutive elements of type T kept packed (2 x 16 B for fp32, 1 x 16 B for bf16) so that many rows can be in flight
+template <typename T> struct Raw8;
+template <> struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) { a = *reinterpret_cast<const float4*>(p); b = *reinterpret_cast<const float4*>(p + 4); }
+    __device__ __forceinline__ void get(float* v) const { v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w; }
+};
+template <> struct Raw8<bf16> {
+    bf16x8 a;
+    __device__ __forceinline__ void load(const bf16* p) { a = *reinterpret_cast<const bf16x8*>(p); }
+    __device__ __forceinline__ void get(float* v) const {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+};
+
 // Epilogue shared by the GEMM kernels: Cs is the block's fp32 result tile in LDS (row stride BN + 4 floats).
+// A thread owns ONE group of 8 columns (so bias is loaded once) and BM*BN/2048 rows of it; the global loads of up to four rows
+// (residual, ReLU/dropout mask, position-table row, old C) are issued together before any arithmetic, otherwise the epilogue is a
+// chain of dependent L2 round trips.
 template <typename T, int BM, int BN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* Cs, int tile_m, int m0, int n0, int tid) {
     constexpr int ES = sizeof(T), CE = 16 / ES, CS = BN + 4;
+    constexpr int GPR = BN / 8;                // column groups per tile row
+    constexpr int RPT = BM * GPR / 256;        // rows per thread
+    constexpr int RSTEP = 256 / GPR;           // distance between a thread's rows
+
     // ---- per-column statistics of the raw result (BatchNorm2d batch statistics, encoder_cnn.py:33) --------
     if (p.stat_sum != nullptr) {
         for (int c = tid; c < BN * 2; c += 256) {
@@ -203,11 +226,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* Cs
             }
         }
     }
-
-    // ---- epilogue: 8 consecutive columns per thread --------------------------------------------------
-    constexpr int GPR = BN / 8;
     if (gridDim.y > 1) {
-        // split-K partial: fp32 atomic accumulation into a zero-initialised (or accumulating) C; no other epilogue terms
+        // split-K partial: fp32 atomic accumulation into a zero-initialised (or accumulating) C; no other epilogue terms.
         // consecutive lanes add consecutive floats: every atomic wave-instruction covers one contiguous 256-byte segment
         float* Cg = (float*)p.C;
         for (int idx = tid; idx < BM * BN; idx += 256) {
@@ -217,28 +237,114 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* Cs
         }
         return;
     }
+
+    const int cgp = tid % GPR, row0 = tid / GPR;
+    const int n = n0 + cgp * 8;
+    if (n >= p.N) return;
+    const int nv = (p.N - n < 8) ? (p.N - n) : 8;
+    const bool out32 = p.out_f32 || ES == 4;
     const uint32_t thresh = dropout_threshold(p.drop_p);
     const float keep_scale = (p.drop_p > 0.f) ? 1.f / (1.f - p.drop_p) : 1.f;
     const int drop_ld = (p.N + 7) & ~7;
-    for (int g = tid; g < BM * GPR; g += 256) {
-        const int row = g / GPR, cgp = g % GPR;
-        const int m = m0 + row, n = n0 + cgp * 8;
-        if (m >= p.M || n >= p.N) continue;
-        const int nv = (p.N - n < 8) ? (p.N - n) : 8;
+    const bool fast = (nv == 8) && (out32 ? (p.ldc % 4) == 0 : (p.ldc % CE) == 0) && (!p.R || (p.ldr % CE) == 0) &&
+                      (!p.maskY || (p.ldm % CE) == 0) && (!p.C2 || (p.ldc2 % CE) == 0) && (!p.rowtab || (p.ldt % 4) == 0) &&
+                      (!p.bias || (((uintptr_t)(p.bias + n)) & 15) == 0);
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (p.bias != nullptr) {
+        if (fast) Vec8<float>::load(p.bias + n, bias);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nv) bias[e] = p.bias[n + e];
+        }
+    }
+
+    if (fast) {
+        constexpr int NB = (RPT < 4) ? RPT : 4;
+#pragma unroll
+        for (int i0 = 0; i0 < RPT; i0 += NB) {
+            Raw8<T> rR[NB], rM[NB], rC[NB];
+            Raw8<float> rC32[NB], rT[NB];
+            bool ok[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int m = m0 + row0 + (i0 + i) * RSTEP;
+                ok[i] = m < p.M;
+                if (!ok[i]) continue;
+                if (p.R) rR[i].load((const T*)p.R + (size_t)m * p.ldr + n);
+                if (p.maskY) rM[i].load((const T*)p.maskY + (size_t)m * p.ldm + n);
+                if (p.rowtab) rT[i].load(p.rowtab + (size_t)p.rowidx[m] * p.ldt + n);
+                if (p.accumulate) {
+                    if (out32) rC32[i].load((const float*)p.C + (size_t)m * p.ldc + n);
+                    else rC[i].load((const T*)p.C + (size_t)m * p.ldc + n);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                if (!ok[i]) continue;
+                const int row = row0 + (i0 + i) * RSTEP, m = m0 + row;
+                float v[8], t[8];
+                {
+                    const float4 x0 = *reinterpret_cast<const float4*>(&Cs[row * CS + cgp * 8]);
+                    const float4 x1 = *reinterpret_cast<const float4*>(&Cs[row * CS + cgp * 8 + 4]);
+                    v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+                if (p.rowtab) {
+                    rT[i].get(t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += t[e];
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.drop_p > 0.f) {
+                    uint32_t w[4];
+                    dropout_words(p.seed, p.stream_id, ((uint64_t)m * (uint64_t)drop_ld + (uint64_t)n) >> 3, w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (dropout_lane(w, e) >= thresh) ? v[e] * keep_scale : 0.f;
+                }
+                if (p.maskY) {
+                    rM[i].get(t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (t[e] != 0.f) ? v[e] * p.mask_scale : 0.f;
+                }
+                if (p.C2) Vec8<T>::store((T*)p.C2 + (size_t)m * p.ldc2 + n, v);
+                if (p.R) {
+                    rR[i].get(t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += t[e];
+                }
+                if (out32) {
+                    if (p.accumulate) {
+                        rC32[i].get(t);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += t[e];
+                    }
+                    Vec8<float>::store((float*)p.C + (size_t)m * p.ldc + n, v);
+                } else {
+                    if (p.accumulate) {
+                        rC[i].get(t);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += t[e];
+                    }
+                    Vec8<T>::store((T*)p.C + (size_t)m * p.ldc + n, v);
+                }
+            }
+        }
+        return;
+    }
+
+    // ---- general path: ragged last column group / unaligned leading dimensions (element-wise accesses) ----
+    for (int i = 0; i < RPT; ++i) {
+        const int row = row0 + i * RSTEP, m = m0 + row;
+        if (m >= p.M) continue;
         float v[8];
-        {
-            const float4 x0 = *reinterpret_cast<const float4*>(&Cs[row * CS + cgp * 8]);
-            const float4 x1 = *reinterpret_cast<const float4*>(&Cs[row * CS + cgp * 8 + 4]);
-            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-        }
-        if (p.alpha != 1.f) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] *= p.alpha;
-        }
-        if (p.bias != nullptr) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (e < nv) v[e] += p.bias[n + e];
-        }
+        for (int e = 0; e < 8; ++e) v[e] = Cs[row * CS + cgp * 8 + e] * p.alpha + bias[e];
         if (p.rowtab != nullptr) {
             const float* tr = p.rowtab + (size_t)p.rowidx[m] * p.ldt + n;
 #pragma unroll
@@ -249,77 +355,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const float* Cs
             for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
         }
         if (p.drop_p > 0.f) {
-            const uint64_t e0 = (uint64_t)m * (uint64_t)drop_ld + (uint64_t)n;
-            uint32_t w0[4], w1[4];
-            dropout_words(p.seed, p.stream_id, e0 >> 2, w0);
-            dropout_words(p.seed, p.stream_id, (e0 >> 2) + 1, w1);
+            uint32_t w[4];
+            dropout_words(p.seed, p.stream_id, ((uint64_t)m * (uint64_t)drop_ld + (uint64_t)n) >> 3, w);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = (w0[e] >= thresh) ? v[e] * keep_scale : 0.f;
-                v[e + 4] = (w1[e] >= thresh) ? v[e + 4] * keep_scale : 0.f;
-            }
+            for (int e = 0; e < 8; ++e) v[e] = (dropout_lane(w, e) >= thresh) ? v[e] * keep_scale : 0.f;
         }
-        const bool full = (nv == 8);
         if (p.maskY != nullptr) {
             const T* mp = (const T*)p.maskY + (size_t)m * p.ldm + n;
-            float mv[8];
-            if (full && (p.ldm % CE) == 0) Vec8<T>::load(mp, mv);
-            else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) mv[e] = (e < nv) ? to_f32(mp[e]) : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = (mv[e] != 0.f) ? v[e] * p.mask_scale : 0.f;
+            for (int e = 0; e < 8; ++e) if (e < nv) v[e] = (to_f32(mp[e]) != 0.f) ? v[e] * p.mask_scale : 0.f;
         }
         if (p.C2 != nullptr) {
             T* cp = (T*)p.C2 + (size_t)m * p.ldc2 + n;
-            if (full && (p.ldc2 % CE) == 0) Vec8<T>::store(cp, v);
-            else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = from_f32<T>(v[e]);
-            }
+            for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = from_f32<T>(v[e]);
         }
         if (p.R != nullptr) {
             const T* rp = (const T*)p.R + (size_t)m * p.ldr + n;
-            float rv[8];
-            if (full && (p.ldr % CE) == 0) Vec8<T>::load(rp, rv);
-            else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) rv[e] = (e < nv) ? to_f32(rp[e]) : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            for (int e = 0; e < 8; ++e) if (e < nv) v[e] += to_f32(rp[e]);
         }
-        if (p.out_f32 || ES == 4) {
+        if (out32) {
             float* cp = (float*)p.C + (size_t)m * p.ldc + n;
-            const bool vec = full && (p.ldc % 4) == 0;
-            if (p.accumulate) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nv) v[e] += cp[e];
-            }
-            if (vec) Vec8<float>::store(cp, v);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = v[e];
-            }
+            for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = p.accumulate ? cp[e] + v[e] : v[e];
         } else {
             T* cp = (T*)p.C + (size_t)m * p.ldc + n;
-            const bool vec = full && (p.ldc % CE) == 0;
-            if (p.accumulate) {
-                float ov[8];
-                if (vec) Vec8<T>::load(cp, ov);
-                else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) ov[e] = (e < nv) ? to_f32(cp[e]) : 0.f;
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += ov[e];
-            }
-            if (vec) Vec8<T>::store(cp, v);
-            else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = from_f32<T>(v[e]);
-            }
+            for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = from_f32<T>(p.accumulate ? to_f32(cp[e]) + v[e] : v[e]);
         }
     }
 }
@@ -653,6 +716,8 @@ void blt_gemm_tile2(const GemmArgs& a, int* bm, int* bn) {
     }
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
     if (t128 >= 192) { *bm = 128; *bn = 128; return; }
+    // weight-gradient form with split-K: the K-slices provide the parallelism, so keep the (more efficient) large tile
+    if (a.split_k > 0 && a.transA && a.transB && t128 >= 32) { *bm = 128; *bn = 128; return; }
     *bm = 64; *bn = 64;
 }
 
@@ -712,6 +777,8 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
     else BLT_REQUIRE(a.ldb >= a.N, "gemm: ldb=%d too small for N=%d (transB)", a.ldb, a.N);
     BLT_REQUIRE(a.ldc >= a.N, "gemm: ldc=%d < N=%d", a.ldc, a.N);
     BLT_REQUIRE(a.drop_p >= 0.f && a.drop_p < 1.f, "gemm: bad dropout p");
+    BLT_REQUIRE((!a.R || ((uintptr_t)a.R % 16) == 0) && (!a.maskY || ((uintptr_t)a.maskY % 16) == 0) && (!a.C2 || ((uintptr_t)a.C2 % 16) == 0) &&
+                (!a.rowtab || ((uintptr_t)a.rowtab % 16) == 0), "gemm: epilogue operands must be 16-byte aligned");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
     int bm, bn;
     blt_gemm_tile2(a, &bm, &bn);

@@ -346,7 +346,7 @@ __global__ void dropout_mask_kernel(uint64_t seed, uint32_t stream_id, long rows
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / cols;
         const int c = (int)(i - r * cols);
-        out[i] = dropout_keep(seed, stream_id, (uint64_t)r * (uint64_t)ld_index + (uint64_t)c, thresh) ? 1 : 0;
+        out[i] = dropout_keep(seed, stream_id, (uint64_t)r * (uint64_t)ld_index + (uint64_t)c, thresh) ? 1 : 0;   // ld_index % 8 == 0 for GEMM sites
     }
 }
 

@@ -162,6 +162,12 @@ def main():
         ms = dt / a.steps * 1e3
         value = B * world * a.steps / dt
         achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        # HBM bytes per conv launch from the committed PMC passes (profiles/summarize_pmc.py); they were collected for this
+        # default workload only, so any other configuration reports null
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
+        if a.config == "small" and B == 128 and a.dtype == "bf16" and os.path.exists(pmc):
+            traffic = int(json.load(open(pmc))["traffic_MB_per_launch"] * 1e6)
         out = {
             "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
@@ -172,7 +178,8 @@ def main():
                        "global_batch": B * world, "parallelism": "dp%d" % world, "loss_rec": round(stats["rec"], 4),
                        "model_tflops": round(value * FLOP_PER_PAIR[a.config] / 1e12, 2)},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                          "kernel": "gemm_kernel<bf16,*,*,conv> (implicit-GEMM conv of the ResNet-18 stack)",
                          "launches_per_step": conv_launches // max(a.steps, 1),
                          "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),

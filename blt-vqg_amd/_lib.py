@@ -76,6 +76,8 @@ SIGNATURES = {
     "bltvqg_engine_bind": (I, [P, P, P, P, P, P, P, L]),
     "bltvqg_engine_invalidate_frozen": (None, [P]),
     "bltvqg_engine_forward": (I, [P, P, P, P, P, P, I, U64, P]),
+    "bltvqg_engine_decode_greedy": (I, [P, P, P, P, I, I, P, P, P, P]),
+    "bltvqg_engine_set_bn_train": (I, [P, I]),
     "bltvqg_engine_loss_backward": (I, [P, F, P]),
     "bltvqg_engine_backward_external": (I, [P, P, P, F, P, P, P]),
     "bltvqg_engine_optimizer_step": (I, [P, F, F, F, F, F, P]),

@@ -74,8 +74,10 @@ __device__ __forceinline__ void scores_softmax(const AttnArgs& a, int b, const f
         const int i = idx / a.Tk, j = idx - i * a.Tk;
         float acc = 0.f;
         for (int c = 0; c < a.d; ++c) acc += Qs[i * dp + c] * Ks[j * dp + c];
-        const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal && j > i);
-        Pn[i * tp + j] = masked ? -1e18f : acc * a.scale;
+        const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal == 1 && j > i);
+        // causal == 2: a future key does not exist for this query (greedy decoding re-runs the decoder on the PREFIX, iq.py:134-141),
+        // so it is excluded from the softmax instead of being filled with -1e18 (matters only for fully pad-masked rows)
+        Pn[i * tp + j] = (a.causal == 2 && j > i) ? -INFINITY : (masked ? -1e18f : acc * a.scale);
     }
     __syncthreads();
     if (lane < a.Tq) {
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnArgs a) {
         for (int j = 0; j < a.Tk; ++j) {
             // masked_fill REPLACES the logit, so no gradient reaches a masked position — this matters for a fully
             // masked row, whose probabilities are uniform (non-zero) rather than 0
-            const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal && j > lane);
+            const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal != 0 && j > lane);
             dS[lane * tp + j] = masked ? 0.f : Pn[lane * tp + j] * (dS[lane * tp + j] - delta) * a.scale;
         }
     }

@@ -104,6 +104,8 @@ struct bltvqg_engine {
     hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fj[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     bool use_streams = true;
+    int causal_mode = 1;       // 1 = training mask (pad OR future -> -1e18), 2 = prefix decoding (future keys excluded)
+    bool bn_train = true;      // false: BatchNorm layers use their running statistics (module.eval(), greedy decoding)
     int fork(hipStream_t from, hipStream_t to, hipEvent_t ev) {
         if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) { blt_set_error("engine: stream fork/join failed"); return BLT_ERR_HIP; }
         return BLT_OK;
@@ -450,7 +452,7 @@ struct bltvqg_engine {
                 RC(blt_gemm(dt, g, s));
             }
             RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
-                        st.dec ? 1 : 0, sid(st.id, l, 0), s));
+                        st.dec ? causal_mode : 0, sid(st.id, l, 0), s));
             {
                 GemmArgs g = lin(y.ctx, H, a1 + "output_linear.weight", nullptr, y.x1, H, M);
                 g.R = x; g.ldr = H;
@@ -495,7 +497,7 @@ struct bltvqg_engine {
         g.cg.Hi = stem ? imgHp : cs.Hi; g.cg.Wi = stem ? imgWp : cs.Wi;
         g.cg.Cin = cs.CinPad; g.cg.cin_log2 = ilog2(cs.CinPad); g.cg.Ho = cs.Ho; g.cg.Wo = cs.Wo;
         g.cg.KH = cs.K; g.cg.KW = stem ? 8 : cs.K; g.cg.stride = cs.stride; g.cg.pad = stem ? 0 : cs.pad;
-        g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+        if (bn_train) { g.stat_sum = stat_sum; g.stat_sq = stat_sq; }
         if (prof_on) {
             if (prof_n == prof_a.size()) {
                 hipEvent_t a, b;
@@ -510,6 +512,9 @@ struct bltvqg_engine {
             ++prof_n;
             prof_flops += 2.0 * (double)g.M * (double)cs.Cout * (double)(cs.K * cs.K * cs.Cin);   // algorithmic (unpadded Cin)
         }
+        if (!bn_train)
+            return blt_bn_eval_scale(FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"),
+                                     1e-5f, cs.scale, cs.shift, cs.Cout, s);
         const int nparts = blt_gemm_stat_rows(g);
         return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)g.M, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
                                0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,
@@ -559,8 +564,14 @@ struct bltvqg_engine {
             g.bias = P("encoder_cnn.cnn.fc.bias");
             RC(blt_gemm(BLT_F32, g, s));
         }
-        RC(blt_bn1d_fwd(BLT_F32, featpre, P("encoder_cnn.bn.weight"), P("encoder_cnn.bn.bias"), feats32, bn1_mean, bn1_rstd,
-                        FZ("encoder_cnn.bn.running_mean"), FZ("encoder_cnn.bn.running_var"), B, H, 1e-5f, 0.01f, s));
+        if (bn_train) {
+            RC(blt_bn1d_fwd(BLT_F32, featpre, P("encoder_cnn.bn.weight"), P("encoder_cnn.bn.bias"), feats32, bn1_mean, bn1_rstd,
+                            FZ("encoder_cnn.bn.running_mean"), FZ("encoder_cnn.bn.running_var"), B, H, 1e-5f, 0.01f, s));
+        } else {      // bn1_mean / bn1_rstd double as the eval-mode scale / shift
+            RC(blt_bn_eval_scale(P("encoder_cnn.bn.weight"), P("encoder_cnn.bn.bias"), FZ("encoder_cnn.bn.running_mean"),
+                                 FZ("encoder_cnn.bn.running_var"), 1e-5f, bn1_mean, bn1_rstd, H, s));
+            RC(blt_bn_apply(BLT_F32, featpre, bn1_mean, bn1_rstd, nullptr, feats32, B, H, 0, s));
+        }
         return blt_cast_rows(BLT_F32, feats32, H, dt, feats, H, B, H, s);
     }
 
@@ -657,6 +668,63 @@ struct bltvqg_engine {
             RC(blt_gemm(dt, lin(hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", recon, H, B), s));
         }
         fwd_done = true;
+        return BLT_OK;
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // IQ.decode_greedy (reference models/iq.py:117-152): encoder once, then T decoder passes over the growing prefix.  Each pass
+    // runs the decoder on all T positions with "future keys do not exist" attention (causal = 2), which gives position t exactly
+    // the value the reference computes on the length-(t+1) prefix; the next token is the argmax of that position's logits.
+    // ---------------------------------------------------------------------------------------------
+    int decode_greedy(const float* images, const int64_t* ctx, const float* eps, int p2, int train_bn, int* tokens, int* top_idx, float* top_val,
+                      hipStream_t s) {
+        BLT_REQUIRE(bound, "engine_decode_greedy: engine not bound");
+        BLT_REQUIRE(images && ctx && tokens && top_idx && top_val, "engine_decode_greedy: null pointer");
+        BLT_REQUIRE(!p2 || eps, "engine_decode_greedy: eps required when the latent path is on");
+        BLT_REQUIRE(c.attention_dropout == 0.f && c.relu_dropout == 0.f, "engine_decode_greedy: create the decode engine with dropout 0");
+        phase2 = p2; seed = 0; fwd_done = false;
+        const bool saved_bn = bn_train, saved_streams = use_streams;
+        bn_train = train_bn != 0; use_streams = false; causal_mode = 2;
+        int rc = decode_body(images, ctx, eps, tokens, top_idx, top_val, s);
+        bn_train = saved_bn; use_streams = saved_streams; causal_mode = 1;
+        return rc;
+    }
+    int decode_body(const float* images, const int64_t* ctx, const float* eps, int* tokens, int* top_idx, float* top_val, hipStream_t s) {
+        if (dt == BLT_BF16) RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
+        if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
+        RC(blt_prep_decode((const long long*)ctx, B, Sa, T, ids_all, pos_all, ctx32, s));
+        int* ys = ids_all + Ma;
+        RC(cnn_fwd(images, s));
+        int ldw;
+        const void* we = W("embedding.1.weight", &ldw);
+        auto embed = [&](int row0, int rows) -> int {
+            RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all + row0, (char*)emb_rows + (size_t)row0 * Epad * es, rows, E, Epad, s));
+            GemmArgs g = mk((char*)emb_rows + (size_t)row0 * Epad * es, Epad, 0, we, ldw, 0, (char*)X_all + (size_t)row0 * H * es, H, rows, H, E);
+            g.bias = P("embedding.1.bias");
+            g.rowtab = timing; g.rowidx = pos_all + row0; g.ldt = H;
+            return blt_gemm(dt, g, s);
+        };
+        RC(embed(0, Ma));
+        enc.x_in = X_all; enc.key_ids = ctx32;
+        dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = ys;
+        RC(stack_fwd(enc, nullptr, nullptr, s));
+        RC(blt_rows_add(dt, enc.out, (long)Sa * H, feats, H, nullptr, 0, B, H, 1, s));
+        if (phase2) {
+            // Latent.forward with x_p = None (transformer_layers.py:41-48): z = eps * exp(0.5 logvar_prior) + mean_prior
+            if (hipMemcpyAsync(eps_dev, eps, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s) != hipSuccess) return BLT_ERR_HIP;
+            RC(blt_copy2d(dt, enc.out, Sa * H, (char*)cat_in + (size_t)H * es, 2 * H, B, H, s));
+            RC(mlp3_fwd("latent_layer.mean_logvar_prior", (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, mlvp, s));
+            RC(blt_latent_fwd(dt, mlvp, mlvp, eps_dev, zlat, stats + 6, B, Z, 2 * Z, s));      // reparameterise with the PRIOR; KL slot unused
+            RC(blt_gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
+        }
+        for (int t = 0; t < T; ++t) {
+            RC(embed(Ma, Mt));
+            RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, phase2 ? zproj : nullptr, H, B, H, 1, s));     // [:,0] += z + image_features
+            RC(stack_fwd(dec, enc.out, ctx32, s));
+            GemmArgs g = lin((char*)dec.out + (size_t)t * H * es, T * H, "decoder.output.weight", "decoder.output.bias", zlogit, ldV, B);
+            RC(blt_gemm(dt, g, s));
+            RC(blt_argmax_top6(dt, zlogit, ldV, B, V, t, T, ys, tokens, top_idx, top_val, s));
+        }
         return BLT_OK;
     }
 
@@ -982,6 +1050,18 @@ int bltvqg_engine_forward(bltvqg_engine* e, const float* images, const int64_t* 
                           const float* eps, int phase2, uint64_t seed, void* stream) {
     BLT_REQUIRE(e, "engine_forward: null engine");
     return e->forward(images, context, posterior, target, eps, phase2, seed, (hipStream_t)stream);
+}
+
+int bltvqg_engine_decode_greedy(bltvqg_engine* e, const float* images, const int64_t* context, const float* eps, int phase2, int train_bn,
+                                int32_t* tokens, int32_t* top_idx, float* top_val, void* stream) {
+    BLT_REQUIRE(e, "engine_decode_greedy: null engine");
+    return e->decode_greedy(images, context, eps, phase2, train_bn, tokens, top_idx, top_val, (hipStream_t)stream);
+}
+
+int bltvqg_engine_set_bn_train(bltvqg_engine* e, int train) {
+    BLT_REQUIRE(e, "engine_set_bn_train: null engine");
+    e->bn_train = train != 0;
+    return BLT_OK;
 }
 
 int bltvqg_engine_loss_backward(bltvqg_engine* e, float kl_weight, void* stream) {

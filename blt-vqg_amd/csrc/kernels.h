@@ -141,6 +141,13 @@ int blt_latent_fwd(int dtype, const void* mlv_p, const void* mlv_q, const float*
 int blt_latent_bwd(int dtype, const void* mlv_p, const void* mlv_q, const float* eps, const void* dz, float kld_gscale,
                    void* dmlv_p, void* dmlv_q, int B, int Z, int ld, hipStream_t s);
 
+// ---- greedy decoding ----------------------------------------------------------------------------------
+int blt_prep_decode(const long long* ctx, int B, int Sa, int T, int* ids_all, int* pos_all, int* ctx32, hipStream_t s);
+int blt_argmax_top6(int dtype, const void* logits, int ld, int B, int V, int t, int T, int* ys, int* tokens, int* top_idx, float* top_val,
+                    hipStream_t s);
+int blt_bn_eval_scale(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift, int C,
+                      hipStream_t s);
+
 // ---- optimiser ---------------------------------------------------------------------------------
 int blt_sumsq(const float* x, long n, float* out /* += */, hipStream_t s);
 // clip_grad_norm_(max_norm) + Adam (torch defaults) over a flat fp32 buffer; gnorm_sq is a device scalar

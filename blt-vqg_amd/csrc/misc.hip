@@ -303,6 +303,73 @@ __global__ void latent_bwd_kernel(const T* __restrict__ mlvp, const T* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// greedy decoding helpers (reference models/iq.py:117-152)
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void prep_decode_kernel(const long long* __restrict__ ctx, int B, int Sa, int T, int* __restrict__ ids_all, int* __restrict__ pos_all,
+                                   int* __restrict__ ctx32) {
+    const int na = B * Sa, nt = B * T;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nt; i += gridDim.x * blockDim.x) {
+        if (i < na) {
+            const int v = (int)ctx[i];
+            ids_all[i] = v; ctx32[i] = v; pos_all[i] = i % Sa;
+        } else {
+            ids_all[i] = 0;                 // ys starts as <pad> everywhere (iq.py:129)
+            pos_all[i] = (i - na) % T;
+        }
+    }
+}
+
+// One block per sample: argmax of the logits row (first maximum, like torch.max) and the 6 largest softmax probabilities
+// (torch.topk order).  Writes the next input token ys[b, t+1].
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_top6_kernel(const T* __restrict__ logits, int ld, int V, int t, int Tn, int* __restrict__ ys,
+                                                         int* __restrict__ tokens, int* __restrict__ top_idx, float* __restrict__ top_val) {
+    __shared__ float red[16];
+    __shared__ float bv[4];
+    __shared__ int bi[4];
+    __shared__ int picked[6];
+    const int b = blockIdx.x;
+    const T* x = logits + (long)b * ld;
+    float m = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) m = fmaxf(m, to_f32(x[v]));
+    m = block_max(m, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) s += __expf(to_f32(x[v]) - m);
+    s = block_sum(s, red);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = 0; k < 6; ++k) {
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        for (int v = threadIdx.x; v < V; v += blockDim.x) {
+            bool used = false;
+            for (int q = 0; q < k; ++q) used = used || (picked[q] == v);
+            const float xv = to_f32(x[v]);
+            if (!used && (xv > best || (xv == best && v < bidx))) { best = xv; bidx = v; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bidx, o, 64);
+            if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+        }
+        __syncthreads();
+        if (lane == 0) { bv[w] = best; bi[w] = bidx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int q = 1; q < 4; ++q)
+                if (bv[q] > bv[0] || (bv[q] == bv[0] && bi[q] < bi[0])) { bv[0] = bv[q]; bi[0] = bi[q]; }
+            picked[k] = bi[0];
+            top_idx[((long)b * Tn + t) * 6 + k] = bi[0];
+            top_val[((long)b * Tn + t) * 6 + k] = __expf(bv[0] - m) / s;
+            if (k == 0) {
+                tokens[(long)b * Tn + t] = bi[0];
+                if (t + 1 < Tn) ys[(long)b * Tn + t + 1] = bi[0];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // optimiser
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long n, float* __restrict__ out) {
@@ -502,6 +569,21 @@ int blt_latent_bwd(int dtype, const void* mlv_p, const void* mlv_q, const float*
     if (dtype == BLT_F32) hipLaunchKernelGGL(latent_bwd_kernel<float>, dim3(ew_grid((long)B * Z)), dim3(256), 0, s, (const float*)mlv_p, (const float*)mlv_q, eps, (const float*)dz, G, (float*)dmlv_p, (float*)dmlv_q, B, Z, ld);
     else hipLaunchKernelGGL(latent_bwd_kernel<bf16>, dim3(ew_grid((long)B * Z)), dim3(256), 0, s, (const bf16*)mlv_p, (const bf16*)mlv_q, eps, (const bf16*)dz, G, (bf16*)dmlv_p, (bf16*)dmlv_q, B, Z, ld);
     return blt_check_launch("latent_bwd");
+}
+
+int blt_prep_decode(const long long* ctx, int B, int Sa, int T, int* ids_all, int* pos_all, int* ctx32, hipStream_t s) {
+    BLT_REQUIRE(ctx && ids_all && pos_all && ctx32 && B > 0 && Sa > 0 && T > 0, "prep_decode: bad args");
+    hipLaunchKernelGGL(prep_decode_kernel, dim3(ew_grid((long)B * (Sa + T))), dim3(256), 0, s, ctx, B, Sa, T, ids_all, pos_all, ctx32);
+    return blt_check_launch("prep_decode");
+}
+
+int blt_argmax_top6(int dtype, const void* logits, int ld, int B, int V, int t, int T, int* ys, int* tokens, int* top_idx, float* top_val,
+                    hipStream_t s) {
+    CHECK_DTYPE(dtype, "argmax_top6");
+    BLT_REQUIRE(logits && ys && tokens && top_idx && top_val && B > 0 && V >= 6 && ld >= V && t >= 0 && t < T, "argmax_top6: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(argmax_top6_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)logits, ld, V, t, T, ys, tokens, top_idx, top_val);
+    else hipLaunchKernelGGL(argmax_top6_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)logits, ld, V, t, T, ys, tokens, top_idx, top_val);
+    return blt_check_launch("argmax_top6");
 }
 
 int blt_sumsq(const float* x, long n, float* out, hipStream_t s) {

@@ -188,6 +188,15 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict
     }
 }
 
+__global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
+                                     const float* __restrict__ rvar, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
@@ -390,6 +399,14 @@ int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long
     hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, (const double*)scratch, BN_SLICES, C, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, scale, shift, save_mean, save_var);
     return blt_check_launch("bn_finalize");
+}
+
+// eval-mode BatchNorm: y = x*scale + shift with scale = gamma/sqrt(running_var + eps), shift = beta - running_mean*scale
+int blt_bn_eval_scale(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift, int C,
+                      hipStream_t s) {
+    BLT_REQUIRE(gamma && beta && rmean && rvar && scale && shift && C > 0, "bn_eval_scale: bad args");
+    hipLaunchKernelGGL(bn_eval_scale_kernel, dim3(cdiv(C, 64)), dim3(64), 0, s, gamma, beta, rmean, rvar, eps, scale, shift, C);
+    return blt_check_launch("bn_eval_scale");
 }
 
 int blt_bn_apply(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, long rows,

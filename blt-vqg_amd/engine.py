@@ -134,6 +134,19 @@ class StepEngine(object):
         check(self.lib.bltvqg_engine_forward(self.h, ptr(images), ptr(context), ptr(posterior), ptr(target), ptr(eps),
                                              1 if phase2 else 0, int(seed), stream_ptr()), "engine_forward")
 
+    def decode_greedy(self, images, context, eps=None, phase2=False, train_bn=False):
+        """Greedy decode over len_target steps; returns (tokens [B,T] int32, top_idx [B,T,6] int32, top_val [B,T,6] fp32)."""
+        c = self.cfg
+        tokens = torch.zeros(c.batch, c.len_target, dtype=torch.int32, device=self.device)
+        top_idx = torch.zeros(c.batch, c.len_target, 6, dtype=torch.int32, device=self.device)
+        top_val = torch.zeros(c.batch, c.len_target, 6, dtype=torch.float32, device=self.device)
+        check(self.lib.bltvqg_engine_decode_greedy(self.h, ptr(images), ptr(context), ptr(eps), 1 if phase2 else 0, 1 if train_bn else 0,
+                                                   ptr(tokens), ptr(top_idx), ptr(top_val), stream_ptr()), "engine_decode_greedy")
+        return tokens, top_idx, top_val
+
+    def set_bn_train(self, train):
+        check(self.lib.bltvqg_engine_set_bn_train(self.h, 1 if train else 0), "engine_set_bn_train")
+
     def loss_backward(self, kl_weight=0.0):
         check(self.lib.bltvqg_engine_loss_backward(self.h, float(kl_weight), stream_ptr()), "engine_loss_backward")
 

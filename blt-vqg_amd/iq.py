@@ -237,9 +237,44 @@ class IQ(nn.Module):
             return output, None, None, (feats, recon)
         return output, z_logit, kld, (feats, recon)
 
-    def decode_greedy(self, images, answers, max_decode_length=50):
-        raise NotImplementedError("greedy decoding (reference iq.py:117-152) is the next scope row (SURVEY §8f N1); "
-                                  "this build covers the train step")
+    def decode_greedy(self, images, answers, max_decode_length=50, eps=None):
+        """reference models/iq.py:117-152.  Returns (sentences, top_args (B, L+1, 6), top_vals (B, L+1, 6)).  BatchNorm follows
+        `self.training` (Lightning calls this under model.eval(): running statistics).  `eps` injects the latent noise."""
+        if not images.is_cuda:
+            raise RuntimeError("IQ.decode_greedy runs on MI355X only (libbltvqg_hip.so); there is no CPU fallback.")
+        T = max_decode_length + 1
+        B = images.shape[0]
+        key = ("decode", B, answers.shape[1], T, images.shape[2], images.shape[3], images.device.index)
+        eng = self._engines.get(key)
+        if eng is None:
+            a = self.args
+            cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size,
+                              answers.shape[1], 21, T, (images.shape[2], images.shape[3]), self._dtype, 0.0, 0.0)
+            eng = StepEngine(cfg, images.device)
+            if self._primary is None:
+                eng.allocate()
+                self._primary = eng
+                self._adopt(eng)
+            else:
+                eng.allocate(share_from=self._primary)
+            self._engines[key] = eng
+        if not self._aliased():
+            self._adopt(self._primary)
+        phase2 = bool(self.latent_transformer)
+        if phase2 and eps is None:
+            eps = torch.randn(B, self.args.latent_dim, device=images.device, generator=self.eps_generator)
+        tokens, top_idx, top_vals = eng.decode_greedy(images.contiguous().float(), answers.contiguous(),
+                                                      None if eps is None else eps.contiguous().float(), phase2, train_bn=self.training)
+        eos = self.vocab.word2idx[self.vocab.SYM_EOS] if hasattr(self.vocab, "SYM_EOS") else 3
+        sentences = []
+        for row in tokens.cpu().tolist():
+            st = ""
+            for tok in row:
+                if tok == eos:
+                    break
+                st += self.vocab.idx2word[tok] + " "
+            sentences.append(st)
+        return sentences, top_idx.float(), top_vals
 
     # ---- fused train-step access (used by TrainIQ.fused_training_step and bench.py) ---------------------------------
     def engine(self, images, answers, response, target):

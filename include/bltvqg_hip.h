@@ -161,6 +161,15 @@ void bltvqg_engine_invalidate_frozen(bltvqg_engine* e);
  * (may be NULL in phase 1).  train_bn: BatchNorm in train mode (batch statistics + running-stat update), as the reference. */
 int bltvqg_engine_forward(bltvqg_engine* e, const float* images, const int64_t* context, const int64_t* posterior,
                           const int64_t* target, const float* eps, int phase2, uint64_t seed, void* stream);
+/* IQ.decode_greedy (models/iq.py:117-152) on an engine created with len_target = max_decode_length + 1 and dropout 0:
+ * tokens [B,T] (argmax per step), top_idx / top_val [B,T,6] (top-6 softmax probabilities, torch.topk order).
+ * train_bn = 0: BatchNorm layers use running statistics (module.eval(), as under Lightning validation); eps [B,Z] is the latent
+ * noise (required when phase2). */
+int bltvqg_engine_decode_greedy(bltvqg_engine* e, const float* images, const int64_t* context, const float* eps, int phase2, int train_bn,
+                                int32_t* tokens, int32_t* top_idx, float* top_val, void* stream);
+/* BatchNorm mode of bltvqg_engine_forward: 1 = batch statistics + running-stat update (the reference's training behaviour,
+ * default), 0 = running statistics (module.eval()). */
+int bltvqg_engine_set_bn_train(bltvqg_engine* e, int train);
 /* calculate_losses (train_iq.py:81-103) fused with the whole backward pass.  Gradients of every trainable parameter are
  * written to the bound flat gradient buffer (zeroed first).  kl_weight = min(tanh(6*kliter/full_kl_step-3)+1, 1). */
 int bltvqg_engine_loss_backward(bltvqg_engine* e, float kl_weight, void* stream);

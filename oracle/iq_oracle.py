@@ -347,6 +347,33 @@ def iq_forward(P, cfg, images, answers, response, target, phase2, eps=None, mask
     return output, z_logit, kld, (image_features, recon), extras
 
 
+def decode_greedy(P, cfg, images, answers, phase2, eps=None, max_decode_length=50, bn_train=False):
+    """IQ.decode_greedy iq.py:117-152 + GVTransformerDecoder.inference_forward decoder_transformer.py:43-48: the decoder is re-run
+    on the growing prefix (no KV cache); ys starts as a single <pad>.  Returns (tokens [B,L+1], top6 idx [B,L+1,6], top6 probs)."""
+    with torch.no_grad():
+        feats = encoder_cnn(P, images, bn_train, None)
+        src_mask = pad_mask(answers)
+        enc = encoder(P, "answer_encoder.encoder", embed(P, answers), src_mask, cfg)
+        enc = torch.cat([(enc[:, 0] + feats).unsqueeze(1), enc[:, 1:]], dim=1)
+        z = 0
+        if phase2:
+            _, z, _ = latent(P, enc[:, 0], None, eps, cfg.latent_dim)
+            z = F.linear(z, P["latent_projection.weight"], P["latent_projection.bias"])
+        B = answers.shape[0]
+        ys = torch.full((B, 1), PAD, dtype=torch.long)
+        toks, tidx, tval = [], [], []
+        for _ in range(max_decode_length + 1):
+            emb = embed(P, ys)
+            emb = torch.cat([(emb[:, 0] + z + feats).unsqueeze(1), emb[:, 1:]], dim=1)
+            dec = decoder(P, "decoder.decoder", emb, enc, src_mask, pad_mask(ys), cfg)
+            logits = F.linear(dec, P["decoder.output.weight"], P["decoder.output.bias"])[:, -1]
+            nxt = logits.argmax(dim=1)
+            v, i = torch.topk(F.softmax(logits, -1), 6, dim=1)
+            toks.append(nxt); tidx.append(i); tval.append(v)
+            ys = torch.cat([ys, nxt.unsqueeze(1)], dim=1)
+        return torch.stack(toks, 1), torch.stack(tidx, 1), torch.stack(tval, 1)
+
+
 # ----------------------------------------------------------------------------------
 # losses / schedules / optimiser (train_iq.py)
 # ----------------------------------------------------------------------------------

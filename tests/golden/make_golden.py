@@ -230,6 +230,24 @@ def main():
                     if c["full"] or k.startswith("encoder_cnn.bn.") or k.startswith("encoder_cnn.cnn.bn1."):
                         out["p1.buf." + k] = v.numpy()
             # the train-mode forward updated BN running stats inside the model; full_state is reloaded each run
+        if c["full"]:
+            # greedy decoding (iq.py:117-152) under model.eval(), latent off and on (eps injected)
+            import models.transformer_layers as TL
+            for phase2 in (False, True):
+                model.load_state_dict(full_state, strict=False)
+                model.eval()
+                model.switch_GVT_train_mode(phase2)
+                real_randn = torch.randn
+                TL.torch.randn = lambda *a, **k: batch["eps"].clone()
+                try:
+                    with torch.no_grad():
+                        _sent, targs, tvals = model.decode_greedy(batch["images"], batch["answers"], max_decode_length=12)
+                finally:
+                    TL.torch.randn = real_randn
+                tag = "dec2" if phase2 else "dec1"
+                out[tag + ".top_idx"] = targs.numpy().astype(np.int32)
+                out[tag + ".top_val"] = tvals.numpy()
+            model.train()
         if name == "small":
             # state_dict schema of the reference model (260 keys at L=2, aliases included) for tests/test_host_api.py
             with open(os.path.join(HERE, "state_keys_small.txt"), "w") as fh:

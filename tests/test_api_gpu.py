@@ -118,3 +118,36 @@ def test_batch_shape_change_shares_parameters():
     e = list(t.model._engines.values())
     assert len(e) == 2 and e[0].flat_train.data_ptr() == e[1].flat_train.data_ptr()
     assert np.isfinite(t.last_stats()["loss"])
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2"])
+@pytest.mark.parametrize("phase2", [False, True])
+def test_decode_greedy_token_ids_bit_exact(name, phase2):
+    """models.IQ.decode_greedy (HIP engine, fp32) vs the reference fixture: bit-exact token indices (north_star), top-6 too."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    z, cfg, state, batch = load_golden(name)
+    tag = "dec2" if phase2 else "dec1"
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")
+    t.eval()                                   # Lightning runs validation_epoch_end (train_iq.py:159-206) under model.eval()
+    t.model.switch_GVT_train_mode(phase2)
+    sent, top_args, top_vals = t.model.decode_greedy(batch["images"].cuda(), batch["answers"].cuda(), max_decode_length=12,
+                                                     eps=batch["eps"].cuda())
+    assert top_args.shape == (batch["images"].shape[0], 13, 6) and len(sent) == batch["images"].shape[0]
+    assert np.array_equal(top_args.cpu().numpy().astype(np.int32), z[tag + ".top_idx"])
+    assert np.allclose(top_vals.cpu().numpy(), z[tag + ".top_val"], rtol=2e-3, atol=1e-6)
+    # sentences are the argmax words up to <end>
+    first = [t.model.vocab.idx2word[int(i)] for i in z[tag + ".top_idx"][0, :, 0]]
+    want = ""
+    for wd in first:
+        if wd == "<end>":
+            break
+        want += wd + " "
+    assert sent[0] == want
+    # train-mode forward afterwards still uses batch statistics (the decode switch is local)
+    t.train()
+    out, _, _, _ = t.model(batch["images"].cuda(), batch["answers"].cuda(), batch["posteriors"].cuda(), batch["questions"].cuda(),
+                           eps=batch["eps"].cuda())
+    ptag = "p2" if phase2 else "p1"
+    assert rel_err(out.detach().cpu(), z[ptag + ".output"]) < 2e-4

@@ -85,3 +85,16 @@ def test_timing_signal_is_concat_sin_cos():
     assert s.shape == (21, 64)
     assert torch.allclose(s[0, :32], torch.zeros(32)) and torch.allclose(s[0, 32:], torch.ones(32))
     assert abs(float(s[3, 0]) - np.sin(3.0)) < 1e-6 and abs(float(s[3, 32]) - np.cos(3.0)) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny2"])
+@pytest.mark.parametrize("phase2", [False, True])
+def test_oracle_greedy_decode_matches_reference(name, phase2):
+    """IQ.decode_greedy under model.eval(): token ids and top-6 indices bit-exact, probabilities to 1e-5."""
+    z, cfg, state, batch = load_golden(name)
+    tag = "dec2" if phase2 else "dec1"
+    P = O.clone_params(state, requires_grad=False)
+    toks, tidx, tval = O.decode_greedy(P, cfg, batch["images"], batch["answers"], phase2, batch["eps"], max_decode_length=12)
+    assert np.array_equal(tidx.numpy().astype(np.int32), z[tag + ".top_idx"])
+    assert np.array_equal(toks.numpy().astype(np.int32), z[tag + ".top_idx"][:, :, 0])
+    assert np.allclose(tval.numpy(), z[tag + ".top_val"], rtol=1e-4, atol=1e-7)

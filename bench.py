@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--phase", type=int, default=2, choices=[1, 2], help="1 = pre-training (latent off), 2 = latent on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--autotune", action="store_true", help="time candidate GEMM/conv kernels per launch in the first warm-up step")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -134,6 +135,13 @@ def main():
                  kl_weight=0.5, lr=1e-4, max_norm=5.0)
 
     print("[bench] rank %d: engine ready (workspace %.2f GB), warming up" % (rank, eng.workspace_bytes / 1e9), file=sys.stderr, flush=True)
+    if a.autotune:
+        # measure, don't guess: the first warm-up step times every candidate GEMM/conv kernel (tile shape, LDS-DMA ring vs
+        # register staging) on the real operands of each distinct launch and caches the fastest (csrc/gemm.hip::autotune)
+        eng.lib.bltvqg_debug_set(2, 1)
+        one_step(0)
+        torch.cuda.synchronize()
+        eng.lib.bltvqg_debug_set(2, 0)
     for i in range(a.warmup):
         one_step(i)
     torch.cuda.synchronize()

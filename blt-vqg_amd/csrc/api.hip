@@ -40,7 +40,7 @@ int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int H
 
 int bltvqg_conv2d_stat_rows(int N, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad) {
     GemmArgs g = conv_args(nullptr, nullptr, nullptr, N, Hi, Wi, 8, Cout, KH, KW, stride, pad);
-    return blt_gemm_stat_rows(g);
+    return blt_gemm_stat_rows(g, BLT_BF16);
 }
 
 int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, int pad_top, int pad_left, int Hp, int Wp,
@@ -69,7 +69,7 @@ int bltvqg_conv_stem_stat_rows(int N, int H, int W, int Cout) {
     GemmArgs g;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     g.M = N * Ho * Wo; g.N = Cout; g.K = 224;
-    return blt_gemm_stat_rows(g);
+    return blt_gemm_stat_rows(g, BLT_BF16);
 }
 
 int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,

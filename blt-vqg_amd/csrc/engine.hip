@@ -400,6 +400,19 @@ struct bltvqg_engine {
         return rc;
     }
 
+    // dX = dY W with a vocabulary-sized contraction (K = V): few output tiles and a long K loop, so the K range is split over
+    // workgroups into an fp32 scratch (atomics) and cast back; falls through to the plain kernel in fp32 mode / small V
+    int dgrad_bigk(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M, hipStream_t s) {
+        GemmArgs g = dgrad(dY, ldy, wname, dX, ldx, M);
+        if (dt != BLT_BF16 || g.K < 2048) return blt_gemm(dt, g, s);
+        float* acc = (float*)sF[0];                          // >= Mmax*F*2 bytes >= M*H*4 because F >= 2H
+        if ((size_t)M * g.N * 4 > (size_t)(Mp > Mt ? Mp : Mt) * F * es) return blt_gemm(dt, g, s);
+        if (hipMemsetAsync(acc, 0, (size_t)M * g.N * 4, s) != hipSuccess) { blt_set_error("dgrad_bigk: memset failed"); return BLT_ERR_HIP; }
+        g.C = acc; g.ldc = g.N; g.out_f32 = 1; g.split_k = 16;
+        { const int rc_ = blt_gemm(dt, g, s); if (rc_) return rc_; }
+        return blt_cast_rows(BLT_F32, acc, g.N, dt, dX, ldx, M, g.N, s);
+    }
+
     uint32_t sid(int stack, int layer, int site) const { return (uint32_t)(stack * 1000 + layer * 10 + site); }
 
 #define RC(x) do { int _rc = (x); if (_rc) return _rc; } while (0)
@@ -515,7 +528,7 @@ struct bltvqg_engine {
         if (!bn_train)
             return blt_bn_eval_scale(FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"),
                                      1e-5f, cs.scale, cs.shift, cs.Cout, s);
-        const int nparts = blt_gemm_stat_rows(g);
+        const int nparts = blt_gemm_stat_rows(g, dt);
         return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)g.M, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
                                0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,
                                nullptr, stat_tmp, s);
@@ -805,7 +818,7 @@ struct bltvqg_engine {
         // ---- vocabulary projection + decoder ----
         RC(wgrad(logits, ldV, dec.out, H, "decoder.output.weight", "decoder.output.bias", Mt, s));
         void* gA = sA[0];
-        RC(blt_gemm(dt, dgrad(logits, ldV, "decoder.output.weight", gA, H, Mt), s));
+        RC(dgrad_bigk(logits, ldV, "decoder.output.weight", gA, H, Mt, s));
         void* dxT = (char*)dX_all + (size_t)Ma * H * es;
         {
             const void* xL = dec.layers[L - 1].x2;
@@ -831,7 +844,7 @@ struct bltvqg_engine {
             RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
             // ---- z_classifier ----
             RC(wgrad(dzl, ldV, zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", B, s));
-            RC(blt_gemm(dt, dgrad(dzl, ldV, "decoder.z_classifier.weight", g_b2, H, B), s));
+            RC(dgrad_bigk(dzl, ldV, "decoder.z_classifier.weight", g_b2, H, B, s));
             RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
             RC(blt_rows_add(dt, d_feats, H, g_b2, H, nullptr, 0, B, H, 1, s));
             // ---- latent projection, reparameterisation + KL, prior / posterior nets ----

@@ -19,6 +19,8 @@
 //
 // Replaces: torch.nn.Linear / F.conv2d call sites of the reference hot path
 // (models/transformer_layers.py:453-456,489-491,530,400-408; models/encoder_cnn.py:20,33; models/iq.py:39,72-78).
+#include <unordered_map>
+#include <vector>
 #include "kernels.h"
 
 namespace {
@@ -699,46 +701,56 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 
 }  // namespace
 
-// process-wide tuning switches for A/B benchmarking (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile
+// process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode
 static int g_debug[4] = {0, 0, 0, 0};
 void blt_debug_set(int key, int value) { if (key >= 0 && key < 4) g_debug[key] = value; }
 
-// tile heuristic: 128-wide tiles once they fill the chip; a 64-column tile when N <= 64 (Cout = 64 convolutions)
-void blt_gemm_tile2(const GemmArgs& a, int* bm, int* bn) {
-    if (a.force_tile == 64) { *bm = 64; *bn = 64; return; }
-    if (a.force_tile == 128) { *bm = 128; *bn = 128; return; }
-    if (a.force_tile == 12864) { *bm = 128; *bn = 64; return; }
+struct Choice { int bm, bn, no_dma; };
+static std::unordered_map<uint64_t, Choice> g_tuned;     // filled by autotune mode: measured best kernel per GEMM descriptor
+
+static uint64_t tune_key(const GemmArgs& a, int dtype) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix((uint64_t)dtype); mix((uint64_t)a.M); mix((uint64_t)a.N); mix((uint64_t)a.K); mix((uint64_t)(a.transA * 2 + a.transB));
+    mix((uint64_t)a.is_conv); mix((uint64_t)(a.cg.KH * 16 + a.cg.stride)); mix((uint64_t)(a.split_k > 0)); mix((uint64_t)a.out_f32);
+    return h;
+}
+
+// heuristic: 128-wide tiles once they fill the chip; a 64-column tile when N <= 64 (Cout = 64 convolutions)
+static Choice heuristic(const GemmArgs& a) {
     if (a.N <= 64) {
-        const long t = cdiv(a.M, 128);
-        if (t >= 192) { *bm = 128; *bn = 64; return; }
-        *bm = 64; *bn = 64;
-        return;
+        if (cdiv(a.M, 128) >= 192) return {128, 64, 0};
+        return {64, 64, 0};
     }
     const long t128 = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
-    if (t128 >= 192) { *bm = 128; *bn = 128; return; }
+    if (t128 >= 192) return {128, 128, 0};
     // weight-gradient form with split-K: the K-slices provide the parallelism, so keep the (more efficient) large tile
-    if (a.split_k > 0 && a.transA && a.transB && t128 >= 32) { *bm = 128; *bn = 128; return; }
-    *bm = 64; *bn = 64;
+    if (a.split_k > 0 && a.transA && a.transB && t128 >= 32) return {128, 128, 0};
+    return {64, 64, 0};
 }
 
-int blt_gemm_tile(const GemmArgs& a_in) {
-    GemmArgs a = a_in;
-    if (g_debug[1] && !a.force_tile) a.force_tile = g_debug[1];
-    int bm, bn;
-    blt_gemm_tile2(a, &bm, &bn);
-    return bm;
+static Choice choose(const GemmArgs& a, int dtype) {
+    Choice c = heuristic(a);
+    auto it = g_tuned.find(tune_key(a, dtype));
+    if (it != g_tuned.end()) c = it->second;
+    const int ft = a.force_tile ? a.force_tile : g_debug[1];
+    if (ft == 64) { c.bm = 64; c.bn = 64; }
+    else if (ft == 128) { c.bm = 128; c.bn = 128; }
+    else if (ft == 12864) { c.bm = 128; c.bn = 64; }
+    if (a.no_dma || g_debug[0]) c.no_dma = 1;
+    return c;
 }
 
-int blt_gemm_stat_rows(const GemmArgs& a) { return 2 * cdiv(a.M, blt_gemm_tile(a)); }
+int blt_gemm_tile(const GemmArgs& a, int dtype) { return choose(a, dtype).bm; }
+int blt_gemm_stat_rows(const GemmArgs& a, int dtype) { return 2 * cdiv(a.M, choose(a, dtype).bm); }
 
-// split-K only for the fp32-accumulating weight-gradient form (both operands token-major, fp32 output, no epilogue terms)
+// split-K for fp32-accumulating outputs without epilogue terms (weight gradients; input gradients with a vocabulary-sized K)
 int blt_gemm_splits(const GemmArgs& a, int dtype) {
     if (a.split_k <= 0) return 1;
-    if (!(a.transA && a.transB) || !(a.out_f32 || dtype == BLT_F32)) return 1;
+    if (!(a.out_f32 || dtype == BLT_F32)) return 1;
     if (a.bias || a.relu || a.drop_p > 0.f || a.maskY || a.C2 || a.R || a.rowtab || a.stat_sum) return 1;
-    int bm, bn;
-    blt_gemm_tile2(a, &bm, &bn);
-    const long tiles = (long)cdiv(a.M, bm) * cdiv(a.N, bn);
+    const Choice c = choose(a, dtype);
+    const long tiles = (long)cdiv(a.M, c.bm) * cdiv(a.N, c.bn);
     const int bk = (dtype == BLT_BF16) ? 64 : 32;
     const int nk = cdiv(a.K, bk);
     long s = (tiles >= 256) ? 1 : (384 / tiles);
@@ -748,10 +760,48 @@ int blt_gemm_splits(const GemmArgs& a, int dtype) {
     return (int)s;
 }
 
+static int run_choice(int dtype, const GemmArgs& a, const Choice& c, int splits, hipStream_t stream) {
+    const bool dma_ok = (a.is_conv != 1) || (a.cg.Cin % 64 == 0);      // the DMA conv loader wants one filter tap per K-tile
+    if (dtype == BLT_BF16 && !a.transA && !a.transB && splits == 1 && !c.no_dma && dma_ok) {
+        if (c.bm == 128 && c.bn == 128) return dispatch_dma<128, 128>(a, stream);
+        if (c.bm == 128 && c.bn == 64) return dispatch_dma<128, 64>(a, stream);
+        return dispatch_dma<64, 64>(a, stream);
+    }
+    if (dtype == BLT_BF16) return dispatch_tile<bf16>(a, c.bm, c.bn, splits, stream);
+    return dispatch_tile<float>(a, c.bm, c.bn, splits, stream);
+}
+
+// autotune: time every candidate kernel for this descriptor on the real operands (idempotent launches only) and remember the best
+static int autotune(int dtype, const GemmArgs& a, hipStream_t stream) {
+    std::vector<Choice> cands;
+    const bool nt = !a.transA && !a.transB;
+    const int tiles[3][2] = {{64, 64}, {128, 64}, {128, 128}};
+    for (int t = 0; t < 3; ++t) {
+        if (dtype == BLT_BF16 && nt) cands.push_back({tiles[t][0], tiles[t][1], 0});
+        cands.push_back({tiles[t][0], tiles[t][1], 1});
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return BLT_ERR_HIP;
+    float best = 1e30f;
+    Choice bc = heuristic(a);
+    for (const Choice& c : cands) {
+        int rc = run_choice(dtype, a, c, 1, stream);      // warm-up (also sets function attributes)
+        if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+        (void)hipEventRecord(e0, stream);
+        for (int r = 0; r < 3; ++r) run_choice(dtype, a, c, 1, stream);
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return BLT_ERR_HIP; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) { best = ms; bc = c; }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    g_tuned[tune_key(a, dtype)] = bc;
+    return BLT_OK;
+}
+
 int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
-    GemmArgs a = a_in;
-    if (g_debug[0]) a.no_dma = 1;
-    if (g_debug[1] && !a.force_tile) a.force_tile = g_debug[1];
+    const GemmArgs& a = a_in;
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "gemm: bad dtype %d", dtype);
     BLT_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
     BLT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -780,15 +830,10 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
     BLT_REQUIRE((!a.R || ((uintptr_t)a.R % 16) == 0) && (!a.maskY || ((uintptr_t)a.maskY % 16) == 0) && (!a.C2 || ((uintptr_t)a.C2 % 16) == 0) &&
                 (!a.rowtab || ((uintptr_t)a.rowtab % 16) == 0), "gemm: epilogue operands must be 16-byte aligned");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
-    int bm, bn;
-    blt_gemm_tile2(a, &bm, &bn);
     const int splits = blt_gemm_splits(a, dtype);
-    const bool dma_ok = (a.is_conv != 1) || (a.cg.Cin % 64 == 0);      // the DMA conv loader wants one filter tap per K-tile
-    if (dtype == BLT_BF16 && !a.transA && !a.transB && splits == 1 && !a.no_dma && dma_ok) {
-        if (bm == 128 && bn == 128) return dispatch_dma<128, 128>(a, stream);
-        if (bm == 128 && bn == 64) return dispatch_dma<128, 64>(a, stream);
-        return dispatch_dma<64, 64>(a, stream);
+    if (g_debug[2] && splits == 1 && !a.accumulate && !a.force_tile && g_tuned.find(tune_key(a, dtype)) == g_tuned.end()) {
+        int rc = autotune(dtype, a, stream);
+        if (rc) return rc;
     }
-    if (dtype == BLT_BF16) return dispatch_tile<bf16>(a, bm, bn, splits, stream);
-    return dispatch_tile<float>(a, bm, bn, splits, stream);
+    return run_choice(dtype, a, choose(a, dtype), splits, stream);
 }

@@ -47,8 +47,8 @@ struct GemmArgs {
     int force_tile = 0;          // 0 = heuristic, 64 or 128
 };
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
-int blt_gemm_stat_rows(const GemmArgs& a);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
-int blt_gemm_tile(const GemmArgs& a);
+int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
+int blt_gemm_tile(const GemmArgs& a, int dtype);
 void blt_debug_set(int key, int value);
 int blt_gemm_splits(const GemmArgs& a, int dtype);
 

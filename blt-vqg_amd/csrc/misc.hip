@@ -136,19 +136,20 @@ __global__ void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __res
     }
 }
 
-// NCHW fp32 image -> NHWC [N, Hp, Wp, Cpad]: image placed at (pt, pl), zeros in the border and in the padded channels
+// NCHW fp32 image -> NHWC [N, Hp, Wp, Cpad]: image placed at (pt, pl), zeros in the border and in the padded channels.
+// One thread per output PIXEL: the C plane reads are coalesced along w, the Cpad channel values are written contiguously.
 template <typename T>
 __global__ void img_pack_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int H, int W, int Cpad, int pt, int pl,
                                 int Hp, int Wp) {
-    const long total = (long)N * Hp * Wp * Cpad;
+    const long total = (long)N * Hp * Wp;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cpad);
-        long t = i / Cpad;
+        long t = i;
         const int w = (int)(t % Wp) - pl; t /= Wp;
         const int h = (int)(t % Hp) - pt;
         const long n = t / Hp;
-        const bool ok = c < C && (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
-        dst[i] = from_f32<T>(ok ? src[((n * C + c) * H + h) * W + w] : 0.f);
+        const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        T* o = dst + i * Cpad;
+        for (int c = 0; c < Cpad; ++c) o[c] = from_f32<T>((in && c < C) ? src[((n * C + c) * H + h) * W + w] : 0.f);
     }
 }
 
@@ -512,7 +513,7 @@ int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long ro
 int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, int pt, int pl, int Hp, int Wp, hipStream_t s) {
     CHECK_DTYPE(dtype, "img_pack");
     BLT_REQUIRE(nchw && nhwc && N > 0 && C > 0 && C <= Cpad && H > 0 && W > 0 && pt >= 0 && pl >= 0 && Hp >= H + pt && Wp >= W + pl, "img_pack: bad args");
-    const long n = (long)N * Hp * Wp * Cpad;
+    const long n = (long)N * Hp * Wp;
     if (dtype == BLT_F32) hipLaunchKernelGGL(img_pack_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (float*)nhwc, N, C, H, W, Cpad, pt, pl, Hp, Wp);
     else hipLaunchKernelGGL(img_pack_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (bf16*)nhwc, N, C, H, W, Cpad, pt, pl, Hp, Wp);
     return blt_check_launch("img_pack");

@@ -386,8 +386,8 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     return blt_check_launch("layernorm_bwd");
 }
 
-static constexpr int BN_SLICES = 32;
-int blt_bn_scratch_doubles(int C) { return BN_SLICES * 2 * C; }
+static constexpr int BN_MAX_SLICES = 512;
+int blt_bn_scratch_doubles(int C) { return BN_MAX_SLICES * 2 * C; }
 
 int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long count, const float* gamma,
                     const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
@@ -395,8 +395,12 @@ int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long
     BLT_REQUIRE(psum && psq && gamma && beta && scale && shift && scratch, "bn_finalize: null pointer");
     BLT_REQUIRE(nparts > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
     BLT_REQUIRE(((uintptr_t)scratch % 8) == 0, "bn_finalize: scratch must be 8-byte aligned");
-    hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 64), BN_SLICES), dim3(256), 0, s, psum, psq, nparts, C, scratch);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, (const double*)scratch, BN_SLICES, C, (double)count, gamma, beta, eps,
+    // one slice per ~64 partial rows (32..512 slices, a multiple of 32): enough workgroups for the 25 k partials of the stem conv
+    int slices = (nparts / 64 + 31) / 32 * 32;
+    if (slices < 32) slices = 32;
+    if (slices > BN_MAX_SLICES) slices = BN_MAX_SLICES;
+    hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 64), slices), dim3(256), 0, s, psum, psq, nparts, C, scratch);
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, (const double*)scratch, slices, C, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, scale, shift, save_mean, save_var);
     return blt_check_launch("bn_finalize");
 }

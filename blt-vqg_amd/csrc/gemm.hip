@@ -492,7 +492,9 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base)
 
 template <int BM, int BN, int LOADER>
 struct DmaCfg {
-    static constexpr int NST = 3;
+    // ring depth: 2 stages (one K-tile in flight per block) for the 128x128 tile so that TWO blocks fit a CU (68 KB each: the
+    // second block's MFMAs cover this block's DMA wait); 3 stages (two tiles in flight) for the smaller tiles
+    static constexpr int NST = (BM == 128 && BN == 128) ? 2 : 3;
     static constexpr int BK = 64;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -598,13 +600,14 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
     const int l15 = lane & 15, lg = lane >> 4;
 
     const int nk = (p.K + BK - 1) / BK;
+    constexpr int AHEAD = C::NST - 1;                          // K-tiles kept in flight
     issue(0, 0);
-    if (nk > 1) issue(1, 1);
+    if (AHEAD > 1 && nk > 1) issue(1, 1);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) wait_vmcnt<C::CH_A + C::CH_B>();      // tile kt landed (this wave's part); tile kt+1 may still fly
+        if (AHEAD > 1 && kt + 1 < nk) wait_vmcnt<C::CH_A + C::CH_B>();   // tile kt landed (this wave's part); tile kt+1 may still fly
         else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                          // every wave's part of tile kt landed; stage (kt+2)%3 is free
-        if (kt + 2 < nk) issue(kt + 2, (kt + 2) % C::NST);
+        __builtin_amdgcn_s_barrier();                          // every wave's part of tile kt landed; stage (kt+AHEAD)%NST is free
+        if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % C::NST);
         const char* a_st = smem + (kt % C::NST) * C::STAGE;
         const char* b_st = a_st + C::A_BYTES;
 #pragma unroll

@@ -30,6 +30,7 @@ CONFIGS = {
 }
 # algorithmic FLOP per pair per train step: CNN fwd x1 + everything trainable x3
 FLOP_PER_PAIR = {"small": 4.25e9, "big": 9.95e9}
+PROFILE_EVERY = 5
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -149,9 +150,14 @@ def main():
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.profile_enable(True)
+    # The conv kernels are bracketed by HIP events on their own stream for the roofline figure.  An event record costs the stream
+    # a ~5.7 us bubble (40 of them per step = 5 % of a 4 ms step), so only every PROFILE_EVERY-th timed step carries them.
+    profiled = 0
     t0 = time.perf_counter()
     for i in range(a.steps):
+        on = (i % PROFILE_EVERY == 0)
+        eng.profile_enable(on)
+        profiled += int(on)
         one_step(a.warmup + i)
     torch.cuda.synchronize()
     if dist:
@@ -189,9 +195,10 @@ def main():
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                          "kernel": "gemm_kernel<bf16,*,*,conv> (implicit-GEMM conv of the ResNet-18 stack)",
-                         "launches_per_step": conv_launches // max(a.steps, 1),
+                         "launches_per_step": conv_launches // max(profiled, 1),
                          "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
-                         "kernel_share_of_step": round(conv_ms / (dt * 1e3), 4)},
+                         "profiled_steps": "%d of the %d timed steps (every %dth) carry the HIP events" % (profiled, a.steps, PROFILE_EVERY),
+                         "kernel_share_of_step": round(conv_ms / max(profiled, 1) / (dt / a.steps * 1e3), 4)},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, phase2, a.cpu_batch, a.cpu_steps)

@@ -37,6 +37,7 @@ SIGNATURES = {
     "bltvqg_last_error_string": (S, []),
     "bltvqg_debug_set": (None, [I, I]),
     "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
+    "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv2d_stat_rows": (I, [I, I, I, I, I, I, I, I]),
     "bltvqg_img_pack": (I, [I, P, P, I, I, I, I, I, I, I, I, I, P]),

@@ -18,6 +18,15 @@ int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, in
     return blt_gemm(dtype, g, (hipStream_t)stream);
 }
 
+int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* dbias, int rows, int N, int K,
+                        int split_k, void* stream) {
+    BLT_REQUIRE(dY && X && dW && rows > 0 && N > 0 && K > 0, "linear_wgrad: bad args");
+    GemmArgs g;
+    g.A = dY; g.lda = ldy; g.transA = 1; g.B = X; g.ldb = ldx; g.transB = 1; g.C = dW; g.ldc = ldw; g.M = N; g.N = K; g.K = rows;
+    g.out_f32 = 1; g.accumulate = 1; g.split_k = split_k; g.a_rowsum = dbias;
+    return blt_gemm(dtype, g, (hipStream_t)stream);
+}
+
 static GemmArgs conv_args(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     GemmArgs g;
     const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;

@@ -1,5 +1,5 @@
 // Fused small-sequence multi-head attention core (forward + backward) for sequences of <= 64 tokens.
-// One wavefront per (batch, head): Q/K/V head slices live in LDS as fp32, the whole Tq x Tk score tile stays on
+// One workgroup (4 wavefronts) per (batch, head): Q/K/V head slices live in LDS as fp32, the whole Tq x Tk score tile stays on
 // chip (never written to HBM), the pad / causal mask is derived from the key token ids, softmax statistics are
 // per-lane rows, dropout masks come from the Philox counter RNG so that backward regenerates them exactly.
 // The QKV / output projections are MFMA GEMMs (gemm.hip); this kernel is the part in between.
@@ -11,13 +11,17 @@
 
 namespace {
 
+// four waves per (batch, head): the tile is tiny, so the kernel is bound by LDS / global latency, not throughput — more waves
+// per workgroup (sharing one LDS image) hide it
+constexpr int ATT_THREADS = 256;
+
 // head slice [Tn, d] of a packed projection -> fp32 LDS rows of d+1 floats; 16-byte global loads when the layout allows
 template <typename T>
 __device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int b, int Tn, int h, int d, float* dst, int lane) {
     const int dp = d + 1;
     if ((d & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)src) & 15) == 0) {
         const int d8 = d >> 3;
-        for (int idx = lane; idx < Tn * d8; idx += 64) {
+        for (int idx = lane; idx < Tn * d8; idx += ATT_THREADS) {
             const int i = idx / d8, c = (idx - i * d8) * 8;
             float v[8];
             Vec8<T>::load(src + (size_t)(b * Tn + i) * ld + h * d + c, v);
@@ -26,7 +30,7 @@ __device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int
         }
         return;
     }
-    for (int idx = lane; idx < Tn * d; idx += 64) {
+    for (int idx = lane; idx < Tn * d; idx += ATT_THREADS) {
         const int i = idx / d, c = idx - i * d;
         dst[i * dp + c] = to_f32(src[(size_t)(b * Tn + i) * ld + h * d + c]);
     }
@@ -41,7 +45,7 @@ __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, in
     const bool vec = (d & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)out) & 15) == 0;
     if (vec) {
         const int d8 = d >> 3;
-        for (int idx = lane; idx < nOut * d8; idx += 64) {
+        for (int idx = lane; idx < nOut * d8; idx += ATT_THREADS) {
             const int o = idx / d8, c = (idx - o * d8) * 8;
             float acc[8];
 #pragma unroll
@@ -57,7 +61,7 @@ __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, in
         }
         return;
     }
-    for (int idx = lane; idx < nOut * d; idx += 64) {
+    for (int idx = lane; idx < nOut * d; idx += ATT_THREADS) {
         const int o = idx / d, c = idx - o * d;
         float acc = 0.f;
         for (int r = 0; r < nRed; ++r) acc += (TRANS ? Wt[r * tp + o] : Wt[o * tp + r]) * X[r * dp + c];
@@ -70,7 +74,7 @@ __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, in
 __device__ __forceinline__ void scores_softmax(const AttnArgs& a, int b, const float* Qs, const float* Ks, float* Pn,
                                                int lane) {
     const int dp = a.d + 1, tp = a.Tk + 1;
-    for (int idx = lane; idx < a.Tq * a.Tk; idx += 64) {
+    for (int idx = lane; idx < a.Tq * a.Tk; idx += ATT_THREADS) {
         const int i = idx / a.Tk, j = idx - i * a.Tk;
         float acc = 0.f;
         for (int c = 0; c < a.d; ++c) acc += Qs[i * dp + c] * Ks[j * dp + c];
@@ -96,7 +100,7 @@ __device__ __forceinline__ void scores_softmax(const AttnArgs& a, int b, const f
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
     if (a.drop_p > 0.f) {
         const uint32_t thresh = dropout_threshold(a.drop_p);
         const float ks = 1.f / (1.f - a.drop_p);
-        for (int idx = lane; idx < a.Tq * a.Tk; idx += 64) {
+        for (int idx = lane; idx < a.Tq * a.Tk; idx += ATT_THREADS) {
             const int i = idx / a.Tk, j = idx - i * a.Tk;
             const uint64_t e = ((uint64_t)blockIdx.x * a.Tq + i) * a.Tk + j;
             Pn[i * tp + j] = dropout_keep(a.seed, a.stream_id, e, thresh) ? Pn[i * tp + j] * ks : 0.f;
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(64) void attn_fwd_kernel(const AttnArgs a) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(64) void attn_bwd_kernel(const AttnArgs a) {
     scores_softmax(a, b, Qs, Ks, Pn, lane);
     const uint32_t thresh = dropout_threshold(a.drop_p);
     const float ks = (a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
-    for (int idx = lane; idx < a.Tq * a.Tk; idx += 64) {
+    for (int idx = lane; idx < a.Tq * a.Tk; idx += ATT_THREADS) {
         const int i = idx / a.Tk, j = idx - i * a.Tk;
         float g = 0.f;
         for (int c = 0; c < a.d; ++c) g += dOs[i * dp + c] * Vs[j * dp + c];
@@ -211,10 +215,10 @@ int blt_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
     const size_t lds = lds_bytes(a, false);
     if (dtype == BLT_F32) {
         if ((rc = set_lds(attn_fwd_kernel<float>, lds, "attn_fwd"))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(a.B * a.heads), dim3(64), lds, s, a);
+        hipLaunchKernelGGL(attn_fwd_kernel<float>, dim3(a.B * a.heads), dim3(ATT_THREADS), lds, s, a);
     } else {
         if ((rc = set_lds(attn_fwd_kernel<bf16>, lds, "attn_fwd"))) return rc;
-        hipLaunchKernelGGL(attn_fwd_kernel<bf16>, dim3(a.B * a.heads), dim3(64), lds, s, a);
+        hipLaunchKernelGGL(attn_fwd_kernel<bf16>, dim3(a.B * a.heads), dim3(ATT_THREADS), lds, s, a);
     }
     return blt_check_launch("attn_fwd");
 }
@@ -226,10 +230,10 @@ int blt_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s) {
     const size_t lds = lds_bytes(a, true);
     if (dtype == BLT_F32) {
         if ((rc = set_lds(attn_bwd_kernel<float>, lds, "attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(a.B * a.heads), dim3(64), lds, s, a);
+        hipLaunchKernelGGL(attn_bwd_kernel<float>, dim3(a.B * a.heads), dim3(ATT_THREADS), lds, s, a);
     } else {
         if ((rc = set_lds(attn_bwd_kernel<bf16>, lds, "attn_bwd"))) return rc;
-        hipLaunchKernelGGL(attn_bwd_kernel<bf16>, dim3(a.B * a.heads), dim3(64), lds, s, a);
+        hipLaunchKernelGGL(attn_bwd_kernel<bf16>, dim3(a.B * a.heads), dim3(ATT_THREADS), lds, s, a);
     }
     return blt_check_launch("attn_bwd");
 }

@@ -389,15 +389,13 @@ struct bltvqg_engine {
         const PInfo& p = tpi(wname);
         return mk(dY, ldy, 0, w, ldw, 1, dX, ldx, M, p.dims[1], p.dims[0]);
     }
-    // dW[N,K] = dY[M,N]^T X[M,K]  (fp32, into the flat gradient buffer) ; db[N] = colsum(dY)
+    // dW[N,K] += dY[M,N]^T X[M,K]  (fp32, into the flat gradient buffer) ; db[N] += colsum(dY)
     int wgrad(const void* dY, int ldy, const void* X, int ldx, const std::string& wname, const char* bias, int M, hipStream_t s) {
         const PInfo& p = tpi(wname);
         GemmArgs g = mk(dY, ldy, 1, X, ldx, 1, G(wname), p.dims[1], p.dims[0], p.dims[1], M);
         g.out_f32 = 1; g.split_k = 32;
-        int rc = blt_gemm(dt, g, s);
-        if (rc) return rc;
-        if (bias) rc = blt_colsum(dt, dY, ldy, M, p.dims[0], G(bias), 1, s);
-        return rc;
+        if (bias) g.a_rowsum = G(bias);       // bias gradient in the same launch
+        return blt_gemm(dt, g, s);
     }
 
     // dX = dY W with a vocabulary-sized contraction (K = V): few output tiles and a long K loop, so the K range is split over
@@ -644,10 +642,13 @@ struct bltvqg_engine {
         dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = tgt_shift;
         renc.x_in = (char*)X_all + (size_t)(Ma + Mt) * H * es; renc.key_ids = post32;
         if (use_streams) RC(fork(s0, s1, fj[1]));
+        // the CNN is the long pole (2 ms of the step) and its ~90 launches take the host ~0.3 ms to enqueue: it goes first when the
+        // side streams exist, so that the GPU is not left waiting for it behind the (short) encoder stacks' enqueue
+        if (use_streams) RC(cnn_fwd(images, s));
         RC(stack_fwd(enc, nullptr, nullptr, s1));
         // the reference runs r_encoder in both phases (encoder_transformer.py:23-25)
         RC(stack_fwd(renc, nullptr, nullptr, s0));
-        RC(cnn_fwd(images, s));
+        if (!use_streams) RC(cnn_fwd(images, s));
         if (use_streams) { RC(fork(s0, s, fj[2])); RC(fork(s1, s, fj[3])); }
         RC(blt_rows_add(dt, enc.out, (long)Sa * H, feats, H, nullptr, 0, B, H, 1, s));   // encoder_outputs[:,0] += image_features
         if (phase2) {
@@ -1119,9 +1120,7 @@ uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site) { retur
 
 int bltvqg_engine_profile_enable(bltvqg_engine* e, int on) {
     BLT_REQUIRE(e, "engine_profile_enable: null engine");
-    e->prof_on = on != 0;
-    e->prof_n = 0;
-    e->prof_flops = 0.0;
+    e->prof_on = on != 0;       // pause / resume: the recorded launches accumulate until bltvqg_engine_profile_read drains them
     return BLT_OK;
 }
 

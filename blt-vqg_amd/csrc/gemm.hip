@@ -52,7 +52,9 @@ struct Cfg {
     static constexpr int STAGE = A_BYTES + B_BYTES;
     static constexpr int CH_A = BM * 8 / 256, CH_B = BN * 8 / 256;
     static constexpr int CS = BN + 4;            // fp32 C-tile row stride (floats)
-    static constexpr int LDS_BYTES = (2 * STAGE > BM * CS * 4) ? 2 * STAGE : BM * CS * 4;
+    static constexpr int RS_OFF = BM * CS * 4;   // [4 waves][BM] fp32 row sums of op(A) (transA form), behind the C tile
+    static constexpr int EPI_BYTES = BM * CS * 4 + (TA ? 4 * BM * 4 : 0);
+    static constexpr int LDS_BYTES = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
 };
 
 // per-thread geometry of the rows a thread stages for the implicit-GEMM loaders
@@ -435,11 +437,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int l15 = lane & 15, lg = lane >> 4;
 
+    // Row sums of op(A) (the bias gradient of the weight-gradient form) fall out of the A staging registers: with an m-contiguous
+    // A every chunk a thread stages covers the SAME CE columns m0 + (tid % CPR)*CE.., so it keeps CE running sums; only the
+    // workgroups of the first column tile do it, once per K-slice.
+    constexpr int CPR_A = BM * ES / 16;
+    const bool do_rs = TA && p.a_rowsum != nullptr && tile_n == 0;
+    float rs[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) rs[e] = 0.f;
+    auto add_rs = [&](const uint4 (&ra)[C::CH_A]) {
+#pragma unroll
+        for (int i = 0; i < C::CH_A; ++i) {
+            const T* v = reinterpret_cast<const T*>(&ra[i]);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) rs[e] += to_f32(v[e]);
+        }
+    };
+
     if (kt0 < kt1) {
         uint4 ra[C::CH_A], rb[C::CH_B];
         load_a<C, T>(p, Ag, cr, m0, kt0 * BK, tid, ra);
         load_b<C, T>(p, Bg, n0, kt0 * BK, tid, rb);
         store_ab<C>(smem, smem + C::A_BYTES, tid, ra, rb);
+        if constexpr (TA) { if (do_rs) add_rs(ra); }
         __syncthreads();
         for (int kt = kt0; kt < kt1; ++kt) {
             const int cur = (kt - kt0) & 1;
@@ -451,8 +471,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 load_b<C, T>(p, Bg, n0, (kt + 1) * BK, tid, rb);
             }
             compute_tile<C, T>(a_cur, a_cur + C::A_BYTES, wm, wn, l15, lg, acc);
-            if (more) store_ab<C>(a_nxt, a_nxt + C::A_BYTES, tid, ra, rb);
+            if (more) {
+                store_ab<C>(a_nxt, a_nxt + C::A_BYTES, tid, ra, rb);
+                if constexpr (TA) { if (do_rs) add_rs(ra); }
+            }
             __syncthreads();
+        }
+    }
+    if constexpr (TA) {
+        if (do_rs) {
+            // lanes with equal (lane % CPR) hold the same columns: butterfly over the remaining lane bits, park the wave's sums behind
+            // the C tile; after the barrier below one thread per column adds the four waves and issues ONE atomic (device-scope
+            // float atomics on a single address serialise, so the count per address is what matters)
+#pragma unroll
+            for (int o = 32; o >= CPR_A; o >>= 1)
+#pragma unroll
+                for (int e = 0; e < CE; ++e) rs[e] += __shfl_xor(rs[e], o, 64);
+            float* Rs = reinterpret_cast<float*>(smem + C::RS_OFF);
+            if (lane < CPR_A) {
+#pragma unroll
+                for (int e = 0; e < CE; ++e) Rs[wave * BM + lane * CE + e] = rs[e];
+            }
         }
     }
 
@@ -466,6 +505,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 4; ++r)
                 Cs[(wm * C::WM + i * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[i][j][r];
     __syncthreads();
+
+    if constexpr (TA) {
+        if (do_rs && tid < BM && m0 + tid < p.M) {
+            const float* Rs = reinterpret_cast<const float*>(smem + C::RS_OFF);
+            atomicAdd(p.a_rowsum + m0 + tid, (Rs[tid] + Rs[BM + tid] + Rs[2 * BM + tid] + Rs[3 * BM + tid]) * p.alpha);
+        }
+    }
 
     gemm_epilogue<T, BM, BN>(p, Cs, tile_m, m0, n0, tid);
 }
@@ -490,11 +536,13 @@ __device__ __forceinline__ void dma16(const void* gsrc, char* lds_dst_wave_base)
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int LOADER>
+template <int BM, int BN, int LOADER, int NST_>
 struct DmaCfg {
-    // ring depth: 2 stages (one K-tile in flight per block) for the 128x128 tile so that TWO blocks fit a CU (68 KB each: the
-    // second block's MFMAs cover this block's DMA wait); 3 stages (two tiles in flight) for the smaller tiles
-    static constexpr int NST = (BM == 128 && BN == 128) ? 2 : 3;
+    // ring depth.  128x128 tile: 2 stages (one K-tile in flight per block) so that TWO blocks fit a CU (68 KB each: the second
+    // block's MFMAs cover this block's DMA wait) — unless the grid has no second block to give a CU (<= 256 tiles, e.g. the
+    // 7x7x512 convs: 196 tiles), where a lone block is bound by the DMA landing latency (~0.9 us per K-tile); it then takes 4
+    // stages (three tiles in flight, 128 KB).  Smaller tiles: 3 stages (two tiles in flight).
+    static constexpr int NST = NST_;
     static constexpr int BK = 64;
     static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -503,9 +551,17 @@ struct DmaCfg {
     static constexpr int LDS_BYTES = (NST * STAGE > BM * CS * 4) ? NST * STAGE : BM * CS * 4;
 };
 
-template <int BM, int BN, int LOADER>
+#ifdef BLT_STAMP
+__device__ unsigned long long g_stamps[1 << 16];      // [block][8] phase time stamps of the DMA kernel (experiment builds only)
+#define STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+template <int BM, int BN, int LOADER, int NST>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
-    typedef DmaCfg<BM, BN, LOADER> C;
+    typedef DmaCfg<BM, BN, LOADER, NST> C;
+    STAMP(0);
     constexpr int BK = C::BK, CS = C::CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -601,10 +657,18 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
 
     const int nk = (p.K + BK - 1) / BK;
     constexpr int AHEAD = C::NST - 1;                          // K-tiles kept in flight
+    constexpr int PER_TILE = C::CH_A + C::CH_B;                // DMA instructions per wave per K-tile (vmcnt units)
+    static_assert((AHEAD - 1) * PER_TILE <= 63, "vmcnt is a 6-bit counter");
+    STAMP(1);
     issue(0, 0);
     if (AHEAD > 1 && nk > 1) issue(1, 1);
+    if (AHEAD > 2 && nk > 2) issue(2, 2);
     for (int kt = 0; kt < nk; ++kt) {
-        if (AHEAD > 1 && kt + 1 < nk) wait_vmcnt<C::CH_A + C::CH_B>();   // tile kt landed (this wave's part); tile kt+1 may still fly
+        if (kt == 1) STAMP(2);
+        // this wave's part of tile kt has landed once at most min(AHEAD-1, tiles issued beyond kt) tiles are still in flight
+        const int beyond = (nk - 1 - kt < AHEAD - 1) ? nk - 1 - kt : AHEAD - 1;
+        if (AHEAD > 2 && beyond == 2) wait_vmcnt<2 * PER_TILE>();
+        else if (AHEAD > 1 && beyond >= 1) wait_vmcnt<PER_TILE>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                          // every wave's part of tile kt landed; stage (kt+AHEAD)%NST is free
         if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % C::NST);
@@ -630,6 +694,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
+    STAMP(3);
     __syncthreads();          // all MFMA reads of the ring are done before the C tile overwrites it
 
     float* Cs = reinterpret_cast<float*>(smem);
@@ -641,14 +706,21 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
             for (int r = 0; r < 4; ++r)
                 Cs[(wm * C::WM + i * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[i][j][r];
     __syncthreads();
+    STAMP(4);
     gemm_epilogue<bf16, BM, BN>(p, Cs, tile_m, m0, n0, tid);
+    STAMP(5);
 }
+#ifdef BLT_STAMP
+extern "C" int bltvqg_debug_read_stamps(unsigned long long* host, int n) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n) == hipSuccess ? 0 : -1;
+}
+#endif
 
-template <int BM, int BN, int LOADER>
+template <int BM, int BN, int LOADER, int NST>
 int launch_dma(const GemmArgs& a, hipStream_t stream) {
-    typedef DmaCfg<BM, BN, LOADER> C;
+    typedef DmaCfg<BM, BN, LOADER, NST> C;
     static bool attr_set = false;
-    auto kern = gemm_dma_kernel<BM, BN, LOADER>;
+    auto kern = gemm_dma_kernel<BM, BN, LOADER, NST>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
             blt_set_error("gemm: hipFuncSetAttribute(%d) failed", C::LDS_BYTES);
@@ -661,11 +733,11 @@ int launch_dma(const GemmArgs& a, hipStream_t stream) {
     return blt_check_launch("gemm_dma");
 }
 
-template <int BM, int BN>
+template <int BM, int BN, int NST>
 int dispatch_dma(const GemmArgs& a, hipStream_t s) {
-    if (a.is_conv == 2) return launch_dma<BM, BN, LD_STEM>(a, s);
-    if (a.is_conv) return launch_dma<BM, BN, LD_CONV>(a, s);
-    return launch_dma<BM, BN, LD_PLAIN>(a, s);
+    if (a.is_conv == 2) return launch_dma<BM, BN, LD_STEM, NST>(a, s);
+    if (a.is_conv) return launch_dma<BM, BN, LD_CONV, NST>(a, s);
+    return launch_dma<BM, BN, LD_PLAIN, NST>(a, s);
 }
 
 template <typename T, int BM, int BN, bool TA, bool TB, int LOADER>
@@ -704,7 +776,8 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 
 }  // namespace
 
-// process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode
+// process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode,
+// [3] = ring depth of the 128x128 DMA kernel (0 = by grid size, 1 = always 4 stages, 2 = always 2 stages)
 static int g_debug[4] = {0, 0, 0, 0};
 void blt_debug_set(int key, int value) { if (key >= 0 && key < 4) g_debug[key] = value; }
 
@@ -766,9 +839,14 @@ int blt_gemm_splits(const GemmArgs& a, int dtype) {
 static int run_choice(int dtype, const GemmArgs& a, const Choice& c, int splits, hipStream_t stream) {
     const bool dma_ok = (a.is_conv != 1) || (a.cg.Cin % 64 == 0);      // the DMA conv loader wants one filter tap per K-tile
     if (dtype == BLT_BF16 && !a.transA && !a.transB && splits == 1 && !c.no_dma && dma_ok) {
-        if (c.bm == 128 && c.bn == 128) return dispatch_dma<128, 128>(a, stream);
-        if (c.bm == 128 && c.bn == 64) return dispatch_dma<128, 64>(a, stream);
-        return dispatch_dma<64, 64>(a, stream);
+        if (c.bm == 128 && c.bn == 128) {
+            // one block per CU at most -> deep ring (see DmaCfg); debug key 3: 1 = always deep, 2 = never
+            const long tiles = (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+            const bool deep = g_debug[3] == 1 || (g_debug[3] != 2 && tiles <= 256);
+            return deep ? dispatch_dma<128, 128, 4>(a, stream) : dispatch_dma<128, 128, 2>(a, stream);
+        }
+        if (c.bm == 128 && c.bn == 64) return dispatch_dma<128, 64, 3>(a, stream);
+        return dispatch_dma<64, 64, 3>(a, stream);
     }
     if (dtype == BLT_BF16) return dispatch_tile<bf16>(a, c.bm, c.bn, splits, stream);
     return dispatch_tile<float>(a, c.bm, c.bn, splits, stream);
@@ -833,6 +911,7 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
     BLT_REQUIRE((!a.R || ((uintptr_t)a.R % 16) == 0) && (!a.maskY || ((uintptr_t)a.maskY % 16) == 0) && (!a.C2 || ((uintptr_t)a.C2 % 16) == 0) &&
                 (!a.rowtab || ((uintptr_t)a.rowtab % 16) == 0), "gemm: epilogue operands must be 16-byte aligned");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
+    BLT_REQUIRE(!a.a_rowsum || (a.transA && !a.is_conv), "gemm: a_rowsum needs the transA (weight-gradient) form");
     const int splits = blt_gemm_splits(a, dtype);
     if (g_debug[2] && splits == 1 && !a.accumulate && !a.force_tile && g_tuned.find(tune_key(a, dtype)) == g_tuned.end()) {
         int rc = autotune(dtype, a, stream);

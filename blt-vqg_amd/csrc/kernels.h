@@ -45,6 +45,7 @@ struct GemmArgs {
     int split_k = 0;             // max K-splits (fp32 atomic accumulation) for the weight-gradient form; 0 = off
     ConvGeom cg = {};
     int force_tile = 0;          // 0 = heuristic, 64 or 128
+    float* a_rowsum = nullptr;   // transA only: a_rowsum[m] += sum_k op(A)[m,k]  (bias gradient of the weight-gradient form, float atomics)
 };
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)

@@ -57,7 +57,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 }
 
 // Each wave walks rows with a grid stride, keeps its slice of dgamma/dbeta in registers and adds it to the
-// global fp32 gradient once at the end (one float atomic per column per wave).
+// global fp32 gradient once at the end (one float atomic per column per block).  Rows of <= 256 columns need only 32 lanes
+// (8 columns each), so a wave then carries TWO rows at once (`lpr` lanes per row) — the kernel is latency-bound, rows in flight
+// are what count.
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -66,21 +68,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                            float* __restrict__ dbeta, long rows, int cols) {
     const int lane = threadIdx.x & 63;
     const int nch = cols >> 3;
+    const int lpr = (nch <= 32) ? 32 : 64, rpw = 64 / lpr;
+    const int l = lane & (lpr - 1), sub = lane / lpr;
     float ag[LN_MAX_CHUNKS][8], ab[LN_MAX_CHUNKS][8], g[LN_MAX_CHUNKS][8];
 #pragma unroll
     for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
-        const int c = lane + 64 * j;
+        const int c = l + lpr * j;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; g[j][e] = 0.f; }
         if (c < nch) Vec8<float>::load(gamma + c * 8, g[j]);
     }
-    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+    for (long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub; row < rows; row += (long)gridDim.x * 4 * rpw) {
         const float mu = mean[row], rs = rstd[row];
         float xh[LN_MAX_CHUNKS][8], dxh[LN_MAX_CHUNKS][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
-            const int c = lane + 64 * j;
+            const int c = l + lpr * j;
             if (c < nch) {
                 float d[8];
                 Vec8<T>::load(dy + row * cols + c * 8, d);
@@ -96,10 +100,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 }
             }
         }
-        const float c1 = wave_sum(s1) / (float)cols, c2 = wave_sum(s2) / (float)cols;
+        for (int o = lpr >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+        const float c1 = s1 / (float)cols, c2 = s2 / (float)cols;
 #pragma unroll
         for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
-            const int c = lane + 64 * j;
+            const int c = l + lpr * j;
             if (c < nch) {
                 float o[8];
 #pragma unroll
@@ -114,11 +119,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             }
         }
     }
+    if (lpr == 32) {
+        // both half-waves hold partial sums of the same 256 columns (chunk group 0); after the exchange lanes >= 32 carry
+        // duplicates that land beyond `cols` in the pass below and are dropped there
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ag[0][e] += __shfl_xor(ag[0][e], 32, 64); ab[0][e] += __shfl_xor(ab[0][e], 32, 64); }
+    }
     // combine the 4 waves of the block through LDS, then one atomic per column per block
     __shared__ float red[4][LN_MAX_CHUNKS * 64 * 8 / 4];   // reused in two passes (gamma then beta), 512 cols per pass
     const int w = threadIdx.x >> 6;
     for (int pass = 0; pass < 2; ++pass) {
         for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+            if (64 * 8 * j >= cols) break;
             __syncthreads();
 #pragma unroll
             for (int e = 0; e < 8; ++e) red[w][lane * 8 + e] = pass == 0 ? ag[j][e] : ab[j][e];
@@ -138,6 +150,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 // ---------------------------------------------------------------------------------------------------------------
 // BatchNorm2d, train mode.  Stage 1 reduces the GEMM's per-half-tile partial sums (fp32) into `S` slices in fp64;
 // stage 2 finishes per channel and applies the reference's running-statistics update (momentum 0.1, unbiased var).
+// (A single-launch variant with a device-scope ticket counter was measured 2.4x SLOWER: the release fence writes back the whole
+// XCD L2, which is full of freshly written conv output at that point.)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ psum, const float* __restrict__ psq,
                                                        int nparts, int C, double* __restrict__ tmp /* [S][2][C] */) {
@@ -377,8 +391,9 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_bwd: bad dtype");
     BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_bwd: bad cols=%d", cols);
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
-    int grid = cdiv(rows, 16);     // ~4 rows per wave: fewer per-block reductions / float atomics for dgamma, dbeta
-    if (grid > 256) grid = 256;
+    const int rpw = (cols <= 256) ? 2 : 1;      // rows a wave carries at once
+    int grid = cdiv(rows, 4 * rpw * 2);          // ~2 row-iterations per wave: latency-bound, yet few enough blocks for the dgamma/dbeta atomics
+    if (grid > 512) grid = 512;
     if (grid < 1) grid = 1;
     DISPATCH_T(dtype,
                hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols),

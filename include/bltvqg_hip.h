@@ -51,6 +51,12 @@ int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, in
                 const void* maskY, int ldm, float mask_scale, const void* R, int ldr, int accumulate, int out_f32,
                 int force_tile, int split_k, void* stream);
 
+/* Backward of y = x W^T + b w.r.t. the parameters (autograd of nn.Linear, transformer_layers.py:453-456,400-408):
+ * dW[N,K] += dY[rows,N]^T X[rows,K] and, when dbias is non-null, dbias[N] += column sums of dY — both fp32, in ONE launch (the bias
+ * gradient falls out of the staging registers of the dY operand).  split_k > 0: up to that many slices of `rows`, fp32 atomics. */
+int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* dbias, int rows,
+                        int N, int K, int split_k, void* stream);
+
 /* NHWC implicit-GEMM convolution y[N,Ho,Wo,Cout] = conv(x[N,Hi,Wi,Cin], w[Cout,KH,KW,Cin]); Cin a power of two >= 8 (bf16)
  * / 4 (fp32).  stat_sum/stat_sq (optional): per-half-tile column partial sums, bltvqg_conv2d_stat_rows() rows of Cout. */
 int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
@@ -73,6 +79,7 @@ int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const flo
 int bltvqg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, void* stream);
 
+/* `scratch` holds bltvqg_bn_scratch_doubles(C) doubles (slice sums of the two-stage fp64 reduction; contents need not be initialised) */
 int bltvqg_bn_scratch_doubles(int C);
 int bltvqg_bn_finalize(const float* psum, const float* psq, int nparts, int C, int64_t count, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,
@@ -187,7 +194,8 @@ uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site);
 /* In-stream timing of the dominant kernel (the implicit-GEMM convolution launches of the frozen ResNet-18 stack): while enabled,
  * every conv launch is bracketed by a hipEvent pair on the caller's stream.  profile_read synchronises on those events and
  * returns the summed kernel time, the number of launches and their ALGORITHMIC flops (2*M*Cout*KH*KW*Cin, unpadded) since
- * the last read. */
+ * the last read.  enable(0) only pauses recording (an event record costs the stream a ~6 us bubble, so callers sample a
+ * subset of their steps); the recorded launches accumulate until profile_read drains them. */
 int bltvqg_engine_profile_enable(bltvqg_engine* e, int on);
 int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host);
 /* gradient buckets for data-parallel overlap: contiguous float ranges of the flat gradient buffer in the order backward

@@ -100,6 +100,31 @@ def test_gemm_split_k_weight_gradient(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("split_k", [0, 32])
+@pytest.mark.parametrize("shape", [(256, 256, 2688), (96, 300, 1000), (1024, 256, 2688), (8, 64, 37)])
+def test_linear_wgrad_with_bias_gradient(dtype, split_k, shape):
+    """nn.Linear parameter gradients in one launch: dW += dY^T X and db += colsum(dY) (from the dY staging registers); exact on
+    integers, for the 64- and 128-row tiles, ragged N / rows, with and without split-K."""
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, ptr, stream_ptr, load
+    Nout, Kin, Mtok = shape
+    ce = 8 if dtype == torch.bfloat16 else 4
+    pad = lambda n: (n + ce - 1) // ce * ce           # noqa: E731
+    g = torch.Generator().manual_seed(Mtok + Nout)
+    dY = torch.zeros(Mtok, pad(Nout)); dY[:, :Nout] = _ints((Mtok, Nout), -2, 2, g, torch.float32)
+    X = torch.zeros(Mtok, pad(Kin)); X[:, :Kin] = _ints((Mtok, Kin), -2, 2, g, torch.float32)
+    W0 = _ints((Nout, Kin), -3, 3, g, torch.float32)
+    b0 = _ints((Nout,), -3, 3, g, torch.float32)
+    dW, db = W0.clone().cuda(), b0.clone().cuda()
+    dYd, Xd = dY.to(dtype).cuda(), X.to(dtype).cuda()
+    check(load().bltvqg_linear_wgrad(G.DT[dtype], ptr(dYd), dYd.stride(0), ptr(Xd), Xd.stride(0), ptr(dW), Kin, ptr(db), Mtok, Nout, Kin,
+                                     split_k, stream_ptr()), "linear_wgrad")
+    torch.cuda.synchronize()
+    assert torch.equal(dW.cpu().double(), dY[:, :Nout].double().t() @ X[:, :Kin].double() + W0.double())
+    assert torch.equal(db.cpu().double(), dY[:, :Nout].double().sum(0) + b0.double())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_random_accuracy(dtype):
     import gpu_ops as G
     M, N, K = 512, 384, 512
@@ -181,7 +206,7 @@ def test_batchnorm2d_train_pipeline(dtype):
     psq = torch.stack([(p * p).sum(0) for p in parts]).contiguous()
     scale = torch.empty(C, device="cuda"); shift = torch.empty(C, device="cuda")
     rmd, rvd = rm.cuda(), rv.cuda()
-    scratch = torch.empty(lib.bltvqg_bn_scratch_doubles(C), dtype=torch.float64, device="cuda")
+    scratch = torch.zeros(lib.bltvqg_bn_scratch_doubles(C), dtype=torch.float64, device="cuda")   # ticket counters start at zero
     check(lib.bltvqg_bn_finalize(ptr(psum), ptr(psq), nparts, C, xf.shape[0], ptr(gamma.cuda()), ptr(beta.cuda()), 1e-5, 0.1, ptr(rmd), ptr(rvd),
                                  ptr(scale), ptr(shift), ptr(scratch), stream_ptr()), "bn_finalize")
     tol = 1e-4 if dtype == torch.float32 else 3e-2

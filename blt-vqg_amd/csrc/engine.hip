@@ -38,6 +38,11 @@ struct Layer {   // saved activations of one transformer layer
     // decoder only
     void *q2, *kv2, *ctx2, *x1b, *xn3;
     float *m3, *r3;
+    // backward: gradients that are OPERANDS of a (deferred) weight-gradient GEMM live in buffers of their own, never reused inside one
+    // backward pass, so that those GEMMs can run on a side stream while the main stream walks on down the chain:
+    // gY = d(FFN output before the residual), gF = d(FFN hidden), gQKV = d(q|k|v), dx1..3 = d(sub-layer outputs), and for the
+    // decoder gQ = d(enc-dec query), gKV = d(enc-dec key|value)
+    void *gY, *gF, *gQKV, *dx1, *dx2, *dx3, *gQ, *gKV;
 };
 
 struct Stack {
@@ -77,6 +82,12 @@ struct bltvqg_engine {
     int last_bwd_phase2 = 0;
     // workspace buffers
     void* wshadow = nullptr;    // bf16 mirror of the flat trainable buffer (bf16 mode)
+    void* wshadowT = nullptr;   // same offsets, every dgrad operand stored TRANSPOSED ([K,N], ld N): dX = dY W becomes an NT GEMM
+    struct TEnt { int off, rows, cols, tile0; };
+    std::vector<TEnt> tlist;    // matrices with a transposed shadow (fused q|k|v and k|v groups are one matrix)
+    std::map<int64_t, int> trows;   // element offset -> rows of the transposed matrix registered there
+    void* ttable = nullptr;     // device copy of tlist
+    int ttiles = 0;
     void* wemb_pad = nullptr;   // padded shadow of embedding.1.weight when E % chunk != 0
     int ld_wemb = 0;
     float* timing = nullptr;
@@ -95,14 +106,21 @@ struct bltvqg_engine {
     void *r_in, *hrec, *recon;
     float* eps_dev;
     // gradient scratch
-    void *sA[2], *sB[2], *sC[2], *sF[2], *sQKV[2];   // gradient scratch sets: [0] main stream, [1] posterior-encoder stream
-    void *gKV, *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
+    void *sA[2], *sB[2], *sC[2];   // short-lived gradient scratch (consumed by the next launch): [0] main stream, [1] posterior-encoder stream
+    float* acc_big;                // fp32 accumulator of the split-K vocabulary dgrad
+    void *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
     void *g_b1, *g_b2, *g_b3, *g_b4, *g_cat, *g_mq;   // small [B, *] scratch
     hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
     // side streams: independent sub-graphs (CNN | posterior encoder | context encoder) run concurrently so that their small
     // launches (40-160 workgroups each) fill the 256 CUs together; fork/join with events (capturable into a hipGraph)
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t fj[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // side[2], side[3]: weight-gradient streams (see flush_wgrads)
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fj[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    // weight-gradient GEMMs of the transformer stacks are off the critical path of backward (nothing downstream reads dW): they are
+    // collected while a stack's input-gradient chain is enqueued and then issued on a side stream, where they fill the CUs that the
+    // chain's small latency-bound launches leave idle
+    std::vector<GemmArgs> pending_wgrads;
+    bool defer_wgrads = false;
     bool use_streams = true;
     int causal_mode = 1;       // 1 = training mask (pad OR future -> -1e18), 2 = prefix decoding (future keys excluded)
     bool bn_train = true;      // false: BatchNorm layers use their running statistics (module.eval(), greedy decoding)
@@ -213,6 +231,22 @@ struct bltvqg_engine {
         add_enc_stack("answer_encoder.r_encoder", 1);
         bucket_off[2] = late_off; bucket_len[2] = tsize - late_off; bucket_late[2] = 1;
 
+        // ---- transposed-shadow table: every weight that appears as the B operand of an input-gradient GEMM ----
+        auto ends_with = [](const std::string& a, const char* suf) { const size_t n = strlen(suf); return a.size() >= n && a.compare(a.size() - n, n, suf) == 0; };
+        for (const PInfo& p : tp) {
+            if (p.ndim != 2 || p.name == "embedding.0.weight" || p.name == "encoder_cnn.cnn.fc.weight") continue;
+            int rows = p.dims[0];
+            const bool encdec = p.name.find("multi_head_attention_enc_dec.") != std::string::npos;
+            if (ends_with(p.name, "value_linear.weight")) continue;                       // part of a fused group
+            if (ends_with(p.name, "key_linear.weight")) { if (!encdec) continue; rows = 2 * H; }      // enc-dec k|v
+            if (ends_with(p.name, "query_linear.weight") && !encdec) rows = 3 * H;          // self-attention q|k|v
+            if (rows % 8 != 0) continue;                                                   // ld of the transposed operand must be 16-byte aligned
+            TEnt t; t.off = (int)p.off; t.rows = rows; t.cols = p.dims[1]; t.tile0 = ttiles;
+            ttiles += ((rows + 63) / 64) * ((p.dims[1] + 63) / 64);
+            tlist.push_back(t);
+            trows[p.off] = rows;
+        }
+
         // ---- frozen backbone (torchvision resnet18 names, encoder_cnn.py:17) + running statistics ----
         auto add_bn = [&](const std::string& n, int C) {
             add_f(n + ".weight", C, 0, 0, 0, 1);
@@ -266,6 +300,8 @@ struct bltvqg_engine {
         auto AF = [&](int64_t n) -> float* { return (float*)A(n * 4); };
         auto AI = [&](int64_t n) -> int* { return (int*)A(n * 4); };
         wshadow = (dt == BLT_BF16) ? A(tsize * 2) : nullptr;
+        wshadowT = (dt == BLT_BF16) ? A(tsize * 2) : nullptr;
+        ttable = (dt == BLT_BF16) ? A((int64_t)tlist.size() * 16) : nullptr;
         const int ce = 16 / es;
         ld_wemb = round_up(E, ce);
         wemb_pad = (E % ce != 0) ? AT((int64_t)H * ld_wemb) : nullptr;
@@ -306,9 +342,12 @@ struct bltvqg_engine {
                 y.xn1 = AT(M * H); y.qkv = AT(M * 3 * H); y.ctx = AT(M * H); y.x1 = AT(M * H); y.xn2 = AT(M * H);
                 y.h = AT(M * F); y.y2 = AT(M * H); y.x2 = AT(M * H);
                 y.m1 = AF(M); y.r1 = AF(M); y.m2 = AF(M); y.r2 = AF(M);
+                y.gY = AT(M * H); y.gF = AT(M * F); y.gQKV = AT(M * 3 * H); y.dx1 = AT(M * H); y.dx2 = AT(M * H); y.dx3 = nullptr;
+                y.gQ = nullptr; y.gKV = nullptr;
                 if (s.dec) {
                     y.q2 = AT(M * H); y.kv2 = AT((int64_t)Ma * 2 * H); y.ctx2 = AT(M * H); y.x1b = AT(M * H); y.xn3 = AT(M * H);
                     y.m3 = AF(M); y.r3 = AF(M);
+                    y.dx3 = AT(M * H); y.gQ = AT(M * H); y.gKV = AT((int64_t)Ma * 2 * H);
                 }
             }
             s.out = AT((int64_t)s.M * H);
@@ -324,8 +363,8 @@ struct bltvqg_engine {
         r_in = AT((int64_t)B * H); hrec = AT((int64_t)B * F); recon = AT((int64_t)B * H);
         // gradient scratch
         const int64_t Mmax = (Mp > Mt ? Mp : Mt);
-        for (int k = 0; k < 2; ++k) { sA[k] = AT(Mmax * H); sB[k] = AT(Mmax * H); sC[k] = AT(Mmax * H); sF[k] = AT(Mmax * F); sQKV[k] = AT(Mmax * 3 * H); }
-        gKV = AT((int64_t)Ma * 2 * H);
+        for (int k = 0; k < 2; ++k) { sA[k] = AT(Mmax * H); sB[k] = AT(Mmax * H); sC[k] = AT(Mmax * H); }
+        acc_big = AF(Mmax * H);
         d_enc = AT((int64_t)Ma * H); d_renc = AT((int64_t)Mp * H);
         dX_all = AT((int64_t)Mtot * H); dE = AT((int64_t)Mtot * Epad);
         d_feats = AT((int64_t)B * H); d_zproj = AT((int64_t)B * H); d_recon = AT((int64_t)B * H); dzl = AT((int64_t)B * ldV);
@@ -382,12 +421,24 @@ struct bltvqg_engine {
         if (bias) g.bias = P(bias);
         return g;
     }
-    // dX[M,K] = dY[M,N] W[N,K]
-    GemmArgs dgrad(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M) {
+    // transposed shadow of the [rows, K] matrix that starts at wname (rows > dims[0] for the fused q|k|v / k|v groups), or null
+    const void* WT(const std::string& wname, int rows) const {
+        if (dt != BLT_BF16) return nullptr;
+        const PInfo& p = tpi(wname);
+        auto it = trows.find(p.off);
+        if (it == trows.end() || it->second != rows) return nullptr;
+        return (const char*)wshadowT + p.off * 2;
+    }
+    // dX[M,K] = dY[M,N] W[N,K]: through the transposed shadow (k-contiguous B -> LDS-DMA kernel) when there is one
+    GemmArgs dgrad_rows(const void* dY, int ldy, const std::string& wname, int rows, void* dX, int ldx, int M) {
+        const PInfo& p = tpi(wname);
+        if (const void* wt = WT(wname, rows)) return mk(dY, ldy, 0, wt, rows, 0, dX, ldx, M, p.dims[1], rows);
         int ldw;
         const void* w = W(wname, &ldw);
-        const PInfo& p = tpi(wname);
-        return mk(dY, ldy, 0, w, ldw, 1, dX, ldx, M, p.dims[1], p.dims[0]);
+        return mk(dY, ldy, 0, w, ldw, 1, dX, ldx, M, p.dims[1], rows);
+    }
+    GemmArgs dgrad(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M) {
+        return dgrad_rows(dY, ldy, wname, tpi(wname).dims[0], dX, ldx, M);
     }
     // dW[N,K] += dY[M,N]^T X[M,K]  (fp32, into the flat gradient buffer) ; db[N] += colsum(dY)
     int wgrad(const void* dY, int ldy, const void* X, int ldx, const std::string& wname, const char* bias, int M, hipStream_t s) {
@@ -397,14 +448,40 @@ struct bltvqg_engine {
         if (bias) g.a_rowsum = G(bias);       // bias gradient in the same launch
         return blt_gemm(dt, g, s);
     }
+    // same, but deferred to the weight-gradient stream when the caller's operands are stable (stack_bwd)
+    int wgrad_later(const GemmArgs& g, hipStream_t s) {
+        if (defer_wgrads) { pending_wgrads.push_back(g); return BLT_OK; }
+        return blt_gemm(dt, g, s);
+    }
+    int wgrad_later(const void* dY, int ldy, const void* X, int ldx, const std::string& wname, const char* bias, int M, hipStream_t s) {
+        const PInfo& p = tpi(wname);
+        GemmArgs g = mk(dY, ldy, 1, X, ldx, 1, G(wname), p.dims[1], p.dims[0], p.dims[1], M);
+        g.out_f32 = 1; g.split_k = 32;
+        if (bias) g.a_rowsum = G(bias);
+        return wgrad_later(g, s);
+    }
+    // issue the collected weight-gradient GEMMs on `to`, ordered after everything enqueued on `from` so far
+    int flush_wgrads(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+        if (pending_wgrads.empty()) return BLT_OK;
+        int rc = fork(from, to, ev);
+        for (size_t i = 0; i < pending_wgrads.size() && !rc; ++i) rc = blt_gemm(dt, pending_wgrads[i], to);
+        pending_wgrads.clear();
+        return rc;
+    }
 
     // dX = dY W with a vocabulary-sized contraction (K = V): few output tiles and a long K loop, so the K range is split over
     // workgroups into an fp32 scratch (atomics) and cast back; falls through to the plain kernel in fp32 mode / small V
     int dgrad_bigk(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M, hipStream_t s) {
-        GemmArgs g = dgrad(dY, ldy, wname, dX, ldx, M);
-        if (dt != BLT_BF16 || g.K < 2048) return blt_gemm(dt, g, s);
-        float* acc = (float*)sF[0];                          // >= Mmax*F*2 bytes >= M*H*4 because F >= 2H
-        if ((size_t)M * g.N * 4 > (size_t)(Mp > Mt ? Mp : Mt) * F * es) return blt_gemm(dt, g, s);
+        if (dt != BLT_BF16 || tpi(wname).dims[0] < 2048) return blt_gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
+        GemmArgs g;
+        {   // n-contiguous B (the plain shadow): the split-K path lives in the register-staged kernel
+            int ldw;
+            const void* w = W(wname, &ldw);
+            const PInfo& p = tpi(wname);
+            g = mk(dY, ldy, 0, w, ldw, 1, dX, ldx, M, p.dims[1], p.dims[0]);
+        }
+        float* acc = acc_big;
+        if ((size_t)M * g.N > (size_t)(Mp > Mt ? Mp : Mt) * H) return blt_gemm(dt, g, s);
         if (hipMemsetAsync(acc, 0, (size_t)M * g.N * 4, s) != hipSuccess) { blt_set_error("dgrad_bigk: memset failed"); return BLT_ERR_HIP; }
         g.C = acc; g.ldc = g.N; g.out_f32 = 1; g.split_k = 16;
         { const int rc_ = blt_gemm(dt, g, s); if (rc_) return rc_; }
@@ -620,7 +697,10 @@ struct bltvqg_engine {
         phase2 = p2; seed = seed_; fwd_done = false;
         if (hipMemsetAsync(stats, 0, 8 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
         // weight shadows
-        if (dt == BLT_BF16) RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
+        if (dt == BLT_BF16) {
+            RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
+            if (!tlist.empty()) RC(blt_shadow_transpose(train, nullptr, wshadowT, ttable, (int)tlist.size(), ttiles, s));
+        }
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
                            tgt32, ctx32, post32, counters, s));
@@ -745,23 +825,27 @@ struct bltvqg_engine {
     // ---------------------------------------------------------------------------------------------
     // backward pieces.  `dx` holds the gradient w.r.t. the layer OUTPUT on entry and w.r.t. its INPUT on exit.
     // ---------------------------------------------------------------------------------------------
+    // dx_in = d(sub-layer output); dx_out = d(sub-layer input) = LayerNorm backward of the FFN branch + dx_in (residual)
     int ffn_bwd(const std::string& fp_, const void* xn, const void* xres, const float* m, const float* r, const std::string& ln,
-                Layer& y, void* dx, int M, int k, hipStream_t s) {
-        void *gA = sA[k], *gB = sB[k], *gF = sF[k];
+                Layer& y, const void* dx_in, void* dx_out, int M, int k, hipStream_t s) {
+        void* gB = sB[k];
         const float ks = (c.relu_dropout > 0.f) ? 1.f / (1.f - c.relu_dropout) : 1.f;
-        RC(blt_mask_scale(dt, dx, y.y2, gA, (long)M * H, ks, s));
-        RC(wgrad(gA, H, y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), M, s));
-        GemmArgs g = dgrad(gA, H, fp_ + "layers.1.weight", gF, F, M);
+        RC(blt_mask_scale(dt, dx_in, y.y2, y.gY, (long)M * H, ks, s));
+        RC(wgrad_later(y.gY, H, y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), M, s));
+        GemmArgs g = dgrad(y.gY, H, fp_ + "layers.1.weight", y.gF, F, M);
         g.maskY = y.h; g.ldm = F; g.mask_scale = ks;
         RC(blt_gemm(dt, g, s));
-        RC(wgrad(gF, F, xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), M, s));
-        RC(blt_gemm(dt, dgrad(gF, F, fp_ + "layers.0.weight", gB, H, M), s));
-        return blt_layernorm_bwd(dt, gB, xres, P(ln + ".weight"), m, r, dx, dx, G(ln + ".weight"), G(ln + ".bias"), M, H, s);
+        RC(wgrad_later(y.gF, F, xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), M, s));
+        RC(blt_gemm(dt, dgrad(y.gF, F, fp_ + "layers.0.weight", gB, H, M), s));
+        return blt_layernorm_bwd(dt, gB, xres, P(ln + ".weight"), m, r, dx_in, dx_out, G(ln + ".weight"), G(ln + ".bias"), M, H, s);
     }
 
+    // `dx` holds d(stack output before the final LayerNorm) on entry and d(stack input) on exit; the gradients in between live in the
+    // layers' own buffers (Layer::dx1..3)
     int stack_bwd(Stack& st, void* dx, const void* enc_out, const int* src_ids, hipStream_t s) {
         const int M = st.M, S = st.S;
-        void *gA = sA[st.scr], *gB = sB[st.scr], *gC = sC[st.scr], *gQKV = sQKV[st.scr];
+        void *gA = sA[st.scr], *gB = sB[st.scr], *gC = sC[st.scr];
+        const void* cur = dx;
         for (int l = L - 1; l >= 0; --l) {
             Layer& y = st.layers[l];
             const void* x = (l == 0) ? st.x_in : st.layers[l - 1].x2;
@@ -769,46 +853,49 @@ struct bltvqg_engine {
             const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
             const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
             if (st.dec) {
-                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, dx, M, st.scr, s));
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, cur, y.dx1, M, st.scr, s));
+                cur = y.dx1;
                 // encoder-decoder attention
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
-                RC(wgrad(dx, H, y.ctx2, H, a2 + "output_linear.weight", nullptr, M, s));
-                RC(blt_gemm(dt, dgrad(dx, H, a2 + "output_linear.weight", gA, H, M), s));
-                RC(attn_bwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, gA, gB, H, gKV, (char*)gKV + (size_t)H * es, 2 * H, src_ids, S,
-                            Sa, 0, sid(st.id, l, 3), s));
-                RC(wgrad(gB, H, y.xn2, H, a2 + "query_linear.weight", nullptr, M, s));
-                RC(blt_gemm(dt, dgrad(gB, H, a2 + "query_linear.weight", gC, H, M), s));
+                RC(wgrad_later(cur, H, y.ctx2, H, a2 + "output_linear.weight", nullptr, M, s));
+                RC(blt_gemm(dt, dgrad(cur, H, a2 + "output_linear.weight", gA, H, M), s));
+                RC(attn_bwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, gA, y.gQ, H, y.gKV, (char*)y.gKV + (size_t)H * es, 2 * H, src_ids,
+                            S, Sa, 0, sid(st.id, l, 3), s));
+                RC(wgrad_later(y.gQ, H, y.xn2, H, a2 + "query_linear.weight", nullptr, M, s));
+                RC(blt_gemm(dt, dgrad(y.gQ, H, a2 + "query_linear.weight", gC, H, M), s));
                 {   // key/value projections of encoder_outputs: [2H,H] fused
                     const PInfo& pk = tpi(a2 + "key_linear.weight");
-                    GemmArgs g = mk(gKV, 2 * H, 1, enc_out, H, 1, grad + pk.off, H, 2 * H, H, Ma);
+                    GemmArgs g = mk(y.gKV, 2 * H, 1, enc_out, H, 1, grad + pk.off, H, 2 * H, H, Ma);
                     g.out_f32 = 1; g.split_k = 32;
-                    RC(blt_gemm(dt, g, s));
-                    int ldw;
-                    const void* w = W(a2 + "key_linear.weight", &ldw);
-                    g = mk(gKV, 2 * H, 0, w, ldw, 1, d_enc, H, Ma, H, 2 * H);
+                    RC(wgrad_later(g, s));
+                    g = dgrad_rows(y.gKV, 2 * H, a2 + "key_linear.weight", 2 * H, d_enc, H, Ma);
                     g.accumulate = (l == L - 1) ? 0 : 1;
                     RC(blt_gemm(dt, g, s));
                 }
                 const std::string ln2 = lp + "layer_norm_mha_enc";
-                RC(blt_layernorm_bwd(dt, gC, y.x1, P(ln2 + ".weight"), y.m2, y.r2, dx, dx, G(ln2 + ".weight"), G(ln2 + ".bias"), M, H, s));
+                RC(blt_layernorm_bwd(dt, gC, y.x1, P(ln2 + ".weight"), y.m2, y.r2, cur, y.dx2, G(ln2 + ".weight"), G(ln2 + ".bias"), M, H, s));
+                cur = y.dx2;
             } else {
-                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, dx, M, st.scr, s));
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, cur, y.dx1, M, st.scr, s));
+                cur = y.dx1;
             }
             // self attention
-            RC(wgrad(dx, H, y.ctx, H, a1 + "output_linear.weight", nullptr, M, s));
-            RC(blt_gemm(dt, dgrad(dx, H, a1 + "output_linear.weight", gA, H, M), s));
-            RC(attn_bwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, gA, gQKV, 3 * H,
-                        (char*)gQKV + (size_t)H * es, (char*)gQKV + (size_t)2 * H * es, 3 * H, st.key_ids, S, S, st.dec ? 1 : 0, sid(st.id, l, 0), s));
+            RC(wgrad_later(cur, H, y.ctx, H, a1 + "output_linear.weight", nullptr, M, s));
+            RC(blt_gemm(dt, dgrad(cur, H, a1 + "output_linear.weight", gA, H, M), s));
+            RC(attn_bwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, gA, y.gQKV, 3 * H,
+                        (char*)y.gQKV + (size_t)H * es, (char*)y.gQKV + (size_t)2 * H * es, 3 * H, st.key_ids, S, S, st.dec ? 1 : 0, sid(st.id, l, 0), s));
             {
                 const PInfo& pq = tpi(a1 + "query_linear.weight");
-                GemmArgs g = mk(gQKV, 3 * H, 1, y.xn1, H, 1, grad + pq.off, H, 3 * H, H, M);
+                GemmArgs g = mk(y.gQKV, 3 * H, 1, y.xn1, H, 1, grad + pq.off, H, 3 * H, H, M);
                 g.out_f32 = 1; g.split_k = 32;
-                RC(blt_gemm(dt, g, s));
-                int ldw;
-                const void* w = W(a1 + "query_linear.weight", &ldw);
-                RC(blt_gemm(dt, mk(gQKV, 3 * H, 0, w, ldw, 1, gB, H, M, H, 3 * H), s));
+                RC(wgrad_later(g, s));
+                RC(blt_gemm(dt, dgrad_rows(y.gQKV, 3 * H, a1 + "query_linear.weight", 3 * H, gB, H, M), s));
             }
-            RC(blt_layernorm_bwd(dt, gB, x, P(ln1 + ".weight"), y.m1, y.r1, dx, dx, G(ln1 + ".weight"), G(ln1 + ".bias"), M, H, s));
+            // the last sub-layer of the stack writes d(stack input) back into the caller's buffer (its old content is dead by now:
+            // only the top layer's FFN branch read it, on this same stream)
+            void* out = (l == 0) ? dx : (st.dec ? y.dx3 : y.dx2);
+            RC(blt_layernorm_bwd(dt, gB, x, P(ln1 + ".weight"), y.m1, y.r1, cur, out, G(ln1 + ".weight"), G(ln1 + ".bias"), M, H, s));
+            cur = out;
         }
         return BLT_OK;
     }
@@ -816,6 +903,8 @@ struct bltvqg_engine {
     // Everything downstream of the loss-gradient seeds: `logits` holds d(output), dzl holds d(z_logit) (phase 2),
     // d_feats holds the direct gradient of image_features, d_recon that of the reconstruction.
     int backward_core(float kld_g, hipStream_t s) {
+        pending_wgrads.clear();
+        defer_wgrads = false;
         // ---- vocabulary projection + decoder ----
         RC(wgrad(logits, ldV, dec.out, H, "decoder.output.weight", "decoder.output.bias", Mt, s));
         void* gA = sA[0];
@@ -826,8 +915,12 @@ struct bltvqg_engine {
             RC(blt_layernorm_bwd(dt, gA, xL, P("decoder.decoder.layer_norm.weight"), dec.mF, dec.rF, nullptr, dxT,
                                  G("decoder.decoder.layer_norm.weight"), G("decoder.decoder.layer_norm.bias"), Mt, H, s));
         }
+        defer_wgrads = use_streams;
         RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
-        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], s);
+        // the decoder's weight gradients run on side[2] from here on, under the rest of backward; bucket 0 (decoder.*) is complete when
+        // that stream gets here
+        RC(flush_wgrads(s, side[2], fj[6]));
+        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], use_streams ? side[2] : s);
         // target_embedding[:,0] += image_features (+ z)
         RC(blt_rows_add(dt, d_feats, H, dxT, (long)T * H, nullptr, 0, B, H, 1, s));
         if (phase2) RC(blt_rows_add(dt, d_zproj, H, dxT, (long)T * H, nullptr, 0, B, H, 0, s));
@@ -873,6 +966,7 @@ struct bltvqg_engine {
             RC(blt_layernorm_bwd(dt, d_renc, xL, P("answer_encoder.r_encoder.layer_norm.weight"), renc.mF, renc.rF, nullptr, dxP,
                                  G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s0));
             RC(stack_bwd(renc, dxP, nullptr, nullptr, s0));
+            RC(flush_wgrads(s0, side[3], fj[7]));
             Memb = Mtot;
         }
         // ---- context encoder (main stream) ----
@@ -882,6 +976,8 @@ struct bltvqg_engine {
                                  G("answer_encoder.encoder.layer_norm.weight"), G("answer_encoder.encoder.layer_norm.bias"), Ma, H, s));
         }
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
+        RC(flush_wgrads(s, side[2], fj[8]));
+        defer_wgrads = false;
         if (s0 != s) RC(fork(s0, s, fj[5]));
         // ---- shared embedding (rows of the streams that received gradient) ----
         {
@@ -904,6 +1000,10 @@ struct bltvqg_engine {
             GemmArgs g = mk(dfeatpre32, H, 1, pooled, 512, 1, grad + pw.off, 512, H, 512, B);
             RC(blt_gemm(BLT_F32, g, s));
             RC(blt_colsum(BLT_F32, dfeatpre32, H, B, H, G("encoder_cnn.cnn.fc.bias"), 1, s));
+        }
+        if (use_streams) {      // join the weight-gradient streams
+            RC(fork(side[2], s, fj[9]));
+            if (phase2) RC(fork(side[3], s, fj[10]));
         }
         if (bucket_ev[1]) (void)hipEventRecord(bucket_ev[1], s);
         if (bucket_ev[2]) (void)hipEventRecord(bucket_ev[2], s);
@@ -950,15 +1050,16 @@ struct bltvqg_engine {
         BLT_REQUIRE(bound, "engine_optimizer_step: engine not bound");
         const int64_t n_main = late_off, n_late = tsize - late_off;
         if (hipMemsetAsync(stats + 4, 0, sizeof(float), s) != hipSuccess) return BLT_ERR_HIP;
-        RC(blt_sumsq(grad, n_main, stats + 4, s));
-        if (last_bwd_phase2) RC(blt_sumsq(grad + late_off, n_late, stats + 4, s));
+        // the latent-phase parameters sit right behind the others in the flat buffers: one launch covers both regions when both are live
+        RC(blt_sumsq(grad, last_bwd_phase2 ? tsize : n_main, stats + 4, s));
         ++step_main;
+        if (last_bwd_phase2) ++step_late;
+        if (last_bwd_phase2 && step_late == step_main)      // same bias correction: one launch (only when training began in phase 2)
+            return blt_adam_step(train, grad, adam_m, adam_v, tsize, stats + 4, max_norm, lr, b1, b2, eps, step_main, s);
         RC(blt_adam_step(train, grad, adam_m, adam_v, n_main, stats + 4, max_norm, lr, b1, b2, eps, step_main, s));
-        if (last_bwd_phase2) {
-            ++step_late;
+        if (last_bwd_phase2)
             RC(blt_adam_step(train + late_off, grad + late_off, adam_m + late_off, adam_v + late_off, n_late, stats + 4, max_norm, lr, b1, b2,
                              eps, step_late, s));
-        }
         return BLT_OK;
     }
 #undef RC
@@ -987,8 +1088,8 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
 void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (!e) return;
     for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
-    for (int i = 0; i < 6; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
-    for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+    for (int i = 0; i < 12; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
+    for (int i = 0; i < 4; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
     for (size_t i = 0; i < e->prof_a.size(); ++i) { (void)hipEventDestroy(e->prof_a[i]); (void)hipEventDestroy(e->prof_b[i]); }
     delete e;
 }
@@ -1038,18 +1139,23 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
             blt_set_error("engine_bind: timing table upload failed");
             return BLT_ERR_HIP;
         }
+        if (e->ttable && !e->tlist.empty() &&
+            hipMemcpy(e->ttable, e->tlist.data(), e->tlist.size() * sizeof(bltvqg_engine::TEnt), hipMemcpyHostToDevice) != hipSuccess) {
+            blt_set_error("engine_bind: transposed-shadow table upload failed");
+            return BLT_ERR_HIP;
+        }
     }
     for (int i = 0; i < 3; ++i)
         if (!e->bucket_ev[i] && hipEventCreateWithFlags(&e->bucket_ev[i], hipEventDisableTiming) != hipSuccess) {
             blt_set_error("engine_bind: event creation failed");
             return BLT_ERR_HIP;
         }
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 12; ++i)
         if (!e->fj[i] && hipEventCreateWithFlags(&e->fj[i], hipEventDisableTiming) != hipSuccess) {
             blt_set_error("engine_bind: event creation failed");
             return BLT_ERR_HIP;
         }
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
         if (!e->side[i] && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) {
             blt_set_error("engine_bind: stream creation failed");
             return BLT_ERR_HIP;

@@ -663,11 +663,14 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
     issue(0, 0);
     if (AHEAD > 1 && nk > 1) issue(1, 1);
     if (AHEAD > 2 && nk > 2) issue(2, 2);
+    if (AHEAD > 3 && nk > 3) issue(3, 3);
+    static_assert(AHEAD <= 4, "prologue issues at most four K-tiles");
     for (int kt = 0; kt < nk; ++kt) {
         if (kt == 1) STAMP(2);
         // this wave's part of tile kt has landed once at most min(AHEAD-1, tiles issued beyond kt) tiles are still in flight
         const int beyond = (nk - 1 - kt < AHEAD - 1) ? nk - 1 - kt : AHEAD - 1;
-        if (AHEAD > 2 && beyond == 2) wait_vmcnt<2 * PER_TILE>();
+        if (AHEAD > 3 && beyond == 3) wait_vmcnt<3 * PER_TILE>();
+        else if (AHEAD > 2 && beyond == 2) wait_vmcnt<2 * PER_TILE>();
         else if (AHEAD > 1 && beyond >= 1) wait_vmcnt<PER_TILE>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                          // every wave's part of tile kt landed; stage (kt+AHEAD)%NST is free
@@ -777,7 +780,7 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 }  // namespace
 
 // process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode,
-// [3] = ring depth of the 128x128 DMA kernel (0 = by grid size, 1 = always 4 stages, 2 = always 2 stages)
+// [3] = ring depth of the DMA kernels (0 = by grid size; 128x128: 1 = always 4 stages, 2 = always 2; 64x64: 3 = always 5, 4 = always 3)
 static int g_debug[4] = {0, 0, 0, 0};
 void blt_debug_set(int key, int value) { if (key >= 0 && key < 4) g_debug[key] = value; }
 
@@ -846,7 +849,11 @@ static int run_choice(int dtype, const GemmArgs& a, const Choice& c, int splits,
             return deep ? dispatch_dma<128, 128, 4>(a, stream) : dispatch_dma<128, 128, 2>(a, stream);
         }
         if (c.bm == 128 && c.bn == 64) return dispatch_dma<128, 64, 3>(a, stream);
-        return dispatch_dma<64, 64, 3>(a, stream);
+        // small grids of 64x64 tiles (the transformer's Linear layers: 40-700 workgroups, K = 256..1024) are bound by the DMA landing
+        // latency times the number of ring refills, so they keep four K-tiles in flight (80 KB ring)
+        const long t64 = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
+        const bool deep64 = g_debug[3] == 3 || (g_debug[3] != 4 && t64 <= 1024);
+        return deep64 ? dispatch_dma<64, 64, 5>(a, stream) : dispatch_dma<64, 64, 3>(a, stream);
     }
     if (dtype == BLT_BF16) return dispatch_tile<bf16>(a, c.bm, c.bn, splits, stream);
     return dispatch_tile<float>(a, c.bm, c.bn, splits, stream);

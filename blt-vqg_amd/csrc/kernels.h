@@ -124,6 +124,8 @@ int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, 
 // [Cout, Cin, KH, KW] fp32 -> [Cout, KH, KWpad, Cpad] (zeros in the padding)
 int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad, hipStream_t s);
 int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long rows, int cols, hipStream_t s);
+// table_dev: int4 {element offset, rows, cols, first 64x64 tile} per matrix; dst_bf16 may be null (transposed copy only)
+int blt_shadow_transpose(const float* src, void* dst_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s);
 
 // ---- losses ------------------------------------------------------------------------------------
 // token CE with ignore_index=0, mean over non-pad targets (count from counters[0]); writes d(logits) IN PLACE scaled by

@@ -136,6 +136,37 @@ __global__ void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __res
     }
 }
 
+// bf16 shadows of a list of fp32 matrices that live in one flat buffer: every table entry {off, rows, cols, first tile} names a
+// row-major [rows, cols] matrix at element offset `off`; its 64x64 tiles are cast into `dst` (same offsets, same layout) and into
+// `dstT` as the TRANSPOSE [cols, rows] (leading dimension rows).  The transposed copy turns the input-gradient GEMM
+// dX = dY W into the k-contiguous (NT) form that the LDS-DMA kernel takes.  One launch for the whole parameter buffer.
+__global__ __launch_bounds__(256) void shadow_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, bf16* __restrict__ dstT,
+                                                              const int4* __restrict__ table, int nent) {
+    __shared__ float tile[64][65];
+    int e = 0;
+    while (e + 1 < nent && (int)blockIdx.x >= table[e + 1].w) ++e;          // uniform scan, <= a few dozen entries
+    const int4 t = table[e];
+    const int off = t.x, rows = t.y, cols = t.z;
+    const int tiles_c = (cols + 63) >> 6;
+    const int lt = (int)blockIdx.x - t.w;
+    const int r0 = (lt / tiles_c) << 6, c0 = (lt % tiles_c) << 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        float v = 0.f;
+        if (r < rows && c < cols) {
+            v = src[(size_t)off + (size_t)r * cols + c];
+            if (dst) dst[(size_t)off + (size_t)r * cols + c] = (bf16)v;
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dstT[(size_t)off + (size_t)c * rows + r] = (bf16)tile[tx][i];
+    }
+}
+
 // NCHW fp32 image -> NHWC [N, Hp, Wp, Cpad]: image placed at (pt, pl), zeros in the border and in the padded channels.
 // One thread per output PIXEL: the C plane reads are coalesced along w, the Cpad channel values are written contiguously.
 template <typename T>
@@ -378,7 +409,15 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     float s = 0.f;
     const long n4 = n >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    // four independent 16-byte loads in flight per thread: the loop is bound by load latency, not by the adds
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        s += (a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w) + (b.x * b.x + b.y * b.y + b.z * b.z + b.w * b.w) +
+             (c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w) + (d.x * d.x + d.y * d.y + d.z * d.z + d.w * d.w);
+    }
+    for (; i < n4; i += stride) {
         const float4 v = x4[i];
         s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
     }
@@ -494,6 +533,12 @@ static int cast_rows_impl(int dtype_src, const void* src, int lds_, int dtype_ds
     else if (dtype_dst == BLT_F32) hipLaunchKernelGGL((cast_rows_kernel<bf16, float>), g, b, 0, s, (const bf16*)src, lds_, (float*)dst, ldd, rows, cols, width);
     else hipLaunchKernelGGL((cast_rows_kernel<bf16, bf16>), g, b, 0, s, (const bf16*)src, lds_, (bf16*)dst, ldd, rows, cols, width);
     return blt_check_launch("cast_rows");
+}
+
+int blt_shadow_transpose(const float* src, void* dst_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s) {
+    BLT_REQUIRE(src && dstT_bf16 && table_dev && nent > 0 && total_tiles > 0, "shadow_transpose: bad args");
+    hipLaunchKernelGGL(shadow_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, src, (bf16*)dst_bf16, (bf16*)dstT_bf16, (const int4*)table_dev, nent);
+    return blt_check_launch("shadow_transpose");
 }
 
 // dst[r, 0:cols] = cast(src[r, 0:cols]); dst[r, cols:ldd] = 0

@@ -40,6 +40,16 @@ SIGNATURES = {
     "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv2d_stat_rows": (I, [I, I, I, I, I, I, I, I]),
+    "bltvqg_pp_pixels": (L, [I, I, I]),
+    "bltvqg_pp_guard_front": (I, []),
+    "bltvqg_pp_guard_tail": (I, []),
+    "bltvqg_conv3x3_pp": (I, [P, P, P, I, I, I, I, I, P, P, P]),
+    "bltvqg_conv3x3_pp_stat_rows": (I, [I, I, I]),
+    "bltvqg_conv2d_pp": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P]),
+    "bltvqg_conv2d_pp_stat_rows": (I, [I, I, I, I, I, I, I, I, I, I, I]),
+    "bltvqg_bn_apply_pp": (I, [I, P, P, P, P, P, I, I, I, I, I, P]),
+    "bltvqg_bn_relu_maxpool_pp": (I, [I, P, P, P, P, I, I, I, I, P]),
+    "bltvqg_avgpool_pp": (I, [I, P, P, I, I, I, I, P]),
     "bltvqg_img_pack": (I, [I, P, P, I, I, I, I, I, I, I, I, I, P]),
     "bltvqg_conv_pack_w": (I, [I, P, P, I, I, I, I, I, I, P]),
     "bltvqg_conv_stem": (I, [I, P, P, P, I, I, I, I, I, I, P, P, P]),

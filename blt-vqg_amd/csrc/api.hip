@@ -47,6 +47,52 @@ int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int H
     return blt_gemm(dtype, g, (hipStream_t)stream);
 }
 
+/* ---- padded-pitch (PP) activations ---- */
+int64_t bltvqg_pp_pixels(int N, int H, int W) { return (int64_t)blt_pp_pixels(N, H, W); }
+int bltvqg_pp_guard_front(void) { return BLT_PP_GUARD_FRONT; }
+int bltvqg_pp_guard_tail(void) { return BLT_PP_GUARD_TAIL; }
+
+int bltvqg_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
+                      void* stream) {
+    return blt_conv3x3_pp(x, w, y, N, H, W, Cin, Cout, stat_sum, stat_sq, (hipStream_t)stream);
+}
+int bltvqg_conv3x3_pp_stat_rows(int N, int H, int W) { return blt_conv3x3_pp_stat_rows(N, H, W); }
+
+static GemmArgs conv_args_pp(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,
+                             int in_pp, int out_pp) {
+    GemmArgs g = conv_args(x, w, y, N, Hi, Wi, Cin, Cout, KH, KW, stride, pad);
+    const int Ho = g.cg.Ho, Wo = g.cg.Wo;
+    g.cg.in_rows = Hi + (in_pp ? 1 : 0); g.cg.in_pitch = Wi + (in_pp ? 1 : 0);
+    g.cg.Hov = Ho; g.cg.Wov = Wo;
+    g.cg.Ho = Ho + (out_pp ? 1 : 0); g.cg.Wo = Wo + (out_pp ? 1 : 0);
+    g.M = N * g.cg.Ho * g.cg.Wo;
+    return g;
+}
+
+int bltvqg_conv2d_pp(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride,
+                     int pad, int in_pp, int out_pp, float* stat_sum, float* stat_sq, void* stream) {
+    BLT_REQUIRE(N > 0 && Hi > 0 && Wi > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "conv2d_pp: bad sizes");
+    BLT_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv2d_pp: stat_sum and stat_sq go together");
+    GemmArgs g = conv_args_pp(x, w, y, N, Hi, Wi, Cin, Cout, KH, KW, stride, pad, in_pp, out_pp);
+    g.stat_sum = stat_sum; g.stat_sq = stat_sq;
+    return blt_gemm(dtype, g, (hipStream_t)stream);
+}
+int bltvqg_conv2d_pp_stat_rows(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int out_pp) {
+    GemmArgs g = conv_args_pp((const void*)16, (const void*)16, (void*)16, N, Hi, Wi, Cin, Cout, KH, KW, stride, pad, 0, out_pp);
+    return blt_gemm_stat_rows(g, dtype);
+}
+int bltvqg_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W, int C,
+                       int relu, void* stream) {
+    return blt_bn_apply_pp(dtype, x, scale, shift, res, y, N, H, W, C, relu, (hipStream_t)stream);
+}
+int bltvqg_bn_relu_maxpool_pp(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi, int C,
+                              void* stream) {
+    return blt_bn_relu_maxpool_pp(dtype, x, scale, shift, y, N, Hi, Wi, C, (hipStream_t)stream);
+}
+int bltvqg_avgpool_pp(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream) {
+    return blt_avgpool_pp(dtype, x, y, N, H, W, C, 0, (hipStream_t)stream);
+}
+
 int bltvqg_conv2d_stat_rows(int N, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad) {
     GemmArgs g = conv_args(nullptr, nullptr, nullptr, N, Hi, Wi, 8, Cout, KH, KW, stride, pad);
     return blt_gemm_stat_rows(g, BLT_BF16);

@@ -29,7 +29,8 @@ struct ConvSpec {
     int Cin, CinPad, Cout, K, stride, pad, Hi, Wi, Ho, Wo;
     void* wpacked = nullptr;
     float *scale = nullptr, *shift = nullptr;
-    void* out = nullptr;   // raw conv output / in-place BN result [B,Ho,Wo,Cout]
+    void* out = nullptr;   // raw conv output / in-place BN result: [B,Ho,Wo,Cout] (stem) or padded-pitch [B,Ho+1,Wo+1,Cout] (pp)
+    bool pp = false;       // input AND output in the padded-pitch layout (every convolution after the stem / max-pool)
 };
 
 struct Layer {   // saved activations of one transformer layer
@@ -316,8 +317,15 @@ struct bltvqg_engine {
         for (auto& cs : convs) {
             cs.wpacked = AT((int64_t)cs.Cout * cs.K * (cs.Cin < 8 ? 8 : cs.K) * cs.CinPad);
             cs.scale = AF(cs.Cout); cs.shift = AF(cs.Cout);
-            cs.out = AT((int64_t)B * cs.Ho * cs.Wo * cs.Cout);
-            const int64_t M = (int64_t)B * cs.Ho * cs.Wo;
+            cs.pp = (&cs != &convs[0]);
+            int64_t M = (int64_t)B * cs.Ho * cs.Wo;
+            if (cs.pp) {      // guards of zero pixels in front of / behind the positions (the bind-time memset provides the zeros)
+                M = blt_pp_pixels(B, cs.Ho, cs.Wo);
+                char* base_ = (char*)AT((BLT_PP_GUARD_FRONT + M + BLT_PP_GUARD_TAIL) * cs.Cout);
+                cs.out = base_ + (size_t)BLT_PP_GUARD_FRONT * cs.Cout * es;
+            } else {
+                cs.out = AT(M * cs.Cout);
+            }
             const int64_t rows = 2 * ((M + 63) / 64);   // upper bound for either tile size
             if (rows * cs.Cout > max_stat) max_stat = rows * cs.Cout;
         }
@@ -325,7 +333,8 @@ struct bltvqg_engine {
         stat_tmp = (double*)A((int64_t)blt_bn_scratch_doubles(512) * 8);
         {
             const int ph = (convs[0].Ho + 2 - 3) / 2 + 1, pw = (convs[0].Wo + 2 - 3) / 2 + 1;
-            pool0 = AT((int64_t)B * ph * pw * 64);
+            char* base_ = (char*)AT((BLT_PP_GUARD_FRONT + blt_pp_pixels(B, ph, pw) + BLT_PP_GUARD_TAIL) * 64);
+            pool0 = base_ + (size_t)BLT_PP_GUARD_FRONT * 64 * es;
         }
         pooled = AF((int64_t)B * 512);
         featpre = AF((int64_t)B * H); feats32 = AF((int64_t)B * H); dfeats32 = AF((int64_t)B * H); dfeatpre32 = AF((int64_t)B * H);
@@ -576,15 +585,24 @@ struct bltvqg_engine {
     }
 
     int conv_fwd(ConvSpec& cs, const void* x, hipStream_t s) {
+        const bool stem = cs.Cin < 8;
+        // 3x3 stride-1 convolutions on padded-pitch bf16 activations: the LDS-patch kernel (conv_pp.hip); everything else (stem,
+        // stride-2, 1x1, fp32 mode) is an implicit GEMM, reading / writing the padded-pitch layout through the generalised loader
+        const bool direct = cs.pp && dt == BLT_BF16 && cs.K == 3 && cs.stride == 1 && cs.pad == 1 && cs.Cin % 64 == 0 && cs.Cout % 64 == 0 &&
+                            cs.Wo <= 62;
         GemmArgs g;
         g.A = x; g.B = cs.wpacked; g.C = cs.out;
-        const bool stem = cs.Cin < 8;
         g.M = B * cs.Ho * cs.Wo; g.N = cs.Cout; g.K = stem ? 224 : cs.K * cs.K * cs.CinPad;
         g.lda = cs.CinPad; g.ldb = g.K; g.ldc = cs.Cout;
         g.is_conv = stem ? 2 : 1;
         g.cg.Hi = stem ? imgHp : cs.Hi; g.cg.Wi = stem ? imgWp : cs.Wi;
         g.cg.Cin = cs.CinPad; g.cg.cin_log2 = ilog2(cs.CinPad); g.cg.Ho = cs.Ho; g.cg.Wo = cs.Wo;
         g.cg.KH = cs.K; g.cg.KW = stem ? 8 : cs.K; g.cg.stride = cs.stride; g.cg.pad = stem ? 0 : cs.pad;
+        if (cs.pp) {
+            g.cg.in_rows = cs.Hi + 1; g.cg.in_pitch = cs.Wi + 1;
+            g.cg.Hov = cs.Ho; g.cg.Wov = cs.Wo; g.cg.Ho = cs.Ho + 1; g.cg.Wo = cs.Wo + 1;
+            g.M = B * g.cg.Ho * g.cg.Wo;
+        }
         if (bn_train) { g.stat_sum = stat_sum; g.stat_sq = stat_sq; }
         if (prof_on) {
             if (prof_n == prof_a.size()) {
@@ -594,19 +612,24 @@ struct bltvqg_engine {
             }
             (void)hipEventRecord(prof_a[prof_n], s);
         }
-        RC(blt_gemm(dt, g, s));
+        if (direct) RC(blt_conv3x3_pp(x, cs.wpacked, cs.out, B, cs.Ho, cs.Wo, cs.Cin, cs.Cout, g.stat_sum, g.stat_sq, s));
+        else RC(blt_gemm(dt, g, s));
         if (prof_on) {
             (void)hipEventRecord(prof_b[prof_n], s);
             ++prof_n;
-            prof_flops += 2.0 * (double)g.M * (double)cs.Cout * (double)(cs.K * cs.K * cs.Cin);   // algorithmic (unpadded Cin)
+            prof_flops += 2.0 * (double)B * cs.Ho * cs.Wo * (double)cs.Cout * (double)(cs.K * cs.K * cs.Cin);   // algorithmic: real pixels, unpadded Cin
         }
         if (!bn_train)
             return blt_bn_eval_scale(FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"),
                                      1e-5f, cs.scale, cs.shift, cs.Cout, s);
-        const int nparts = blt_gemm_stat_rows(g, dt);
-        return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)g.M, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
+        const int nparts = direct ? blt_conv3x3_pp_stat_rows(B, cs.Ho, cs.Wo) : blt_gemm_stat_rows(g, dt);
+        return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)B * cs.Ho * cs.Wo, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
                                0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,
                                nullptr, stat_tmp, s);
+    }
+    // BatchNorm apply (+ residual, ReLU) in place on a convolution's padded-pitch output: pad positions become zeros
+    int bn_act(ConvSpec& cs, const void* res, int relu, hipStream_t s) {
+        return blt_bn_apply_pp(dt, cs.out, cs.scale, cs.shift, res, cs.out, B, cs.Ho, cs.Wo, cs.Cout, relu, s);
     }
 
     int cnn_fwd(const float* images, hipStream_t s) {
@@ -619,7 +642,7 @@ struct bltvqg_engine {
         size_t ci = 0;
         ConvSpec& c1 = convs[ci++];
         RC(conv_fwd(c1, img, s));
-        RC(blt_bn_relu_maxpool(dt, c1.out, c1.scale, c1.shift, pool0, B, c1.Ho, c1.Wo, 64, s));
+        RC(blt_bn_relu_maxpool_pp(dt, c1.out, c1.scale, c1.shift, pool0, B, c1.Ho, c1.Wo, 64, s));
         const void* x = pool0;
         int cin = 64;
         const int couts[4] = {64, 128, 256, 512};
@@ -630,22 +653,22 @@ struct bltvqg_engine {
                 ConvSpec& ca = convs[ci++];
                 ConvSpec& cb = convs[ci++];
                 RC(conv_fwd(ca, x, s));
-                RC(blt_bn_apply(dt, ca.out, ca.scale, ca.shift, nullptr, ca.out, (long)B * ca.Ho * ca.Wo, ca.Cout, 1, s));
+                RC(bn_act(ca, nullptr, 1, s));
                 RC(conv_fwd(cb, ca.out, s));
                 const void* res = x;
                 if (st != 1 || cin != cout) {
                     ConvSpec& cd = convs[ci++];
                     RC(conv_fwd(cd, x, s));
-                    RC(blt_bn_apply(dt, cd.out, cd.scale, cd.shift, nullptr, cd.out, (long)B * cd.Ho * cd.Wo, cd.Cout, 0, s));
+                    RC(bn_act(cd, nullptr, 0, s));
                     res = cd.out;
                 }
-                RC(blt_bn_apply(dt, cb.out, cb.scale, cb.shift, res, cb.out, (long)B * cb.Ho * cb.Wo, cb.Cout, 1, s));
+                RC(bn_act(cb, res, 1, s));
                 x = cb.out;
                 cin = cout;
             }
         // Head in fp32 (exact-fp32 MFMA on the fp32 master weights): BatchNorm1d removes the common mode of the pooled feature
         // across the batch, so bf16 rounding of these tiny [B,512]/[B,H] tensors would be amplified into the image feature.
-        RC(blt_avgpool(dt, x, pooled, B, convs.back().Ho * convs.back().Wo, 512, 1, s));
+        RC(blt_avgpool_pp(dt, x, pooled, B, convs.back().Ho, convs.back().Wo, 512, 1, s));
         {
             const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
             GemmArgs g = mk(pooled, 512, 0, train + pw.off, 512, 0, featpre, H, B, H, 512);

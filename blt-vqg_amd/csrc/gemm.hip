@@ -75,7 +75,7 @@ __device__ __forceinline__ void load_a(const GemmArgs& p, const T* __restrict__ 
             const int r = q / p.cg.KW, s = q - r * p.cg.KW;
             const int hi = cr.h0[i] + r, wi = cr.w0[i] + s;
             const bool ok = (cr.base[i] >= 0) && (k < p.K) && ((unsigned)hi < (unsigned)p.cg.Hi) && ((unsigned)wi < (unsigned)p.cg.Wi);
-            const T* src = Ag + (((size_t)(cr.base[i] + hi * p.cg.Wi + wi)) << p.cg.cin_log2) + ci;
+            const T* src = Ag + (((size_t)(cr.base[i] + hi * p.cg.in_pitch + wi)) << p.cg.cin_log2) + ci;
             { uint4 v_ = make_uint4(0u, 0u, 0u, 0u); if (ok) v_ = *reinterpret_cast<const uint4*>(src); ra[i] = v_; }
         } else if constexpr (C::LOADER == LD_STEM) {
             // zero-bordered NHWC4 image: k = r*32 + pixel*4 + c ; every 16-byte chunk is in bounds and aligned
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const int n = gm / hw, rem = gm - n * hw;
             const int ho = rem / p.cg.Wo, wo = rem - ho * p.cg.Wo;
             if constexpr (LOADER == LD_CONV) {
-                cr.base[i] = (gm < p.M) ? n * p.cg.Hi * p.cg.Wi : -1;
+                cr.base[i] = (gm < p.M && ho < p.cg.Hov && wo < p.cg.Wov) ? n * p.cg.in_rows * p.cg.in_pitch : -1;
                 cr.h0[i] = ho * p.cg.stride - p.cg.pad;
                 cr.w0[i] = wo * p.cg.stride - p.cg.pad;
             } else {   // stem: Hi/Wi are the PADDED image dims; the border already holds the conv padding
@@ -596,7 +596,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
             if constexpr (LOADER == LD_CONV) {
                 a_h0[j] = ho * p.cg.stride - p.cg.pad;
                 a_w0[j] = wo * p.cg.stride - p.cg.pad;
-                a_off[j] = (gm < p.M) ? (((long)n * p.cg.Hi + a_h0[j]) * p.cg.Wi + a_w0[j]) * p.cg.Cin + gc * 8 : -(1L << 40);
+                a_off[j] = (gm < p.M && ho < p.cg.Hov && wo < p.cg.Wov)
+                               ? (((long)n * p.cg.in_rows + a_h0[j]) * p.cg.in_pitch + a_w0[j]) * p.cg.Cin + gc * 8 : -(1L << 40);
             } else {   // stem: k = r*32 + pixel*4 + c on the zero-bordered NHWC4 image; a K-tile spans two filter rows
                 a_off[j] = (gm < p.M) ? ((((long)n * p.cg.Hi + ho * 2 + (gc >> 2)) * p.cg.Wi + wo * 2 + (gc & 3) * 2) << 2) : -1;
             }
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmArgs p) {
             const int q = k0 >> p.cg.cin_log2, c0 = k0 & (p.cg.Cin - 1);
             tap_r = q / p.cg.KW;
             tap_s = q - tap_r * p.cg.KW;
-            a_koff = ((long)tap_r * p.cg.Wi + tap_s) * p.cg.Cin + c0;
+            a_koff = ((long)tap_r * p.cg.in_pitch + tap_s) * p.cg.Cin + c0;
         } else if constexpr (LOADER == LD_STEM) {
             a_koff = ((long)(2 * kt) * p.cg.Wi) << 2;
         }
@@ -889,7 +890,13 @@ static int autotune(int dtype, const GemmArgs& a, hipStream_t stream) {
 }
 
 int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
-    const GemmArgs& a = a_in;
+    GemmArgs a = a_in;
+    if (a.is_conv == 1) {      // plain NHWC defaults of the PP generalisation
+        if (a.cg.in_rows == 0) a.cg.in_rows = a.cg.Hi;
+        if (a.cg.in_pitch == 0) a.cg.in_pitch = a.cg.Wi;
+        if (a.cg.Hov == 0) a.cg.Hov = a.cg.Ho;
+        if (a.cg.Wov == 0) a.cg.Wov = a.cg.Wo;
+    }
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "gemm: bad dtype %d", dtype);
     BLT_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
     BLT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);

@@ -4,8 +4,18 @@
 #pragma once
 #include "common.h"
 
+// "Padded-pitch" (PP) activation layout [N][H+1][W+1][C]: every image row is followed by ONE zero pixel and every image by ONE
+// zero row, so that in linear pixel order the left/right/top/bottom neighbours of a border pixel are zeros (the pad pixel after row
+// h is the right pad of row h and the left pad of row h+1) — a 3x3 stride-1 window of a run of consecutive pixels is then itself a
+// run of consecutive pixels, which is what conv3x3_pp (conv_pp.hip) stages through LDS once instead of nine times.  A PP buffer
+// carries BLT_PP_GUARD_FRONT zero pixels before pixel 0 and BLT_PP_GUARD_TAIL after the last one.
+#define BLT_PP_GUARD_FRONT 64
+#define BLT_PP_GUARD_TAIL 384
 struct ConvGeom {
     int Hi, Wi, Cin, cin_log2, Ho, Wo, KH, KW, stride, pad;
+    // generalisation for PP operands (0 = plain NHWC): rows per image / pixels per row of the INPUT buffer, and the number of valid
+    // rows / columns of the output grid Ho x Wo (PP output: Ho = valid + 1, Wo = valid + 1; rows of the pad positions come out 0)
+    int in_rows = 0, in_pitch = 0, Hov = 0, Wov = 0;
 };
 
 // C[M,N] = epilogue( alpha * sum_k A^[m,k] * B^[n,k] )
@@ -53,6 +63,12 @@ int blt_gemm_tile(const GemmArgs& a, int dtype);
 void blt_debug_set(int key, int value);
 int blt_gemm_splits(const GemmArgs& a, int dtype);
 
+// ---- padded-pitch 3x3 stride-1 convolution (conv_pp.hip), bf16 only ----------------
+long blt_pp_pixels(int N, int H, int W);                 // N*(H+1)*(W+1) positions (without the guards)
+int blt_conv3x3_pp_stat_rows(int N, int H, int W);       // partial rows written to stat_sum / stat_sq
+int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
+                   hipStream_t s);
+
 // ---- normalisation -----------------------------------------------------------------
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       long rows, int cols, float eps, hipStream_t s);
@@ -72,6 +88,12 @@ int blt_bn_apply(int dtype, const void* x, const float* scale, const float* shif
 int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
                         int C, hipStream_t s);
 int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, int out_f32, hipStream_t s);
+// padded-pitch (PP) variants: activations [N][H+1][W+1][C] with zero pad pixels (see ConvGeom)
+int blt_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W, int C,
+                    int relu, hipStream_t s);
+int blt_bn_relu_maxpool_pp(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi, int C,
+                           hipStream_t s);
+int blt_avgpool_pp(int dtype, const void* x, void* y, int N, int H, int W, int C, int out_f32, hipStream_t s);
 // BatchNorm1d over the batch (train mode); saves mean / rstd; updates running stats (unbiased var)
 int blt_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                  float* running_mean, float* running_var, int B, int C, float eps, float momentum, hipStream_t s);

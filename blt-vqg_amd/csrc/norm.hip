@@ -214,10 +214,23 @@ __global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const floa
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
-                                                      T* __restrict__ y, long nchunks, int cpr /* chunks per row */, int relu) {
+                                                      T* __restrict__ y, long nchunks, int cpr /* chunks per row */, int relu,
+                                                      int ppH, int ppW) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cpr) * 8;
+        const long row = i / cpr;
+        const int c = (int)(i - row * cpr) * 8;
         float v[8], sc[8], sh[8];
+        if (ppW > 0) {
+            // padded-pitch layout (kernels.h): pad positions hold whatever the convolution computed there -> write the zeros that the
+            // next convolution reads as its padding
+            const long r2 = row / (ppW + 1);
+            if ((int)(row - r2 * (ppW + 1)) == ppW || (int)(r2 % (ppH + 1)) == ppH) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                Vec8<T>::store(y + i * 8, v);
+                continue;
+            }
+        }
         Vec8<T>::load(x + i * 8, v);
         Vec8<float>::load(scale + c, sc);
         Vec8<float>::load(shift + c, sh);
@@ -240,7 +253,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, T* __restrict__ y, int N,
-                                                             int Hi, int Wi, int C, int Ho, int Wo) {
+                                                             int Hi, int Wi, int C, int Ho, int Wo, int pp /* 1: padded-pitch output */) {
     const int cpr = C >> 3;
     const long total = (long)N * Ho * Wo * cpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -266,12 +279,14 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
                 for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e] * sc[e] + sh[e]);
             }
         }
-        Vec8<T>::store(y + i * 8, m);
+        Vec8<T>::store(y + ((((long)n * (Ho + pp) + ho) * (Wo + pp) + wo) * cpr + cc) * 8, m);
     }
 }
 
+// mean over `count` of the HW positions of each image (padded-pitch input: HW = (H+1)(W+1) positions of which the H*W real ones are
+// non-zero)
 template <typename T, typename TO>
-__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, TO* __restrict__ y, int N, int HW, int C) {
+__global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, TO* __restrict__ y, int N, int HW, int C, int count) {
     const int cpr = C >> 3;
     const long total = (long)N * cpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -286,7 +301,7 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] += v[e];
         }
-        const float inv = 1.f / (float)HW;
+        const float inv = 1.f / (float)count;
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] *= inv;
         Vec8<TO>::store(y + n * C + cc * 8, a);
@@ -433,29 +448,56 @@ int blt_bn_apply(int dtype, const void* x, const float* scale, const float* shif
     BLT_REQUIRE(x && scale && shift && y && rows > 0 && C % 8 == 0, "bn_apply: bad args (C=%d)", C);
     const long n = rows * (C / 8);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu),
-               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu));
+               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu, 0, 0),
+               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu, 0, 0));
     return blt_check_launch("bn_apply");
 }
 
-int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
-                        int C, hipStream_t s) {
+// x, res, y in the padded-pitch layout [N][H+1][W+1][C]; pad positions of y are written as zeros
+int blt_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W, int C,
+                    int relu, hipStream_t s) {
+    BLT_REQUIRE(x && scale && shift && y && N > 0 && H > 0 && W > 0 && C % 8 == 0, "bn_apply_pp: bad args (C=%d)", C);
+    const long n = (long)N * (H + 1) * (W + 1) * (C / 8);
+    DISPATCH_T(dtype,
+               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu, H, W),
+               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu, H, W));
+    return blt_check_launch("bn_apply_pp");
+}
+
+static int bn_relu_maxpool_impl(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
+                                int C, int pp, hipStream_t s) {
     BLT_REQUIRE(x && scale && shift && y && C % 8 == 0 && N > 0, "bn_relu_maxpool: bad args");
     const int Ho = (Hi + 2 - 3) / 2 + 1, Wo = (Wi + 2 - 3) / 2 + 1;
     const long n = (long)N * Ho * Wo * (C / 8);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (float*)y, N, Hi, Wi, C, Ho, Wo),
-               hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (bf16*)y, N, Hi, Wi, C, Ho, Wo));
+               hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (float*)y, N, Hi, Wi, C, Ho, Wo, pp),
+               hipLaunchKernelGGL(bn_relu_maxpool_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (bf16*)y, N, Hi, Wi, C, Ho, Wo, pp));
     return blt_check_launch("bn_relu_maxpool");
 }
+int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
+                        int C, hipStream_t s) {
+    return bn_relu_maxpool_impl(dtype, x, scale, shift, y, N, Hi, Wi, C, 0, s);
+}
+// y in the padded-pitch layout [N][Ho+1][Wo+1][C]: only the real pixels are written (the pads keep their zeros)
+int blt_bn_relu_maxpool_pp(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
+                           int C, hipStream_t s) {
+    return bn_relu_maxpool_impl(dtype, x, scale, shift, y, N, Hi, Wi, C, 1, s);
+}
 
-int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, int out_f32, hipStream_t s) {
-    BLT_REQUIRE(x && y && C % 8 == 0 && N > 0 && HW > 0, "avgpool: bad args");
+static int avgpool_impl(int dtype, const void* x, void* y, int N, int HW, int C, int count, int out_f32, hipStream_t s) {
+    BLT_REQUIRE(x && y && C % 8 == 0 && N > 0 && HW > 0 && count > 0, "avgpool: bad args");
     const long n = (long)N * (C / 8);
-    if (dtype == BLT_F32) hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, (float*)y, N, HW, C);
-    else if (out_f32) hipLaunchKernelGGL((avgpool_kernel<bf16, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (float*)y, N, HW, C);
-    else hipLaunchKernelGGL((avgpool_kernel<bf16, bf16>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, HW, C);
+    if (dtype == BLT_F32) hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, (float*)y, N, HW, C, count);
+    else if (out_f32) hipLaunchKernelGGL((avgpool_kernel<bf16, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (float*)y, N, HW, C, count);
+    else hipLaunchKernelGGL((avgpool_kernel<bf16, bf16>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, HW, C, count);
     return blt_check_launch("avgpool");
+}
+int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, int out_f32, hipStream_t s) {
+    return avgpool_impl(dtype, x, y, N, HW, C, HW, out_f32, s);
+}
+// x in the padded-pitch layout [N][H+1][W+1][C] with zero pads
+int blt_avgpool_pp(int dtype, const void* x, void* y, int N, int H, int W, int C, int out_f32, hipStream_t s) {
+    return avgpool_impl(dtype, x, y, N, (H + 1) * (W + 1), C, H * W, out_f32, s);
 }
 
 int blt_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

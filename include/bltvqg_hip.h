@@ -62,6 +62,31 @@ int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int l
 int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
                   int stride, int pad, float* stat_sum, float* stat_sq, void* stream);
 int bltvqg_conv2d_stat_rows(int N, int Hi, int Wi, int Cout, int KH, int KW, int stride, int pad);
+/* ---- padded-pitch (PP) activations: the layout of the ResNet-18 stack between its 3x3 convolutions (encoder_cnn.py:17,33) ----
+ * [N][H+1][W+1][C]: one zero pixel after every image row, one zero row after every image, so that in linear pixel order all four
+ * neighbours of a border pixel are zeros and a 3x3 stride-1 window of a run of pixels is a run of pixels.  A PP buffer holds
+ * bltvqg_pp_guard_front() zero pixels, then bltvqg_pp_pixels(N,H,W) positions, then bltvqg_pp_guard_tail() zero pixels; the functions
+ * below take the address of position 0.  The guards and pad positions must be zero on input; bn_apply_pp / bn_relu_maxpool_pp keep
+ * them zero on output, conv outputs leave arbitrary values at pad positions (excluded from the statistics). */
+int64_t bltvqg_pp_pixels(int N, int H, int W);
+int bltvqg_pp_guard_front(void);
+int bltvqg_pp_guard_tail(void);
+/* bf16 3x3 stride-1 pad-1 convolution, PP in -> PP out, Cin and Cout multiples of 64, W <= 62: the input patch of 128 output
+ * positions is staged in LDS once per 64-channel slice and serves all nine taps (csrc/conv_pp.hip).  w [Cout,3,3,Cin]. */
+int bltvqg_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
+                      void* stream);
+int bltvqg_conv3x3_pp_stat_rows(int N, int H, int W);
+/* general implicit-GEMM convolution (as bltvqg_conv2d) with a PP input and / or PP output (the stride-2 and 1x1 convolutions of the
+ * stack, and every convolution in fp32 mode); PP output rows at pad positions are written as zeros */
+int bltvqg_conv2d_pp(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
+                     int stride, int pad, int in_pp, int out_pp, float* stat_sum, float* stat_sq, void* stream);
+int bltvqg_conv2d_pp_stat_rows(int dtype, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad, int out_pp);
+int bltvqg_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W,
+                       int C, int relu, void* stream);
+int bltvqg_bn_relu_maxpool_pp(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi, int C,
+                              void* stream);
+int bltvqg_avgpool_pp(int dtype, const void* x, void* y, int N, int H, int W, int C, void* stream);
+
 /* NCHW fp32 -> NHWC [N,Hp,Wp,Cpad] with the image at (pad_top, pad_left) and zeros elsewhere */
 int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, int W, int Cpad, int pad_top, int pad_left, int Hp,
                     int Wp, void* stream);

@@ -477,3 +477,142 @@ def test_adam_with_clip_matches_torch():
         assert abs(float(nsq) - float((grad.double() ** 2).sum())) < 1e-4 * float((grad.double() ** 2).sum())
         check(lib.bltvqg_adam_step(ptr(p), ptr(gd), ptr(m), ptr(v), n, ptr(nsq), 5.0, lr, 0.9, 0.999, 1e-8, step, stream_ptr()), "adam")
         assert torch.allclose(p.cpu(), pr.detach(), atol=2e-6, rtol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# padded-pitch (PP) activations: [N][H+1][W+1][C] with zero pad pixels + guards (include/bltvqg_hip.h)
+# ---------------------------------------------------------------------------------------------------------------
+def _pp_alloc(N, H, W, C, dtype, fill=0.0):
+    import gpu_ops as G
+    lib = G.lib()
+    gf, gt, n = lib.bltvqg_pp_guard_front(), lib.bltvqg_pp_guard_tail(), lib.bltvqg_pp_pixels(N, H, W)
+    buf = torch.zeros(gf + n + gt, C, dtype=dtype, device="cuda")
+    body = buf[gf:gf + n]
+    if fill:
+        body.fill_(fill)
+    return buf, body, body.view(N, H + 1, W + 1, C)
+
+
+def _pp_pack(x_nhwc, dtype):
+    N, H, W, C = x_nhwc.shape
+    buf, body, view = _pp_alloc(N, H, W, C, dtype)
+    view[:, :H, :W] = x_nhwc.to(dtype).cuda()
+    return buf, body
+
+
+@pytest.mark.parametrize("geom", [(64, 64, 56, 56, 2), (128, 128, 28, 28, 3), (256, 256, 14, 14, 2), (512, 512, 7, 7, 5),
+                                  (64, 128, 9, 13, 1), (128, 64, 20, 33, 2), (192, 64, 5, 62, 1)])
+def test_conv3x3_pp_exact_integer_and_stats(geom):
+    """The LDS-patch 3x3 convolution (csrc/conv_pp.hip) against F.conv2d on integer data: exact outputs at every real pixel, exact
+    BatchNorm partial sums with the pad positions masked out; the guards and the tile overhang stay untouched."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    lib = G.lib()
+    cin, cout, H, W, N = geom
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout + H)
+    x = _ints((N, cin, H, W), -2, 2, g, torch.float32)
+    w = _ints((cout, cin, 3, 3), -1, 1, g, torch.float32)
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1).permute(0, 2, 3, 1).contiguous()
+    xbuf, xbody = _pp_pack(x.permute(0, 2, 3, 1).contiguous(), dtype)
+    wp = G.conv_pack_w(w.cuda(), dtype, cin)
+    ybuf, ybody, yview = _pp_alloc(N, H, W, cout, dtype, fill=7.0)
+    rows = lib.bltvqg_conv3x3_pp_stat_rows(N, H, W)
+    ssum = torch.zeros(rows, cout, device="cuda")
+    ssq = torch.zeros(rows, cout, device="cuda")
+    check(lib.bltvqg_conv3x3_pp(ptr(xbody), ptr(wp), ptr(ybody), N, H, W, cin, cout, ptr(ssum), ptr(ssq), stream_ptr()), "conv3x3_pp")
+    torch.cuda.synchronize()
+    got = yview[:, :H, :W].float().cpu().double()
+    assert torch.equal(got, ref.float().to(dtype).double()), (got - ref).abs().max()
+    assert torch.equal(ssum.double().sum(0).cpu(), ref.reshape(-1, cout).sum(0))
+    assert torch.equal(ssq.double().sum(0).cpu(), (ref.reshape(-1, cout) ** 2).sum(0))
+    gf = lib.bltvqg_pp_guard_front()
+    assert float(ybuf[:gf].abs().max()) == 0.0 and float(ybuf[gf + ybody.shape[0]:].abs().max()) == 0.0      # guards untouched
+    # without statistics (eval-mode BatchNorm path)
+    ybody.fill_(7.0)
+    check(lib.bltvqg_conv3x3_pp(ptr(xbody), ptr(wp), ptr(ybody), N, H, W, cin, cout, None, None, stream_ptr()), "conv3x3_pp")
+    torch.cuda.synchronize()
+    assert torch.equal(yview[:, :H, :W].float().cpu().double(), ref.float().to(dtype).double())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("geom", [(64, 128, 3, 2, 1, 20, 20, 1, 1), (64, 128, 1, 2, 0, 20, 20, 1, 1), (64, 64, 3, 1, 1, 12, 10, 1, 1),
+                                  (64, 64, 3, 1, 1, 12, 10, 0, 1), (64, 64, 3, 2, 1, 11, 13, 1, 0), (128, 256, 3, 2, 1, 28, 28, 1, 1)])
+def test_conv2d_pp_layouts(dtype, geom):
+    """The implicit-GEMM convolution reading / writing padded-pitch buffers (stride-2 and 1x1 convolutions of the ResNet stack, every
+    convolution in fp32 mode): exact outputs, zeros at the pad positions of a PP output, exact statistics."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    lib = G.lib()
+    cin, cout, k, stride, pad, Hi, Wi, in_pp, out_pp = geom
+    N = 3
+    g = torch.Generator().manual_seed(cin + cout + k + Hi)
+    x = _ints((N, cin, Hi, Wi), -2, 2, g, torch.float32)
+    w = _ints((cout, cin, k, k), -1, 1, g, torch.float32)
+    ref = F.conv2d(x.double(), w.double(), None, stride, pad).permute(0, 2, 3, 1).contiguous()
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    xh = x.permute(0, 2, 3, 1).contiguous()
+    if in_pp:
+        xbuf, xin = _pp_pack(xh, dtype)
+    else:
+        xin = xh.to(dtype).cuda()
+    wp = G.conv_pack_w(w.cuda(), dtype, cin)
+    if out_pp:
+        ybuf, yout, yview = _pp_alloc(N, Ho, Wo, cout, dtype, fill=7.0)
+    else:
+        yout = torch.full((N, Ho, Wo, cout), 7.0, dtype=dtype, device="cuda")
+        yview = yout
+    rows = lib.bltvqg_conv2d_pp_stat_rows(G.DT[dtype], N, Hi, Wi, cin, cout, k, k, stride, pad, out_pp)
+    ssum = torch.zeros(rows, cout, device="cuda")
+    ssq = torch.zeros(rows, cout, device="cuda")
+    check(lib.bltvqg_conv2d_pp(G.DT[dtype], ptr(xin), ptr(wp), ptr(yout), N, Hi, Wi, cin, cout, k, k, stride, pad, in_pp, out_pp, ptr(ssum),
+                               ptr(ssq), stream_ptr()), "conv2d_pp")
+    torch.cuda.synchronize()
+    got = yview[:, :Ho, :Wo].float().cpu().double()
+    assert torch.equal(got, ref.float().to(dtype).double()), (got - ref).abs().max()
+    if out_pp:
+        assert float(yview[:, Ho].abs().max()) == 0.0 and float(yview[:, :, Wo].abs().max()) == 0.0
+    assert torch.equal(ssum.double().sum(0).cpu(), ref.reshape(-1, cout).sum(0))
+    assert torch.equal(ssq.double().sum(0).cpu(), (ref.reshape(-1, cout) ** 2).sum(0))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_padded_pitch_elementwise_ops(dtype):
+    """bn_apply_pp (zeros at pad positions whatever the input holds there), bn_relu_maxpool_pp (PP output), avgpool_pp."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    lib = G.lib()
+    N, H, W, C = 3, 6, 5, 64
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, H, W, C, generator=g)
+    r = torch.randn(N, H, W, C, generator=g)
+    scale, shift = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xbuf, xbody, xview = _pp_alloc(N, H, W, C, dtype, fill=3.0)          # garbage at the pad positions, as a convolution leaves them
+    xview[:, :H, :W] = x.to(dtype).cuda()
+    rbuf, rbody = _pp_pack(r, dtype)
+    check(lib.bltvqg_bn_apply_pp(G.DT[dtype], ptr(xbody), ptr(scale.cuda()), ptr(shift.cuda()), ptr(rbody), ptr(xbody), N, H, W, C, 1,
+                                 stream_ptr()), "bn_apply_pp")
+    torch.cuda.synchronize()
+    ref = torch.relu(x.to(dtype).float() * scale + shift + r.to(dtype).float())
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (xview[:, :H, :W].float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    assert float(xview[:, H].abs().max()) == 0.0 and float(xview[:, :, W].abs().max()) == 0.0
+    # avgpool over the PP tensor == mean over the real pixels
+    out = torch.zeros(N, C, dtype=dtype, device="cuda")
+    check(lib.bltvqg_avgpool_pp(G.DT[dtype], ptr(xbody), ptr(out), N, H, W, C, stream_ptr()), "avgpool_pp")
+    torch.cuda.synchronize()
+    pm = xview[:, :H, :W].float().mean(dim=(1, 2)).cpu()
+    assert (out.float().cpu() - pm).abs().max() < tol * max(1.0, float(pm.abs().max()))
+    # relu(bn(x)) -> maxpool 3x3/2 pad 1 into a PP buffer
+    Hi, Wi = 11, 8
+    z = torch.randn(N, C, Hi, Wi, generator=g)
+    zh = z.permute(0, 2, 3, 1).contiguous().to(dtype).cuda()
+    Ho, Wo = (Hi - 1) // 2 + 1, (Wi - 1) // 2 + 1
+    pbuf, pbody, pview = _pp_alloc(N, Ho, Wo, C, dtype)
+    check(lib.bltvqg_bn_relu_maxpool_pp(G.DT[dtype], ptr(zh), ptr(scale.cuda()), ptr(shift.cuda()), ptr(pbody), N, Hi, Wi, C, stream_ptr()),
+          "bn_relu_maxpool_pp")
+    torch.cuda.synchronize()
+    zr = torch.relu(zh.float().cpu() * scale + shift).permute(0, 3, 1, 2)
+    ref = F.max_pool2d(zr, 3, 2, 1).permute(0, 2, 3, 1)
+    assert (pview[:, :Ho, :Wo].float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
+    assert float(pview[:, Ho].abs().max()) == 0.0 and float(pview[:, :, Wo].abs().max()) == 0.0

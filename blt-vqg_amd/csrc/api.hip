@@ -111,6 +111,8 @@ int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, 
 int bltvqg_conv_stem(int dtype, const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, int Cout, float* stat_sum,
                      float* stat_sq, void* stream) {
     BLT_REQUIRE(N > 0 && H > 0 && W > 0 && Cout > 0, "conv_stem: bad sizes");
+    if (blt_conv_stem_direct_ok(dtype, H, W, Hp, Wp, Cout))
+        return blt_conv_stem_direct(x_padded, w, y, N, H, W, Hp, Wp, stat_sum, stat_sq, (hipStream_t)stream);
     GemmArgs g;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     g.A = x_padded; g.B = w; g.C = y;
@@ -121,10 +123,16 @@ int bltvqg_conv_stem(int dtype, const void* x_padded, const void* w, void* y, in
     return blt_gemm(dtype, g, (hipStream_t)stream);
 }
 int bltvqg_conv_stem_stat_rows(int N, int H, int W, int Cout) {
+    // an upper bound valid for both kernels (the bf16 LDS-patch kernel writes 2 rows per 8x16 tile, the implicit GEMM 2 per M tile);
+    // rows that are not written must be zero (they are summed)
     GemmArgs g;
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     g.M = N * Ho * Wo; g.N = Cout; g.K = 224;
-    return blt_gemm_stat_rows(g, BLT_BF16);
+    int rows = blt_gemm_stat_rows(g, BLT_BF16);
+    const int rows32 = blt_gemm_stat_rows(g, BLT_F32);
+    if (rows32 > rows) rows = rows32;
+    if (Cout == 64 && Ho % 8 == 0 && Wo % 16 == 0 && blt_conv_stem_direct_stat_rows(N, H, W) > rows) rows = blt_conv_stem_direct_stat_rows(N, H, W);
+    return rows;
 }
 
 int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd, int64_t rows,

@@ -41,9 +41,11 @@ struct ConvPPArgs {
     int valid_off;      // byte offset of the 128-float row-validity table (epilogue only: behind the staged output tile)
 };
 
-template <int BN>
+// NSTB = stages of the weight ring: 2 (one tap in flight; two workgroups per CU cover each other's waits) or 4 (three taps in flight, for
+// grids that leave a workgroup alone on its CU, e.g. the 7x7x512 layer: 256 tiles)
+template <int BN, int NSTB>
 __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
-    constexpr int WN = BN / 2, TN = WN / 16, TM = 4, CH_B = BN * 8 / 256, B_STAGE = BN * 128, CSB = BN + 8;
+    constexpr int WN = BN / 2, TN = WN / 16, TM = 4, CH_B = BN * 8 / 256, B_STAGE = BN * 128, CSB = BN + 8, AHEAD = NSTB - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     }
     auto issue_b = [&](int s, int sl, int t) {
         const int k0 = t * p.Cin + (sl << 6);
-        char* st = ring + (s & 1) * B_STAGE;
+        char* st = ring + (s % NSTB) * B_STAGE;
 #pragma unroll
         for (int j = 0; j < CH_B; ++j) {
             const void* src = (b_off[j] >= 0) ? (const void*)(p.Wt + b_off[j] + k0) : (const void*)g_zero16;
@@ -88,7 +90,12 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     };
 
     for (int j = 0; j < p.pw; ++j) issue_patch(0, j);
-    issue_b(0, 0, 0);
+    // the tap steps run s = sl*9 + t; (sa, ta) walks AHEAD steps in front of (sl, t) for the weight ring
+    int sa = 0, ta = 0;
+    for (int s = 0; s < AHEAD && s < nsteps; ++s) {
+        issue_b(s, sa, ta);
+        if (++ta == 9) { ta = 0; ++sa; }
+    }
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -97,16 +104,20 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
 
     int sl = 0, t = 0;
     for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's share of B(s) (and of every older DMA) has landed
-        __builtin_amdgcn_s_barrier();                        // ... everyone's has; the other ring stage and the idle patch buffer are free
-        {
-            int t1 = t + 1, sl1 = sl;
-            if (t1 == 9) { t1 = 0; ++sl1; }
-            if (s + 1 < nsteps) issue_b(s + 1, sl1, t1);
-        }
+        // this wave's share of B(s) and of every older DMA has landed once only the younger taps' weight DMAs are outstanding (the
+        // patch piece of an iteration is issued BEFORE its weight tile, so it is never younger than the tile that is waited for)
+        const int younger = (nsteps - 1 - s < AHEAD - 1) ? nsteps - 1 - s : AHEAD - 1;
+        if (AHEAD > 2 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * CH_B) : "memory");
+        else if (AHEAD > 1 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_B) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // ... everyone's has; ring stage (s-1) % NSTB and the idle patch buffer are free
         if (sl + 1 < NS && t < p.pw) issue_patch(sl + 1, t);
+        if (s + AHEAD < nsteps) {
+            issue_b(s + AHEAD, sa, ta);
+            if (++ta == 9) { ta = 0; ++sa; }
+        }
         const char* pa = (sl & 1) ? patch1 : patch0;
-        const char* bs = ring + (s & 1) * B_STAGE;
+        const char* bs = ring + (s % NSTB) * B_STAGE;
         const int tr = (t >= 6) ? 2 : (t >= 3) ? 1 : 0;
         const int toff = tr * pitch + (t - 3 * tr);
 #pragma unroll
@@ -183,10 +194,10 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     }
 }
 
-template <int BN>
+template <int BN, int NSTB>
 int launch(const ConvPPArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<BN>;
+    auto kern = conv3x3_pp_kernel<BN, NSTB>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             blt_set_error("conv3x3_pp: hipFuncSetAttribute failed");
@@ -224,12 +235,159 @@ int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, i
     const int grid = a.chunked ? 8 * cdiv(a.nblocks, 8) : a.nblocks;
     const int NS = Cin / 64;
     // two workgroups per CU need <= 80 KB each: the validity table (512 B) shares the epilogue's space behind the staged tile
-    size_t lds = (size_t)(NS > 1 ? 2 : 1) * a.pw * 4096 + 2 * (size_t)BN * 128;
+    // a grid that gives most CUs a single workgroup: deep weight ring instead of a partner workgroup
+    const bool deep = a.nblocks <= 320;
+    size_t lds = (size_t)(NS > 1 ? 2 : 1) * a.pw * 4096 + (deep ? 4 : 2) * (size_t)BN * 128;
     const size_t stage = ((size_t)128 * (BN + 8) * 2 + 15) / 16 * 16;
     if (lds < stage + 512) lds = stage + 512;
     a.valid_off = (int)stage;
     BLT_REQUIRE(a.Mq < (1L << 31), "conv3x3_pp: too many positions");
     // the tile overhang of the last workgroup's patch must stay inside the tail guard
     BLT_REQUIRE(a.pw * 32 - (W + 2) <= BLT_PP_GUARD_TAIL, "conv3x3_pp: tail guard too small");
-    return BN == 128 ? launch<128>(a, grid, lds, s) : launch<64>(a, grid, lds, s);
+    if (BN == 128) return deep ? launch<128, 4>(a, grid, lds, s) : launch<128, 2>(a, grid, lds, s);
+    return deep ? launch<64, 4>(a, grid, lds, s) : launch<64, 2>(a, grid, lds, s);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// ResNet stem: 7x7 stride-2 pad-3 convolution of the 3-channel image, 64 output channels (encoder_cnn.py:17, torchvision conv1).
+// Input: zero-bordered NHWC4 bf16 image [N][Hp][Wp][4] (image at (3,3)); weights packed [64][7][8][4] (K = 224: tap column 7 and
+// channel 3 are zero).  As an implicit GEMM each output pixel fetched its own 7 x 64 B window — 448 B per pixel, 75 % of it shared
+// with its neighbours.  Here a workgroup owns an 8 x 16 tile of output pixels of one image, stages the 21 x 38-pixel input patch
+// (6.4 KB instead of 57 KB) and the whole filter (28 KB, seven [64 couts][64 B] planes, one per filter row) in LDS, and runs
+// seven K = 32 MFMA steps: for filter row r the A fragment of output (orow, ocol) is the 16 bytes at patch pixel
+// (2*orow + r, 2*ocol + 2*lg) — consecutive ocol are 16 B apart, so a fragment read is one contiguous 1 KB of LDS.
+// 35 KB of LDS per workgroup: four workgroups per CU overlap their load / MFMA / store phases (a tile is only 56 MFMAs per wave).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct StemArgs {
+    const bf16* X;
+    const bf16* Wt;
+    bf16* Y;
+    int N, Hp, Wp, Ho, Wo;
+    float *stat_sum, *stat_sq;
+};
+
+constexpr int STEM_PITCH = 304;                 // 38 pixels x 8 B per patch row
+constexpr int STEM_PATCH_BYTES = 7 * 1024;      // 21 rows x 19 chunks = 399 chunks -> 7 DMA instructions
+constexpr int STEM_W_BYTES = 28 * 1024;         // 7 planes x 64 couts x 64 B
+
+__global__ __launch_bounds__(256) void conv_stem_direct_kernel(const StemArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
+    const int tiles_w = p.Wo >> 4, tiles_h = p.Ho >> 3;
+    const int b = blockIdx.x;
+    const int n = b / (tiles_w * tiles_h), rem = b - n * (tiles_w * tiles_h);
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int oh0 = th * 8, ow0 = tw * 16;
+    char* const patch = smem;
+    char* const wl = smem + STEM_PATCH_BYTES;
+
+    // ---- LDS-DMA: patch (instructions 0..6), filter planes (28 instructions); instruction ii = j*4 + wave ----
+    const bf16* xin = p.X + (((size_t)n * p.Hp + 2 * oh0) * p.Wp + 2 * ow0) * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ii = j * 4 + wave;
+        if (ii < 7) {
+            const int c = ii * 64 + lane;
+            const int row = c / 19, cc = c - row * 19;
+            const void* src = (c < 21 * 19) ? (const void*)(xin + ((size_t)row * p.Wp) * 4 + cc * 8) : (const void*)g_zero16;
+            dma16(src, patch + ii * 1024);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int ii = j * 4 + wave;
+        const int c = ii * 64 + lane;                    // chunk (r, cout, q): c = (r*64 + cout)*4 + q
+        const int q = c & 3, co = (c >> 2) & 63, r = c >> 8;
+        dma16(p.Wt + co * 224 + r * 32 + q * 8, wl + ii * 1024);
+    }
+
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        bf16x8 af[4], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(patch + (2 * (wm * 4 + i) + r) * STEM_PITCH + (l15 + lg) * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bfr[j] = *reinterpret_cast<const bf16x8*>(wl + ((r * 64 + wn * 32 + j * 16 + l15) * 4 + lg) * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+
+    // ---- BatchNorm partial statistics (every position of the tile is a real pixel): half tile = wave row ----
+    if (p.stat_sum != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[i][j][r];
+                    s1 += v;
+                    s2 += v * v;
+                }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lg == 0) {
+                const size_t o = (size_t)(b * 2 + wm) * 64 + wn * 32 + j * 16 + l15;
+                p.stat_sum[o] = s1;
+                p.stat_sq[o] = s2;
+            }
+        }
+    }
+    // ---- bf16 tile -> LDS -> 16-byte stores.  MFMA result row (lg*4 + r) of fragment i is output column ocol = lg*4 + r of row orow = wm*4 + i
+    constexpr int CSB = 72;
+    bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[((wm * 4 + i) * 16 + lg * 4 + r) * CSB + wn * 32 + j * 16 + l15] = (bf16)acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int c = tid; c < 128 * 8; c += 256) {
+        const int m = c >> 3, ch = c & 7;
+        const int orow = m >> 4, ocol = m & 15;
+        bf16* dst = p.Y + (((size_t)n * p.Ho + oh0 + orow) * p.Wo + ow0 + ocol) * 64 + ch * 8;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(Cs + m * CSB + ch * 8);
+    }
+}
+
+}  // namespace
+
+bool blt_conv_stem_direct_ok(int dtype, int H, int W, int Hp, int Wp, int Cout) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    return dtype == BLT_BF16 && Cout == 64 && Ho % 8 == 0 && Wo % 16 == 0 && Hp >= 2 * (Ho - 1) + 7 && Wp >= 2 * (Wo - 1) + 8 && Wp % 2 == 0;
+}
+int blt_conv_stem_direct_stat_rows(int N, int H, int W) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    return 2 * N * (Ho / 8) * (Wo / 16);
+}
+int blt_conv_stem_direct(const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, float* stat_sum, float* stat_sq,
+                         hipStream_t s) {
+    BLT_REQUIRE(x_padded && w && y && N > 0 && blt_conv_stem_direct_ok(BLT_BF16, H, W, Hp, Wp, 64), "conv_stem_direct: unsupported geometry");
+    BLT_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv_stem_direct: stat_sum and stat_sq go together");
+    BLT_REQUIRE(((uintptr_t)x_padded % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv_stem_direct: operands must be 16-byte aligned");
+    StemArgs a;
+    a.X = (const bf16*)x_padded; a.Wt = (const bf16*)w; a.Y = (bf16*)y; a.N = N; a.Hp = Hp; a.Wp = Wp;
+    a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+    const int grid = N * (a.Ho / 8) * (a.Wo / 16);
+    hipLaunchKernelGGL(conv_stem_direct_kernel, dim3(grid), dim3(256), STEM_PATCH_BYTES + STEM_W_BYTES, s, a);
+    return blt_check_launch("conv_stem_direct");
 }

@@ -241,11 +241,12 @@ struct bltvqg_engine {
             if (ends_with(p.name, "value_linear.weight")) continue;                       // part of a fused group
             if (ends_with(p.name, "key_linear.weight")) { if (!encdec) continue; rows = 2 * H; }      // enc-dec k|v
             if (ends_with(p.name, "query_linear.weight") && !encdec) rows = 3 * H;          // self-attention q|k|v
-            if (rows % 8 != 0) continue;                                                   // ld of the transposed operand must be 16-byte aligned
-            TEnt t; t.off = (int)p.off; t.rows = rows; t.cols = p.dims[1]; t.tile0 = ttiles;
+            // ld of the transposed operand must be 16-byte aligned; otherwise only the plain shadow is written (cols < 0 flags it)
+            const bool tr = (rows % 8 == 0);
+            TEnt t; t.off = (int)p.off; t.rows = rows; t.cols = tr ? p.dims[1] : -p.dims[1]; t.tile0 = ttiles;
             ttiles += ((rows + 63) / 64) * ((p.dims[1] + 63) / 64);
             tlist.push_back(t);
-            trows[p.off] = rows;
+            if (tr) trows[p.off] = rows;
         }
 
         // ---- frozen backbone (torchvision resnet18 names, encoder_cnn.py:17) + running statistics ----
@@ -482,6 +483,9 @@ struct bltvqg_engine {
     // workgroups into an fp32 scratch (atomics) and cast back; falls through to the plain kernel in fp32 mode / small V
     int dgrad_bigk(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M, hipStream_t s) {
         if (dt != BLT_BF16 || tpi(wname).dims[0] < 2048) return blt_gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
+        // enough rows to fill the chip with 64x64 tiles (the decoder's output projection: 40 x 4 tiles, 125 K-tiles each on a deep ring):
+        // the k-contiguous form through the transposed shadow needs no fp32 scratch, memset or cast
+        if (M >= 1024 && WT(wname, tpi(wname).dims[0]) != nullptr) return blt_gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
         GemmArgs g;
         {   // n-contiguous B (the plain shadow): the split-K path lives in the register-staged kernel
             int ldw;
@@ -612,7 +616,9 @@ struct bltvqg_engine {
             }
             (void)hipEventRecord(prof_a[prof_n], s);
         }
+        const bool direct_stem = stem && blt_conv_stem_direct_ok(dt, c.image_h, c.image_w, imgHp, imgWp, cs.Cout);
         if (direct) RC(blt_conv3x3_pp(x, cs.wpacked, cs.out, B, cs.Ho, cs.Wo, cs.Cin, cs.Cout, g.stat_sum, g.stat_sq, s));
+        else if (direct_stem) RC(blt_conv_stem_direct(x, cs.wpacked, cs.out, B, c.image_h, c.image_w, imgHp, imgWp, g.stat_sum, g.stat_sq, s));
         else RC(blt_gemm(dt, g, s));
         if (prof_on) {
             (void)hipEventRecord(prof_b[prof_n], s);
@@ -622,7 +628,8 @@ struct bltvqg_engine {
         if (!bn_train)
             return blt_bn_eval_scale(FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"),
                                      1e-5f, cs.scale, cs.shift, cs.Cout, s);
-        const int nparts = direct ? blt_conv3x3_pp_stat_rows(B, cs.Ho, cs.Wo) : blt_gemm_stat_rows(g, dt);
+        const int nparts = direct ? blt_conv3x3_pp_stat_rows(B, cs.Ho, cs.Wo)
+                           : direct_stem ? blt_conv_stem_direct_stat_rows(B, c.image_h, c.image_w) : blt_gemm_stat_rows(g, dt);
         return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)B * cs.Ho * cs.Wo, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
                                0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,
                                nullptr, stat_tmp, s);
@@ -720,10 +727,8 @@ struct bltvqg_engine {
         phase2 = p2; seed = seed_; fwd_done = false;
         if (hipMemsetAsync(stats, 0, 8 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
         // weight shadows
-        if (dt == BLT_BF16) {
-            RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
-            if (!tlist.empty()) RC(blt_shadow_transpose(train, nullptr, wshadowT, ttable, (int)tlist.size(), ttiles, s));
-        }
+        // bf16 shadows of every GEMM weight (plain + transposed) in one launch; biases / LayerNorm / embedding rows are read in fp32
+        if (dt == BLT_BF16 && !tlist.empty()) RC(blt_shadow_transpose(train, wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
                            tgt32, ctx32, post32, counters, s));

@@ -68,6 +68,11 @@ long blt_pp_pixels(int N, int H, int W);                 // N*(H+1)*(W+1) positi
 int blt_conv3x3_pp_stat_rows(int N, int H, int W);       // partial rows written to stat_sum / stat_sq
 int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
                    hipStream_t s);
+// 7x7/2 stem on the zero-bordered NHWC4 image with the patch + filter staged in LDS (bf16, Cout = 64, Ho % 8 == 0, Wo % 16 == 0)
+bool blt_conv_stem_direct_ok(int dtype, int H, int W, int Hp, int Wp, int Cout);
+int blt_conv_stem_direct_stat_rows(int N, int H, int W);
+int blt_conv_stem_direct(const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, float* stat_sum, float* stat_sq,
+                         hipStream_t s);
 
 // ---- normalisation -----------------------------------------------------------------
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,

@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void shadow_transpose_kernel(const float* __re
     int e = 0;
     while (e + 1 < nent && (int)blockIdx.x >= table[e + 1].w) ++e;          // uniform scan, <= a few dozen entries
     const int4 t = table[e];
-    const int off = t.x, rows = t.y, cols = t.z;
+    const int off = t.x, rows = t.y, cols = t.z < 0 ? -t.z : t.z;
+    const bool transposed = t.z > 0;          // cols < 0: plain shadow only (rows not a multiple of 8)
     const int tiles_c = (cols + 63) >> 6;
     const int lt = (int)blockIdx.x - t.w;
     const int r0 = (lt / tiles_c) << 6, c0 = (lt % tiles_c) << 6;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(256) void shadow_transpose_kernel(const float* __re
         tile[i][tx] = v;
     }
     __syncthreads();
+    if (!transposed) return;
     for (int i = ty; i < 64; i += 4) {
         const int c = c0 + i, r = r0 + tx;
         if (c < cols && r < rows) dstT[(size_t)off + (size_t)c * rows + r] = (bf16)tile[tx][i];
@@ -236,6 +238,128 @@ __global__ __launch_bounds__(256) void ce_kernel(T* __restrict__ logits, int ld,
             x[v] = from_f32<T>(d);
         }
     }
+}
+
+// Register-resident variants (rows of up to 256 * 8 * NCH columns): every thread keeps its NCH chunks of 8 columns in registers, so a
+// row is read ONCE with 16-byte loads and its gradient written once — the three passes above are three trips through L2 with 2-byte
+// accesses.  Thread t owns chunks t, t+256, ... (coalesced).
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void ce_rows_kernel(T* __restrict__ logits, int ld, const int* __restrict__ target, int V,
+                                                     const float* __restrict__ count, float gscale, float* __restrict__ loss_out,
+                                                     int write_grad) {
+    __shared__ float red[16];
+    const long row = blockIdx.x;
+    T* x = logits + row * ld;
+    const int tgt = target[row];
+    const float inv_count = 1.f / fmaxf(count[0], 1.f);
+    const int nch = ld >> 3;
+    if (tgt == 0) {   // ignore_index: contributes nothing, gradient row is zero
+        if (write_grad) {
+            float z[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = 0.f;
+            for (int c = threadIdx.x; c < nch; c += 256) Vec8<T>::store(x + c * 8, z);
+        }
+        return;
+    }
+    float v[NCH][8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nch) Vec8<T>::load(x + c * 8, v[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (c >= nch || c * 8 + e >= V) v[j][e] = -INFINITY;
+            m = fmaxf(m, v[j][e]);
+        }
+    }
+    m = block_max(m, red);
+    float s = 0.f, xt = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s += __expf(v[j][e] - m);
+            if ((threadIdx.x + 256 * j) * 8 + e == tgt) xt = v[j][e];
+        }
+    s = block_sum(s, red);
+    const float lse = m + __logf(s);
+    if (((tgt >> 3) & 255) == (int)threadIdx.x) atomicAdd(loss_out, (lse - xt) * inv_count);     // the thread that holds the target column
+    if (write_grad) {
+        const float g = gscale * inv_count;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = threadIdx.x + 256 * j;
+            if (c < nch) {
+                float d[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int col = c * 8 + e;
+                    d[e] = (col < V) ? (__expf(v[j][e] - lse) - (col == tgt ? 1.f : 0.f)) * g : 0.f;
+                }
+                Vec8<T>::store(x + c * 8, d);
+            }
+        }
+    }
+}
+
+template <typename T, int NCH>
+__global__ __launch_bounds__(256) void bow_ce_rows_kernel(const T* __restrict__ z, int ld, const int* __restrict__ target, int Tn, int V,
+                                                         const float* __restrict__ count, float gscale, float* __restrict__ loss_out,
+                                                         T* __restrict__ dz) {
+    __shared__ float red[16];
+    __shared__ int tg[64];
+    const int b = blockIdx.x;
+    const T* x = z + (long)b * ld;
+    if (threadIdx.x < Tn) tg[threadIdx.x] = target[b * Tn + threadIdx.x];
+    __syncthreads();
+    int nb = 0;
+    for (int t = 0; t < Tn; ++t) nb += (tg[t] != 0);
+    const float inv_count = 1.f / fmaxf(count[0], 1.f);
+    const int nch = ld >> 3;
+    float v[NCH][8];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nch) Vec8<T>::load(x + c * 8, v[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (c >= nch || c * 8 + e >= V) v[j][e] = -INFINITY;
+            m = fmaxf(m, v[j][e]);
+        }
+    }
+    m = block_max(m, red);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += __expf(v[j][e] - m);
+    s = block_sum(s, red);
+    const float lse = m + __logf(s);
+    const float g = gscale * inv_count;
+    float l = 0.f;      // this thread's share of sum_t (lse - x[target_t]): its columns, weighted by how often they are a target
+    T* d = dz ? dz + (long)b * ld : nullptr;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = threadIdx.x + 256 * j;
+        if (c < nch) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int col = c * 8 + e;
+                int hits = 0;
+                for (int t = 0; t < Tn; ++t) hits += (tg[t] == col);
+                if (col == 0) hits = 0;                                  // ignore_index
+                if (hits) l += (float)hits * (lse - v[j][e]);
+                o[e] = (col < V) ? ((float)nb * __expf(v[j][e] - lse) - (float)hits) * g : 0.f;
+            }
+            if (d) Vec8<T>::store(d + c * 8, o);
+        }
+    }
+    l = block_sum(l, red);
+    if (threadIdx.x == 0) atomicAdd(loss_out, l * inv_count);
 }
 
 // bag-of-words CE (train_iq.py:92-94 without materialising the (B,T,V) repeat): one block per sample.
@@ -573,10 +697,25 @@ int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int
     return blt_check_launch("conv_pack_w");
 }
 
+#define ROWS_DISPATCH(KERN, T_, nch_, grid_, ...)                                                                      \
+    do {                                                                                                              \
+        if (nch_ <= 1) hipLaunchKernelGGL((KERN<T_, 1>), dim3(grid_), dim3(256), 0, s, __VA_ARGS__);                   \
+        else if (nch_ <= 2) hipLaunchKernelGGL((KERN<T_, 2>), dim3(grid_), dim3(256), 0, s, __VA_ARGS__);              \
+        else if (nch_ <= 4) hipLaunchKernelGGL((KERN<T_, 4>), dim3(grid_), dim3(256), 0, s, __VA_ARGS__);              \
+        else if (nch_ <= 8) hipLaunchKernelGGL((KERN<T_, 8>), dim3(grid_), dim3(256), 0, s, __VA_ARGS__);              \
+        else hipLaunchKernelGGL((KERN<T_, 16>), dim3(grid_), dim3(256), 0, s, __VA_ARGS__);                            \
+    } while (0)
+
 int blt_ce_fwd_bwd(int dtype, void* logits, int ld, const int* target, long M, int V, const float* count, float gscale,
                    float* loss_out, int write_grad, hipStream_t s) {
     CHECK_DTYPE(dtype, "ce");
     BLT_REQUIRE(logits && target && count && loss_out && M > 0 && V > 0 && ld >= V, "ce: bad args");
+    const int nch = cdiv(ld / 8, 256);       // chunks of 8 columns per thread
+    if (ld % 8 == 0 && nch <= 16 && ((uintptr_t)logits % 16) == 0) {
+        if (dtype == BLT_F32) ROWS_DISPATCH(ce_rows_kernel, float, nch, (unsigned)M, (float*)logits, ld, target, V, count, gscale, loss_out, write_grad);
+        else ROWS_DISPATCH(ce_rows_kernel, bf16, nch, (unsigned)M, (bf16*)logits, ld, target, V, count, gscale, loss_out, write_grad);
+        return blt_check_launch("ce");
+    }
     if (dtype == BLT_F32) hipLaunchKernelGGL(ce_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (float*)logits, ld, target, V, count, gscale, loss_out, write_grad);
     else hipLaunchKernelGGL(ce_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (bf16*)logits, ld, target, V, count, gscale, loss_out, write_grad);
     return blt_check_launch("ce");
@@ -586,6 +725,12 @@ int blt_bow_ce_fwd_bwd(int dtype, const void* z, int ld, const int* target, int 
                        float* loss_out, void* dz, hipStream_t s) {
     CHECK_DTYPE(dtype, "bow_ce");
     BLT_REQUIRE(z && target && count && loss_out && B > 0 && T > 0 && T <= 64 && V > 0 && ld >= V, "bow_ce: bad args");
+    const int nch = cdiv(ld / 8, 256);
+    if (ld % 8 == 0 && nch <= 16 && ((uintptr_t)z % 16) == 0 && ((uintptr_t)dz % 16) == 0) {
+        if (dtype == BLT_F32) ROWS_DISPATCH(bow_ce_rows_kernel, float, nch, B, (const float*)z, ld, target, T, V, count, gscale, loss_out, (float*)dz);
+        else ROWS_DISPATCH(bow_ce_rows_kernel, bf16, nch, B, (const bf16*)z, ld, target, T, V, count, gscale, loss_out, (bf16*)dz);
+        return blt_check_launch("bow_ce");
+    }
     if (dtype == BLT_F32) hipLaunchKernelGGL(bow_ce_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)z, ld, target, T, V, count, gscale, loss_out, (float*)dz);
     else hipLaunchKernelGGL(bow_ce_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)z, ld, target, T, V, count, gscale, loss_out, (bf16*)dz);
     return blt_check_launch("bow_ce");

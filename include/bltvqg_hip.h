@@ -93,7 +93,10 @@ int bltvqg_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int 
 /* [Cout,Cin,KH,KW] fp32 -> [Cout,KH,KWpad,Cpad] */
 int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad, void* stream);
 /* ResNet stem: 7x7 stride-2 pad-3 conv of a zero-bordered NHWC4 image [N,Hp,Wp,4] (image at (3,3), Wp even, Wp >= W+7) with weights
- * packed [Cout,7,8,4]; y [N,Ho,Wo,Cout] */
+ * packed [Cout,7,8,4]; y [N,Ho,Wo,Cout].  bf16 with Cout = 64, Ho % 8 == 0, Wo % 16 == 0 runs the LDS-patch kernel (the 21x38-pixel
+ * input patch of an 8x16 output tile and the whole filter are staged once, csrc/conv_pp.hip), everything else the implicit GEMM.
+ * stat_sum / stat_sq: bltvqg_conv_stem_stat_rows() rows of Cout, an upper bound for either kernel — zero them before the call, the
+ * rows are summed. */
 int bltvqg_conv_stem(int dtype, const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, int Cout,
                      float* stat_sum, float* stat_sq, void* stream);
 int bltvqg_conv_stem_stat_rows(int N, int H, int W, int Cout);

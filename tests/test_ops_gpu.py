@@ -154,7 +154,7 @@ def test_gemm_dropout_matches_exported_mask(dtype):
 
 # --------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("geom", [(3, 64, 7, 2, 3, 38, 34), (64, 64, 3, 1, 1, 14, 14), (64, 128, 3, 2, 1, 15, 13),
+@pytest.mark.parametrize("geom", [(3, 64, 7, 2, 3, 38, 34), (3, 64, 7, 2, 3, 64, 96), (3, 64, 7, 2, 3, 47, 31), (64, 64, 3, 1, 1, 14, 14), (64, 128, 3, 2, 1, 15, 13),
                                   (64, 128, 1, 2, 0, 14, 14), (256, 512, 3, 1, 1, 4, 4)])
 def test_conv2d_exact_integer_and_stats(dtype, geom):
     import gpu_ops as G

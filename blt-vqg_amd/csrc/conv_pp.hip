@@ -226,17 +226,24 @@ int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, i
     a.X = (const bf16*)x; a.Wt = (const bf16*)w; a.Y = (bf16*)y;
     a.Mq = blt_pp_pixels(N, H, W); a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
     a.pw = cdiv(cdiv(P, 8), 4);
-    const int BN = (Cout % 128 == 0) ? 128 : 64;
+    int BN = (Cout % 128 == 0) ? 128 : 64;
+    // a grid that would leave most CUs with a single workgroup (7x7x512: 256 tiles of 128 channels) runs twice as many half-width
+    // tiles instead: two workgroups per CU cover each other's DMA waits (measured 50 -> 42 us; a deeper ring did not help)
+    if (BN == 128 && (long)cdiv(blt_pp_pixels(N, H, W), 128) * (Cout / 128) <= 320) BN = 64;
+    if (blt_debug_get(4) == 64) BN = 64;
+    if (blt_debug_get(4) == 128 && Cout % 128 == 0) BN = 128;
     a.tiles_n = Cout / BN;
     a.nblocks = cdiv(a.Mq, 128) * a.tiles_n;
     // weights that fit an XCD's L2 beside the patches: keep neighbouring tiles on one XCD; otherwise the round-robin deal, which
     // gives each XCD every 8th tile and hence only (tiles_n | 8) of the weight slices
     a.chunked = ((long)Cout * 9 * Cin * 2 <= (2L << 20)) ? 1 : 0;
+    if (blt_debug_get(5)) a.chunked = blt_debug_get(5) == 1;
     const int grid = a.chunked ? 8 * cdiv(a.nblocks, 8) : a.nblocks;
     const int NS = Cin / 64;
     // two workgroups per CU need <= 80 KB each: the validity table (512 B) shares the epilogue's space behind the staged tile
     // a grid that gives most CUs a single workgroup: deep weight ring instead of a partner workgroup
-    const bool deep = a.nblocks <= 320;
+    bool deep = a.nblocks <= 320;
+    if (blt_debug_get(6)) deep = blt_debug_get(6) == 1;
     size_t lds = (size_t)(NS > 1 ? 2 : 1) * a.pw * 4096 + (deep ? 4 : 2) * (size_t)BN * 128;
     const size_t stage = ((size_t)128 * (BN + 8) * 2 + 15) / 16 * 16;
     if (lds < stage + 512) lds = stage + 512;

@@ -782,8 +782,9 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 
 // process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode,
 // [3] = ring depth of the DMA kernels (0 = by grid size; 128x128: 1 = always 4 stages, 2 = always 2; 64x64: 3 = always 5, 4 = always 3)
-static int g_debug[4] = {0, 0, 0, 0};
-void blt_debug_set(int key, int value) { if (key >= 0 && key < 4) g_debug[key] = value; }
+static int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+void blt_debug_set(int key, int value) { if (key >= 0 && key < 8) g_debug[key] = value; }
+int blt_debug_get(int key) { return (key >= 0 && key < 8) ? g_debug[key] : 0; }
 
 struct Choice { int bm, bn, no_dma; };
 static std::unordered_map<uint64_t, Choice> g_tuned;     // filled by autotune mode: measured best kernel per GEMM descriptor

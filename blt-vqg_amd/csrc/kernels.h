@@ -61,6 +61,7 @@ int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
 int blt_gemm_tile(const GemmArgs& a, int dtype);
 void blt_debug_set(int key, int value);
+int blt_debug_get(int key);      // keys 4..6: A/B switches of conv_pp.hip (4 = force BN 64/128, 5 = XCD mapping 1 chunked / 2 round-robin, 6 = ring 1 deep / 2 shallow)
 int blt_gemm_splits(const GemmArgs& a, int dtype);
 
 // ---- padded-pitch 3x3 stride-1 convolution (conv_pp.hip), bf16 only ----------------

@@ -243,16 +243,19 @@ __global__ __launch_bounds__(256) void ce_kernel(T* __restrict__ logits, int ld,
 // Register-resident variants (rows of up to 256 * 8 * NCH columns): every thread keeps its NCH chunks of 8 columns in registers, so a
 // row is read ONCE with 16-byte loads and its gradient written once — the three passes above are three trips through L2 with 2-byte
 // accesses.  Thread t owns chunks t, t+256, ... (coalesced).
+constexpr int CE_ROWS_PER_BLOCK = 4;
 template <typename T, int NCH>
-__global__ __launch_bounds__(256) void ce_rows_kernel(T* __restrict__ logits, int ld, const int* __restrict__ target, int V,
+__global__ __launch_bounds__(256) void ce_rows_kernel(T* __restrict__ logits, int ld, const int* __restrict__ target, long nrows, int V,
                                                      const float* __restrict__ count, float gscale, float* __restrict__ loss_out,
                                                      int write_grad) {
     __shared__ float red[16];
-    const long row = blockIdx.x;
-    T* x = logits + row * ld;
-    const int tgt = target[row];
     const float inv_count = 1.f / fmaxf(count[0], 1.f);
     const int nch = ld >> 3;
+    float loss_acc = 0.f;       // of the thread that holds the target column, over this block's rows
+    // CE_ROWS_PER_BLOCK rows per block: the loss of every row ends in a float atomic on ONE address, and those serialise
+    for (long row = (long)blockIdx.x * CE_ROWS_PER_BLOCK; row < (long)(blockIdx.x + 1) * CE_ROWS_PER_BLOCK && row < nrows; ++row) {
+    T* x = logits + row * ld;
+    const int tgt = target[row];
     if (tgt == 0) {   // ignore_index: contributes nothing, gradient row is zero
         if (write_grad) {
             float z[8];
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(T* __restrict__ logits, in
             for (int e = 0; e < 8; ++e) z[e] = 0.f;
             for (int c = threadIdx.x; c < nch; c += 256) Vec8<T>::store(x + c * 8, z);
         }
-        return;
+        continue;
     }
     float v[NCH][8];
     float m = -INFINITY;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(T* __restrict__ logits, in
         }
     s = block_sum(s, red);
     const float lse = m + __logf(s);
-    if (((tgt >> 3) & 255) == (int)threadIdx.x) atomicAdd(loss_out, (lse - xt) * inv_count);     // the thread that holds the target column
+    if (((tgt >> 3) & 255) == (int)threadIdx.x) loss_acc += (lse - xt) * inv_count;     // the thread that holds the target column
     if (write_grad) {
         const float g = gscale * inv_count;
 #pragma unroll
@@ -302,6 +305,9 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(T* __restrict__ logits, in
             }
         }
     }
+    }
+    loss_acc = block_sum(loss_acc, red);
+    if (threadIdx.x == 0 && loss_acc != 0.f) atomicAdd(loss_out, loss_acc);
 }
 
 template <typename T, int NCH>
@@ -712,8 +718,9 @@ int blt_ce_fwd_bwd(int dtype, void* logits, int ld, const int* target, long M, i
     BLT_REQUIRE(logits && target && count && loss_out && M > 0 && V > 0 && ld >= V, "ce: bad args");
     const int nch = cdiv(ld / 8, 256);       // chunks of 8 columns per thread
     if (ld % 8 == 0 && nch <= 16 && ((uintptr_t)logits % 16) == 0) {
-        if (dtype == BLT_F32) ROWS_DISPATCH(ce_rows_kernel, float, nch, (unsigned)M, (float*)logits, ld, target, V, count, gscale, loss_out, write_grad);
-        else ROWS_DISPATCH(ce_rows_kernel, bf16, nch, (unsigned)M, (bf16*)logits, ld, target, V, count, gscale, loss_out, write_grad);
+        const unsigned grid = (unsigned)cdiv(M, CE_ROWS_PER_BLOCK);
+        if (dtype == BLT_F32) ROWS_DISPATCH(ce_rows_kernel, float, nch, grid, (float*)logits, ld, target, M, V, count, gscale, loss_out, write_grad);
+        else ROWS_DISPATCH(ce_rows_kernel, bf16, nch, grid, (bf16*)logits, ld, target, M, V, count, gscale, loss_out, write_grad);
         return blt_check_launch("ce");
     }
     if (dtype == BLT_F32) hipLaunchKernelGGL(ce_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (float*)logits, ld, target, V, count, gscale, loss_out, write_grad);
@@ -779,7 +786,11 @@ int blt_argmax_top6(int dtype, const void* logits, int ld, int B, int V, int t, 
 
 int blt_sumsq(const float* x, long n, float* out, hipStream_t s) {
     BLT_REQUIRE(x && out && n > 0 && ((uintptr_t)x % 16) == 0, "sumsq: bad args");
-    hipLaunchKernelGGL(sumsq_kernel, dim3(ew_grid(n / 4 + 1, 1024)), dim3(256), 0, s, x, n, out);
+    // every block ends with one float atomic on the same address and those serialise (~15 ns each): 512 blocks keep that tail under
+    // the time the loads take, and still have 8 MB of 16-byte loads in flight
+    int grid = ew_grid(n / 4 + 1, 1024);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, s, x, n, out);
     return blt_check_launch("sumsq");
 }
 

@@ -83,7 +83,7 @@ int bltvqg_conv2d_pp_stat_rows(int dtype, int N, int Hi, int Wi, int Cin, int Co
 }
 int bltvqg_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W, int C,
                        int relu, void* stream) {
-    return blt_bn_apply_pp(dtype, x, scale, shift, res, y, N, H, W, C, relu, (hipStream_t)stream);
+    return blt_bn_apply_pp(dtype, x, scale, shift, res, nullptr, nullptr, y, N, H, W, C, relu, (hipStream_t)stream);
 }
 int bltvqg_bn_relu_maxpool_pp(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi, int C,
                               void* stream) {

@@ -635,8 +635,9 @@ struct bltvqg_engine {
                                nullptr, stat_tmp, s);
     }
     // BatchNorm apply (+ residual, ReLU) in place on a convolution's padded-pitch output: pad positions become zeros
-    int bn_act(ConvSpec& cs, const void* res, int relu, hipStream_t s) {
-        return blt_bn_apply_pp(dt, cs.out, cs.scale, cs.shift, res, cs.out, B, cs.Ho, cs.Wo, cs.Cout, relu, s);
+    int bn_act(ConvSpec& cs, const void* res, const ConvSpec* res_bn, int relu, hipStream_t s) {
+        return blt_bn_apply_pp(dt, cs.out, cs.scale, cs.shift, res, res_bn ? res_bn->scale : nullptr, res_bn ? res_bn->shift : nullptr, cs.out, B,
+                               cs.Ho, cs.Wo, cs.Cout, relu, s);
     }
 
     int cnn_fwd(const float* images, hipStream_t s) {
@@ -660,16 +661,17 @@ struct bltvqg_engine {
                 ConvSpec& ca = convs[ci++];
                 ConvSpec& cb = convs[ci++];
                 RC(conv_fwd(ca, x, s));
-                RC(bn_act(ca, nullptr, 1, s));
+                RC(bn_act(ca, nullptr, nullptr, 1, s));
                 RC(conv_fwd(cb, ca.out, s));
                 const void* res = x;
-                if (st != 1 || cin != cout) {
+                const ConvSpec* res_bn = nullptr;
+                if (st != 1 || cin != cout) {      // downsample branch: its BatchNorm is applied inside the block's final BN + add + ReLU pass
                     ConvSpec& cd = convs[ci++];
                     RC(conv_fwd(cd, x, s));
-                    RC(bn_act(cd, nullptr, 0, s));
                     res = cd.out;
+                    res_bn = &cd;
                 }
-                RC(bn_act(cb, res, 1, s));
+                RC(bn_act(cb, res, res_bn, 1, s));
                 x = cb.out;
                 cin = cout;
             }

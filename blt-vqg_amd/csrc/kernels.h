@@ -95,8 +95,9 @@ int blt_bn_relu_maxpool(int dtype, const void* x, const float* scale, const floa
                         int C, hipStream_t s);
 int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, int out_f32, hipStream_t s);
 // padded-pitch (PP) variants: activations [N][H+1][W+1][C] with zero pad pixels (see ConvGeom)
-int blt_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W, int C,
-                    int relu, hipStream_t s);
+// res (optional) is added before the ReLU; with res_scale / res_shift it is a raw convolution output normalised on the fly
+int blt_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, const float* res_scale,
+                    const float* res_shift, void* y, int N, int H, int W, int C, int relu, hipStream_t s);
 int blt_bn_relu_maxpool_pp(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi, int C,
                            hipStream_t s);
 int blt_avgpool_pp(int dtype, const void* x, void* y, int N, int H, int W, int C, int out_f32, hipStream_t s);

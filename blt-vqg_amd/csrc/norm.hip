@@ -202,6 +202,59 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(const double* __restrict
     }
 }
 
+// Single-launch variant: the slice sums meet in fp64 accumulators through device-scope atomics (no fence: every word that crosses
+// workgroups is only ever touched by atomics, so nothing depends on L2 write-back), a ticket counter finds the last workgroup of a
+// channel block, which swaps the totals out (leaving zeros for the next call) and finishes.  The fp64 additions commute up to the
+// last bit of a double, i.e. far below the fp32 scale / shift that leave this kernel.
+__global__ __launch_bounds__(256) void bn_stats_ticket_kernel(const float* __restrict__ psum, const float* __restrict__ psq, int nparts, int C,
+                                                             double* acc /* [2][C], zero between calls */, int* counters, double count,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                             float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                             float* __restrict__ scale, float* __restrict__ shift,
+                                                             float* __restrict__ save_mean, float* __restrict__ save_var) {
+    __shared__ double sh[2][4][64];
+    __shared__ int is_last;
+    const int cx = threadIdx.x & 63, py = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cx;
+    const int S = gridDim.y, sl = blockIdx.y;
+    double a = 0.0, b = 0.0;
+    if (c < C)
+        for (int part = sl * 4 + py; part < nparts; part += S * 4) {
+            a += (double)psum[(size_t)part * C + c];
+            b += (double)psq[(size_t)part * C + c];
+        }
+    sh[0][py][cx] = a;
+    sh[1][py][cx] = b;
+    __syncthreads();
+    if (py == 0) {       // wave 0: one pair of atomics per channel, then (same wave, after they are acknowledged) the ticket
+        if (c < C) {
+            __hip_atomic_fetch_add(acc + c, sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(acc + C + c, sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (cx == 0) is_last = (__hip_atomic_fetch_add(counters + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == S - 1);
+    }
+    __syncthreads();
+    if (!is_last || py != 0) return;
+    if (cx == 0) __hip_atomic_store(counters + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c >= C) return;
+    a = __hip_atomic_exchange(acc + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    b = __hip_atomic_exchange(acc + C + c, 0.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const double mu = a / count;
+    double var = b / count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (save_mean) save_mean[c] = (float)mu;
+    if (save_var) save_var[c] = (float)var;
+    if (rmean) {
+        const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+    }
+}
+
 __global__ void bn_eval_scale_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rmean,
                                      const float* __restrict__ rvar, float eps, float* __restrict__ scale, float* __restrict__ shift, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -215,7 +268,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ scale,
                                                       const float* __restrict__ shift, const T* __restrict__ res,
                                                       T* __restrict__ y, long nchunks, int cpr /* chunks per row */, int relu,
-                                                      int ppH, int ppW) {
+                                                      int ppH, int ppW, const float* __restrict__ rscale, const float* __restrict__ rshift) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
         const long row = i / cpr;
         const int c = (int)(i - row * cpr) * 8;
@@ -239,6 +292,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
         if (res != nullptr) {
             float r[8];
             Vec8<T>::load(res + i * 8, r);
+            if (rscale != nullptr) {      // the residual is itself a raw convolution output (downsample branch): its BatchNorm on the fly
+                float rs[8], rh[8];
+                Vec8<float>::load(rscale + c, rs);
+                Vec8<float>::load(rshift + c, rh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) r[e] = r[e] * rs[e] + rh[e];
+            }
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
@@ -429,6 +489,13 @@ int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long
     int slices = (nparts / 64 + 31) / 32 * 32;
     if (slices < 32) slices = 32;
     if (slices > BN_MAX_SLICES) slices = BN_MAX_SLICES;
+    if (blt_debug_get(7) != 2) {      // default: single launch (atomics + ticket), measured -40 us per step; debug key 7 = 2 selects the two-launch form
+        if (slices > 128) slices = 128;
+        int* counters = (int*)(scratch + 2 * (size_t)C);
+        hipLaunchKernelGGL(bn_stats_ticket_kernel, dim3(cdiv(C, 64), slices), dim3(256), 0, s, psum, psq, nparts, C, scratch, counters, (double)count,
+                           gamma, beta, eps, momentum, running_mean, running_var, scale, shift, save_mean, save_var);
+        return blt_check_launch("bn_finalize");
+    }
     hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 64), slices), dim3(256), 0, s, psum, psq, nparts, C, scratch);
     hipLaunchKernelGGL(bn_finish_kernel, dim3(cdiv(C, 8)), dim3(256), 0, s, (const double*)scratch, slices, C, (double)count, gamma, beta, eps,
                        momentum, running_mean, running_var, scale, shift, save_mean, save_var);
@@ -448,19 +515,20 @@ int blt_bn_apply(int dtype, const void* x, const float* scale, const float* shif
     BLT_REQUIRE(x && scale && shift && y && rows > 0 && C % 8 == 0, "bn_apply: bad args (C=%d)", C);
     const long n = rows * (C / 8);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu, 0, 0),
-               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu, 0, 0));
+               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu, 0, 0, nullptr, nullptr),
+               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu, 0, 0, nullptr, nullptr));
     return blt_check_launch("bn_apply");
 }
 
 // x, res, y in the padded-pitch layout [N][H+1][W+1][C]; pad positions of y are written as zeros
-int blt_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, void* y, int N, int H, int W, int C,
-                    int relu, hipStream_t s) {
+int blt_bn_apply_pp(int dtype, const void* x, const float* scale, const float* shift, const void* res, const float* res_scale,
+                    const float* res_shift, void* y, int N, int H, int W, int C, int relu, hipStream_t s) {
+    BLT_REQUIRE((res_scale == nullptr) == (res_shift == nullptr) && (res != nullptr || res_scale == nullptr), "bn_apply_pp: bad residual args");
     BLT_REQUIRE(x && scale && shift && y && N > 0 && H > 0 && W > 0 && C % 8 == 0, "bn_apply_pp: bad args (C=%d)", C);
     const long n = (long)N * (H + 1) * (W + 1) * (C / 8);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu, H, W),
-               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu, H, W));
+               hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, scale, shift, (const float*)res, (float*)y, n, C / 8, relu, H, W, res_scale, res_shift),
+               hipLaunchKernelGGL(bn_apply_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, scale, shift, (const bf16*)res, (bf16*)y, n, C / 8, relu, H, W, res_scale, res_shift));
     return blt_check_launch("bn_apply_pp");
 }
 

@@ -107,7 +107,9 @@ int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const flo
 int bltvqg_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                          const void* dres, void* dx, float* dgamma, float* dbeta, int64_t rows, int cols, void* stream);
 
-/* `scratch` holds bltvqg_bn_scratch_doubles(C) doubles (slice sums of the two-stage fp64 reduction; contents need not be initialised) */
+/* Per-channel batch statistics from the convolution's partial sums -> scale / shift (+ running statistics), one launch: the slice sums
+ * meet in fp64 accumulators through device-scope atomics and the last workgroup (ticket counter) finishes.  `scratch` holds
+ * bltvqg_bn_scratch_doubles(C) doubles; the owner zeroes it ONCE (hipMemset) before the first call, every call leaves it zeroed. */
 int bltvqg_bn_scratch_doubles(int C);
 int bltvqg_bn_finalize(const float* psum, const float* psq, int nparts, int C, int64_t count, const float* gamma,
                        const float* beta, float eps, float momentum, float* running_mean, float* running_var, float* scale,

@@ -859,8 +859,8 @@ struct bltvqg_engine {
     int ffn_bwd(const std::string& fp_, const void* xn, const void* xres, const float* m, const float* r, const std::string& ln,
                 Layer& y, const void* dx_in, void* dx_out, int M, int k, hipStream_t s) {
         void* gB = sB[k];
-        const float ks = (c.relu_dropout > 0.f) ? 1.f / (1.f - c.relu_dropout) : 1.f;
-        RC(blt_mask_scale(dt, dx_in, y.y2, y.gY, (long)M * H, ks, s));
+        const float ks = relu_ks();
+        // y.gY = d(FFN output) through the ReLU + dropout: already written by the LayerNorm backward that produced dx_in
         RC(wgrad_later(y.gY, H, y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), M, s));
         GemmArgs g = dgrad(y.gY, H, fp_ + "layers.1.weight", y.gF, F, M);
         g.maskY = y.h; g.ldm = F; g.mask_scale = ks;
@@ -872,6 +872,7 @@ struct bltvqg_engine {
 
     // `dx` holds d(stack output before the final LayerNorm) on entry and d(stack input) on exit; the gradients in between live in the
     // layers' own buffers (Layer::dx1..3)
+    float relu_ks() const { return (c.relu_dropout > 0.f) ? 1.f / (1.f - c.relu_dropout) : 1.f; }
     int stack_bwd(Stack& st, void* dx, const void* enc_out, const int* src_ids, hipStream_t s) {
         const int M = st.M, S = st.S;
         void *gA = sA[st.scr], *gB = sB[st.scr], *gC = sC[st.scr];
@@ -924,7 +925,10 @@ struct bltvqg_engine {
             // the last sub-layer of the stack writes d(stack input) back into the caller's buffer (its old content is dead by now:
             // only the top layer's FFN branch read it, on this same stream)
             void* out = (l == 0) ? dx : (st.dec ? y.dx3 : y.dx2);
-            RC(blt_layernorm_bwd(dt, gB, x, P(ln1 + ".weight"), y.m1, y.r1, cur, out, G(ln1 + ".weight"), G(ln1 + ".bias"), M, H, s));
+            // ... and, for the layer below, the masked gradient that opens its FFN backward (ffn_bwd)
+            const void* nmask = (l > 0) ? st.layers[l - 1].y2 : nullptr;
+            void* ngY = (l > 0) ? st.layers[l - 1].gY : nullptr;
+            RC(blt_layernorm_bwd(dt, gB, x, P(ln1 + ".weight"), y.m1, y.r1, cur, out, G(ln1 + ".weight"), G(ln1 + ".bias"), M, H, s, nmask, relu_ks(), ngY));
             cur = out;
         }
         return BLT_OK;
@@ -943,7 +947,8 @@ struct bltvqg_engine {
         {
             const void* xL = dec.layers[L - 1].x2;
             RC(blt_layernorm_bwd(dt, gA, xL, P("decoder.decoder.layer_norm.weight"), dec.mF, dec.rF, nullptr, dxT,
-                                 G("decoder.decoder.layer_norm.weight"), G("decoder.decoder.layer_norm.bias"), Mt, H, s));
+                                 G("decoder.decoder.layer_norm.weight"), G("decoder.decoder.layer_norm.bias"), Mt, H, s,
+                                 dec.layers[L - 1].y2, relu_ks(), dec.layers[L - 1].gY));
         }
         defer_wgrads = use_streams;
         RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
@@ -994,7 +999,8 @@ struct bltvqg_engine {
             void* dxP = (char*)dX_all + (size_t)(Ma + Mt) * H * es;
             const void* xL = renc.layers[L - 1].x2;
             RC(blt_layernorm_bwd(dt, d_renc, xL, P("answer_encoder.r_encoder.layer_norm.weight"), renc.mF, renc.rF, nullptr, dxP,
-                                 G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s0));
+                                 G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s0,
+                                 renc.layers[L - 1].y2, relu_ks(), renc.layers[L - 1].gY));
             RC(stack_bwd(renc, dxP, nullptr, nullptr, s0));
             RC(flush_wgrads(s0, side[3], fj[7]));
             Memb = Mtot;
@@ -1003,7 +1009,8 @@ struct bltvqg_engine {
         {
             const void* xL = enc.layers[L - 1].x2;
             RC(blt_layernorm_bwd(dt, d_enc, xL, P("answer_encoder.encoder.layer_norm.weight"), enc.mF, enc.rF, nullptr, dX_all,
-                                 G("answer_encoder.encoder.layer_norm.weight"), G("answer_encoder.encoder.layer_norm.bias"), Ma, H, s));
+                                 G("answer_encoder.encoder.layer_norm.weight"), G("answer_encoder.encoder.layer_norm.bias"), Ma, H, s,
+                                 enc.layers[L - 1].y2, relu_ks(), enc.layers[L - 1].gY));
         }
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
         RC(flush_wgrads(s, side[2], fj[8]));

@@ -79,8 +79,10 @@ int blt_conv_stem_direct(const void* x_padded, const void* w, void* y, int N, in
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                       long rows, int cols, float eps, hipStream_t s);
 // dx = LNbwd(dy) (+ dres if non-null); dgamma/dbeta are ACCUMULATED (+=) with float atomics
+// optional second output out2 = (maskY != 0) ? dx * mask_scale : 0 (the ReLU/dropout backward that consumes dx, fused)
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                      const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s);
+                      const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
+                      const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr);
 
 // BatchNorm2d (train mode) on NHWC: finalize partial sums -> scale/shift (+ running stat update)
 int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long count, const float* gamma,

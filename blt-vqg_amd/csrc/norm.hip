@@ -65,7 +65,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const T* dres,
                                                            T* dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, long rows, int cols) {
+                                                           float* __restrict__ dbeta, long rows, int cols,
+                                                           const T* __restrict__ maskY, float mask_scale, T* __restrict__ out2) {
     const int lane = threadIdx.x & 63;
     const int nch = cols >> 3;
     const int lpr = (nch <= 32) ? 32 : 64, rpw = 64 / lpr;
@@ -116,6 +117,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     for (int e = 0; e < 8; ++e) o[e] += r[e];
                 }
                 Vec8<T>::store(dx + row * cols + c * 8, o);
+                if (out2 != nullptr) {
+                    // the consumer of dx is a ReLU + dropout backward (the FFN output of the next layer down): emit its masked,
+                    // rescaled gradient here instead of in a launch of its own
+                    float mk[8];
+                    Vec8<T>::load(maskY + row * cols + c * 8, mk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (mk[e] != 0.f) ? o[e] * mask_scale : 0.f;
+                    Vec8<T>::store(out2 + row * cols + c * 8, o);
+                }
             }
         }
     }
@@ -462,7 +472,9 @@ int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 }
 
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
-                      const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s) {
+                      const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
+                      const void* maskY, float mask_scale, void* out2) {
+    BLT_REQUIRE((maskY == nullptr) == (out2 == nullptr), "layernorm_bwd: maskY and out2 go together");
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_bwd: bad dtype");
     BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_bwd: bad cols=%d", cols);
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
@@ -471,8 +483,8 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     if (grid > 512) grid = 512;
     if (grid < 1) grid = 1;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols),
-               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols));
+               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols, (const float*)maskY, mask_scale, (float*)out2),
+               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols, (const bf16*)maskY, mask_scale, (bf16*)out2));
     return blt_check_launch("layernorm_bwd");
 }
 

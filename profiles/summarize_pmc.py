@@ -29,11 +29,14 @@ def main():
         fh.write("kernel,launches,read_MB_per_launch(2xFETCH_SIZE),write_MB_per_launch\n")
         for r in rows:
             fh.write('"%s",%d,%.3f,%.3f\n' % r)
-    conv = [k for k in F if "gemm_dma_kernel" in k and (", 1>" in k or ", 2>" in k)]
+    # the convolution launches of the ResNet-18 stack: LDS-patch 3x3 kernel, direct stem kernel, implicit-GEMM kernel with the conv (1) or
+    # stem (2) loader (template arguments <BM, BN, LOADER, NST>)
+    import re
+    conv = [k for k in F if "conv3x3_pp_kernel" in k or "conv_stem_direct_kernel" in k or re.search(r"gemm_dma_kernel<\d+, \d+, [12], \d+>", k)]
     n = sum(len(F[k]) for k in conv)
     rd = 2.0 * sum(sum(F[k]) for k in conv) / n / 1024.0
     wr = sum(sum(W[k]) for k in conv if k in W) / max(1, sum(len(W[k]) for k in conv if k in W)) / 1024.0
-    json.dump({"kernel": "gemm_dma_kernel<*,*,conv|stem>", "launches_sampled": n, "read_MB_per_launch": round(rd, 2),
+    json.dump({"kernel": "conv3x3_pp_kernel + conv_stem_direct_kernel + gemm_dma_kernel<*,*,conv,*>", "launches_sampled": n, "read_MB_per_launch": round(rd, 2),
                "write_MB_per_launch": round(wr, 2), "traffic_MB_per_launch": round(rd + wr, 2),
                "note": "reads = 2 x FETCH_SIZE (gfx950 wide-load correction), writes = WRITE_SIZE; separate --pmc passes"},
               open(out + "_conv_traffic.json", "w"), indent=1)

@@ -124,7 +124,7 @@ def main():
     eng = StepEngine(c, dev)
     eng.allocate()
     init_reference_style(eng, seed=0)                      # same weights on every rank
-    step = DataParallelStep(eng, dist)
+    step = DataParallelStep(eng, dist, overlap_optimizer=True)
     from bltvqg_amd.trainer import shard_seed
     batch = synthetic.make_batch(B, cfg["vocab_size"], cfg["latent_dim"], seed=shard_seed(1234, rank))
     d = {k: v.to(dev) for k, v in batch.items() if k in ("images", "answers", "posteriors", "questions")}
@@ -159,6 +159,7 @@ def main():
         eng.profile_enable(on)
         profiled += int(on)
         one_step(a.warmup + i)
+    step.finish()                                           # the last (overlapped) optimiser update is part of the timed region
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

@@ -92,6 +92,8 @@ SIGNATURES = {
     "bltvqg_engine_loss_backward": (I, [P, F, P]),
     "bltvqg_engine_backward_external": (I, [P, P, P, F, P, P, P]),
     "bltvqg_engine_optimizer_step": (I, [P, F, F, F, F, F, P]),
+    "bltvqg_engine_optimizer_step_async": (I, [P, F, F, F, F, F, P]),
+    "bltvqg_engine_optimizer_wait": (I, [P, P]),
     "bltvqg_engine_read": (I, [P, I, P, P]),
     "bltvqg_engine_dropout_stream_id": (U32, [I, I, I]),
     "bltvqg_engine_profile_enable": (I, [P, I]),

@@ -122,6 +122,18 @@ struct bltvqg_engine {
     // chain's small latency-bound launches leave idle
     std::vector<GemmArgs> pending_wgrads;
     bool defer_wgrads = false;
+    // Asynchronous optimiser (bltvqg_engine_optimizer_step_async): gradient norm + clip + Adam run on their own stream behind the
+    // caller's stream (hence behind the gradient all-reduce the caller made that stream wait for), and the NEXT forward only makes
+    // the consumers of trainable parameters wait for them: the frozen CNN (45 % of a step) starts at once, hiding the optimiser and
+    // the tail of the all-reduce.  Every other entry point first orders itself behind the pending update (sync_opt).
+    hipStream_t opt_stream = nullptr;
+    hipEvent_t opt_fork = nullptr, opt_done = nullptr;
+    bool opt_pending = false;
+    int sync_opt(hipStream_t s) {
+        if (!opt_pending) return BLT_OK;
+        if (hipStreamWaitEvent(s, opt_done, 0) != hipSuccess) { blt_set_error("engine: optimiser wait failed"); return BLT_ERR_HIP; }
+        return BLT_OK;
+    }
     bool use_streams = true;
     int causal_mode = 1;       // 1 = training mask (pad OR future -> -1e18), 2 = prefix decoding (future keys excluded)
     bool bn_train = true;      // false: BatchNorm layers use their running statistics (module.eval(), greedy decoding)
@@ -677,6 +689,7 @@ struct bltvqg_engine {
             }
         // Head in fp32 (exact-fp32 MFMA on the fp32 master weights): BatchNorm1d removes the common mode of the pooled feature
         // across the batch, so bf16 rounding of these tiny [B,512]/[B,H] tensors would be amplified into the image feature.
+        RC(sync_opt(s));      // the head (fc + BatchNorm1d) is trainable: behind a pending asynchronous optimiser update
         RC(blt_avgpool_pp(dt, x, pooled, B, convs.back().Ho, convs.back().Wo, 512, 1, s));
         {
             const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
@@ -727,32 +740,33 @@ struct bltvqg_engine {
         BLT_REQUIRE(images && ctx && post && tgt, "engine_forward: null input");
         BLT_REQUIRE(!p2 || eps, "engine_forward: eps required in phase 2");
         phase2 = p2; seed = seed_; fwd_done = false;
-        if (hipMemsetAsync(stats, 0, 8 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
+        // with an optimiser update still in flight only the streams that read trainable parameters wait for it (below)
+        const bool overlap_opt = opt_pending && use_streams;
+        if (opt_pending && !overlap_opt) { RC(sync_opt(s)); opt_pending = false; }
+        // loss statistics [0..3]; [4] (gradient norm) belongs to the optimiser, which may still be reading it
+        if (hipMemsetAsync(stats, 0, 4 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
+        if (overlap_opt) {
+            // the frozen CNN does not depend on the update: it is enqueued first, everything else goes behind the optimiser
+            hipStream_t s0 = side[0];
+            RC(fork(s, s0, fj[0]));
+            RC(cnn_fwd(images, s));
+            RC(sync_opt(s0));
+            RC(forward_tokens(ctx, post, tgt, s0, s0));
+            RC(fork(s0, side[1], fj[1]));
+            RC(stack_fwd(enc, nullptr, nullptr, side[1]));
+            RC(stack_fwd(renc, nullptr, nullptr, s0));
+            RC(fork(s0, s, fj[2]));
+            RC(fork(side[1], s, fj[3]));
+            opt_pending = false;          // s is now ordered behind the update
+            return forward_tail(eps, s);
+        }
         // weight shadows
-        // bf16 shadows of every GEMM weight (plain + transposed) in one launch; biases / LayerNorm / embedding rows are read in fp32
-        if (dt == BLT_BF16 && !tlist.empty()) RC(blt_shadow_transpose(train, wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
-        if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
-        RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
-                           tgt32, ctx32, post32, counters, s));
+        hipStream_t s0 = use_streams ? side[0] : s, s1 = use_streams ? side[1] : s;
+        RC(forward_tokens(ctx, post, tgt, s, s0));
         // three independent sub-graphs until the image feature is injected: CNN (main) | embedding + posterior encoder (side 0) |
         // context encoder (side 1)
-        hipStream_t s0 = use_streams ? side[0] : s, s1 = use_streams ? side[1] : s;
-        if (use_streams) RC(fork(s, s0, fj[0]));
-        // shared embedding over the three token streams at once (iq.py:72-78): gather -> Linear(E,H) + bias + timing signal
-        RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Mtot, E, Epad, s0));
-        {
-            int ldw;
-            const void* w = W("embedding.1.weight", &ldw);
-            GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Mtot, H, E);
-            g.bias = P("embedding.1.bias");
-            g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
-            RC(blt_gemm(dt, g, s0));
-        }
-        enc.x_in = X_all; enc.key_ids = ctx32;
-        dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = tgt_shift;
-        renc.x_in = (char*)X_all + (size_t)(Ma + Mt) * H * es; renc.key_ids = post32;
         if (use_streams) RC(fork(s0, s1, fj[1]));
-        // the CNN is the long pole (2 ms of the step) and its ~90 launches take the host ~0.3 ms to enqueue: it goes first when the
+        // the CNN is the long pole (1.3 ms of the step) and its ~90 launches take the host ~0.3 ms to enqueue: it goes first when the
         // side streams exist, so that the GPU is not left waiting for it behind the (short) encoder stacks' enqueue
         if (use_streams) RC(cnn_fwd(images, s));
         RC(stack_fwd(enc, nullptr, nullptr, s1));
@@ -760,6 +774,36 @@ struct bltvqg_engine {
         RC(stack_fwd(renc, nullptr, nullptr, s0));
         if (!use_streams) RC(cnn_fwd(images, s));
         if (use_streams) { RC(fork(s0, s, fj[2])); RC(fork(s1, s, fj[3])); }
+        return forward_tail(eps, s);
+    }
+
+    // weight shadows, token preparation (on `s`), then the shared embedding of the three token streams (on `se`, forked from `s`
+    // unless they are the same stream)
+    int forward_tokens(const int64_t* ctx, const int64_t* post, const int64_t* tgt, hipStream_t s, hipStream_t se) {
+        // bf16 shadows of every GEMM weight (plain + transposed) in one launch; biases / LayerNorm / embedding rows are read in fp32
+        if (dt == BLT_BF16 && !tlist.empty()) RC(blt_shadow_transpose(train, wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
+        if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
+        RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
+                           tgt32, ctx32, post32, counters, s));
+        if (se != s) RC(fork(s, se, fj[0]));
+        // shared embedding over the three token streams at once (iq.py:72-78): gather -> Linear(E,H) + bias + timing signal
+        RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Mtot, E, Epad, se));
+        {
+            int ldw;
+            const void* w = W("embedding.1.weight", &ldw);
+            GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Mtot, H, E);
+            g.bias = P("embedding.1.bias");
+            g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
+            RC(blt_gemm(dt, g, se));
+        }
+        enc.x_in = X_all; enc.key_ids = ctx32;
+        dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = tgt_shift;
+        renc.x_in = (char*)X_all + (size_t)(Ma + Mt) * H * es; renc.key_ids = post32;
+        return BLT_OK;
+    }
+
+    // everything after the image feature exists: latent, decoder, vocabulary projection, reconstructor (all on `s`)
+    int forward_tail(const float* eps, hipStream_t s) {
         RC(blt_rows_add(dt, enc.out, (long)Sa * H, feats, H, nullptr, 0, B, H, 1, s));   // encoder_outputs[:,0] += image_features
         if (phase2) {
             if (hipMemcpyAsync(eps_dev, eps, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s) != hipSuccess) {
@@ -806,6 +850,7 @@ struct bltvqg_engine {
         BLT_REQUIRE(images && ctx && tokens && top_idx && top_val, "engine_decode_greedy: null pointer");
         BLT_REQUIRE(!p2 || eps, "engine_decode_greedy: eps required when the latent path is on");
         BLT_REQUIRE(c.attention_dropout == 0.f && c.relu_dropout == 0.f, "engine_decode_greedy: create the decode engine with dropout 0");
+        if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
         phase2 = p2; seed = 0; fwd_done = false;
         const bool saved_bn = bn_train, saved_streams = use_streams;
         bn_train = train_bn != 0; use_streams = false; causal_mode = 2;
@@ -1054,6 +1099,7 @@ struct bltvqg_engine {
 
     int loss_backward(float kl_weight, hipStream_t s) {
         BLT_REQUIRE(bound && fwd_done, "engine_loss_backward: forward has not run");
+        if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
         RC(zero_grads(s));
         // train_iq.py:81-103
         RC(blt_ce_fwd_bwd(dt, logits, ldV, tgt32, Mt, V, counters, 1.f, stats + 0, 1, s));
@@ -1069,6 +1115,7 @@ struct bltvqg_engine {
     int backward_external(const float* d_output, const float* d_zlogit, float d_kld, const float* d_feats_in, const float* d_recon_in,
                           hipStream_t s) {
         BLT_REQUIRE(bound && fwd_done, "engine_backward_external: forward has not run");
+        if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
         RC(zero_grads(s));
         if (d_output) RC(blt_cast_rows(BLT_F32, d_output, V, dt, logits, ldV, Mt, V, s));
         else if (hipMemsetAsync(logits, 0, (size_t)Mt * ldV * es, s) != hipSuccess) return BLT_ERR_HIP;
@@ -1083,8 +1130,24 @@ struct bltvqg_engine {
         return backward_core(d_kld, s);
     }
 
-    int optimizer_step(float lr, float max_norm, float b1, float b2, float eps, hipStream_t s) {
+    // async_: run on the engine's optimiser stream behind `s_in` (see opt_stream); the next forward orders itself behind the update
+    int optimizer_step(float lr, float max_norm, float b1, float b2, float eps, hipStream_t s_in, bool async_ = false) {
         BLT_REQUIRE(bound, "engine_optimizer_step: engine not bound");
+        if (opt_pending) { RC(sync_opt(s_in)); opt_pending = false; }
+        hipStream_t s = s_in;
+        if (async_) {
+            RC(fork(s_in, opt_stream, opt_fork));
+            s = opt_stream;
+        }
+        const int rc_ = optimizer_kernels(lr, max_norm, b1, b2, eps, s);
+        if (rc_) return rc_;
+        if (async_) {
+            if (hipEventRecord(opt_done, opt_stream) != hipSuccess) { blt_set_error("engine_optimizer_step: event record failed"); return BLT_ERR_HIP; }
+            opt_pending = true;
+        }
+        return BLT_OK;
+    }
+    int optimizer_kernels(float lr, float max_norm, float b1, float b2, float eps, hipStream_t s) {
         const int64_t n_main = late_off, n_late = tsize - late_off;
         if (hipMemsetAsync(stats + 4, 0, sizeof(float), s) != hipSuccess) return BLT_ERR_HIP;
         // the latent-phase parameters sit right behind the others in the flat buffers: one launch covers both regions when both are live
@@ -1127,6 +1190,9 @@ void bltvqg_engine_destroy(bltvqg_engine* e) {
     for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
     for (int i = 0; i < 12; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
     for (int i = 0; i < 4; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+    if (e->opt_stream) (void)hipStreamDestroy(e->opt_stream);
+    if (e->opt_fork) (void)hipEventDestroy(e->opt_fork);
+    if (e->opt_done) (void)hipEventDestroy(e->opt_done);
     for (size_t i = 0; i < e->prof_a.size(); ++i) { (void)hipEventDestroy(e->prof_a[i]); (void)hipEventDestroy(e->prof_b[i]); }
     delete e;
 }
@@ -1197,7 +1263,16 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
             blt_set_error("engine_bind: stream creation failed");
             return BLT_ERR_HIP;
         }
-    e->bound = true; e->frozen_dirty = true; e->fwd_done = false;
+    if (!e->opt_stream && hipStreamCreateWithFlags(&e->opt_stream, hipStreamNonBlocking) != hipSuccess) {
+        blt_set_error("engine_bind: stream creation failed");
+        return BLT_ERR_HIP;
+    }
+    if ((!e->opt_fork && hipEventCreateWithFlags(&e->opt_fork, hipEventDisableTiming) != hipSuccess) ||
+        (!e->opt_done && hipEventCreateWithFlags(&e->opt_done, hipEventDisableTiming) != hipSuccess)) {
+        blt_set_error("engine_bind: event creation failed");
+        return BLT_ERR_HIP;
+    }
+    e->bound = true; e->frozen_dirty = true; e->fwd_done = false; e->opt_pending = false;
     return BLT_OK;
 }
 
@@ -1236,10 +1311,22 @@ int bltvqg_engine_optimizer_step(bltvqg_engine* e, float lr, float max_norm, flo
     BLT_REQUIRE(e, "engine_optimizer_step: null engine");
     return e->optimizer_step(lr, max_norm, beta1, beta2, eps, (hipStream_t)stream);
 }
+int bltvqg_engine_optimizer_step_async(bltvqg_engine* e, float lr, float max_norm, float beta1, float beta2, float eps, void* stream) {
+    BLT_REQUIRE(e, "engine_optimizer_step_async: null engine");
+    return e->optimizer_step(lr, max_norm, beta1, beta2, eps, (hipStream_t)stream, true);
+}
+int bltvqg_engine_optimizer_wait(bltvqg_engine* e, void* stream) {
+    BLT_REQUIRE(e, "engine_optimizer_wait: null engine");
+    if (!e->opt_pending) return BLT_OK;
+    const int rc = e->sync_opt((hipStream_t)stream);
+    e->opt_pending = false;
+    return rc;
+}
 
 int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
     BLT_REQUIRE(e && e->bound && dst, "engine_read: bad args");
     hipStream_t s = (hipStream_t)stream;
+    if (e->opt_pending) { const int rc_ = e->sync_opt(s); if (rc_) return rc_; }     // stats[4] / parameters of a pending update
     switch (what) {
         case 0: return blt_cast_rows(e->dt, e->logits, e->ldV, BLT_F32, dst, e->V, e->Mt, e->V, s);
         case 1: return blt_cast_rows(e->dt, e->zlogit, e->ldV, BLT_F32, dst, e->V, e->B, e->V, s);

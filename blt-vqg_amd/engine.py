@@ -154,9 +154,16 @@ class StepEngine(object):
         check(self.lib.bltvqg_engine_backward_external(self.h, ptr(d_output), ptr(d_zlogit), float(d_kld), ptr(d_feats), ptr(d_recon),
                                                        stream_ptr()), "engine_backward_external")
 
-    def optimizer_step(self, lr, max_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-8):
-        check(self.lib.bltvqg_engine_optimizer_step(self.h, float(lr), float(max_norm), float(beta1), float(beta2), float(eps),
-                                                    stream_ptr()), "engine_optimizer_step")
+    def optimizer_step(self, lr, max_norm=5.0, beta1=0.9, beta2=0.999, eps=1e-8, overlap=False):
+        """clip_grad_norm_(max_norm) + Adam.  overlap=True enqueues the update on the engine's optimiser stream: the next forward()
+        starts its frozen CNN at once and only the parameter consumers wait; call optimizer_wait() before reading the flat
+        parameter / moment tensors on the current stream."""
+        fn = self.lib.bltvqg_engine_optimizer_step_async if overlap else self.lib.bltvqg_engine_optimizer_step
+        check(fn(self.h, float(lr), float(max_norm), float(beta1), float(beta2), float(eps), stream_ptr()), "engine_optimizer_step")
+
+    def optimizer_wait(self):
+        """Orders the current stream behind a pending overlapped optimiser update (no-op otherwise)."""
+        check(self.lib.bltvqg_engine_optimizer_wait(self.h, stream_ptr()), "engine_optimizer_wait")
 
     _READ_SHAPES = {0: lambda c: (c.batch, c.len_target, c.vocab_size), 1: lambda c: (c.batch, c.vocab_size),
                     2: lambda c: (c.batch, c.hidden_dim), 3: lambda c: (c.batch, c.hidden_dim), 4: lambda c: (8,),

@@ -91,9 +91,12 @@ def shard_seed(base_seed, rank):
 class DataParallelStep(object):
     """forward -> fused losses + backward -> (overlapped gradient all-reduce) -> clip + Adam."""
 
-    def __init__(self, engine, dist=None):
+    def __init__(self, engine, dist=None, overlap_optimizer=False):
         self.e = engine
         self.dist = dist
+        # clip + Adam (and, behind it, the tail of the gradient all-reduce) overlapped with the next step's frozen CNN
+        # (StepEngine.optimizer_step(overlap=True)); call finish() before reading parameters
+        self.overlap_optimizer = overlap_optimizer
         self.comm = torch.cuda.Stream(device=engine.device) if dist is not None else None
         self.buckets = engine.buckets()
         if dist is not None:
@@ -108,7 +111,8 @@ class DataParallelStep(object):
             e.bucket_wait(i, self.comm)          # the side stream waits for the engine's "bucket i is final" event
             with torch.cuda.stream(self.comm):
                 allreduce_bucket(dist, e.flat_grad, off, n)
-        main.wait_stream(self.comm)
+        if not self.overlap_optimizer:
+            main.wait_stream(self.comm)
 
     def run(self, images, context, posterior, target, eps, phase2, seed, kl_weight, lr, max_norm=5.0):
         e = self.e
@@ -116,4 +120,13 @@ class DataParallelStep(object):
         e.loss_backward(kl_weight)
         if self.dist is not None:
             self.reduce_gradients(phase2)
-        e.optimizer_step(lr, max_norm)
+        if self.dist is not None and self.overlap_optimizer:
+            # the update is forked from the COMMUNICATION stream (behind the all-reduces); the main stream never waits for them, the
+            # next forward's parameter consumers wait for the update
+            with torch.cuda.stream(self.comm):
+                e.optimizer_step(lr, max_norm, overlap=True)
+        else:
+            e.optimizer_step(lr, max_norm, overlap=self.overlap_optimizer)
+
+    def finish(self):
+        self.e.optimizer_wait()

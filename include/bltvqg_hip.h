@@ -216,6 +216,14 @@ int bltvqg_engine_backward_external(bltvqg_engine* e, const float* d_output, con
 /* clip_grad_norm_(max_norm) + Adam over the regions that received gradients this step. */
 int bltvqg_engine_optimizer_step(bltvqg_engine* e, float lr, float max_norm, float beta1, float beta2, float eps,
                                  void* stream);
+/* The same update enqueued on the engine's own optimiser stream, ordered behind everything enqueued on `stream` so far (e.g. the
+ * gradient all-reduce that `stream` was made to wait for).  `stream` itself does NOT wait for it: the next bltvqg_engine_forward
+ * lets the frozen CNN start at once and makes only the consumers of trainable parameters wait, which hides the update and the tail
+ * of the all-reduce behind ~45 % of the next step; every other engine call orders itself behind the update first.  A caller that
+ * reads the parameter / moment buffers itself must call bltvqg_engine_optimizer_wait(stream) before doing so on `stream`. */
+int bltvqg_engine_optimizer_step_async(bltvqg_engine* e, float lr, float max_norm, float beta1, float beta2, float eps,
+                                       void* stream);
+int bltvqg_engine_optimizer_wait(bltvqg_engine* e, void* stream);
 /* outputs, converted to contiguous fp32: what = 0 output [B,T,V], 1 z_logit [B,V], 2 image_features [B,H],
  * 3 reconstructed [B,H], 4 stats float[8] = {loss_rec, loss_img, kld, loss_aux, grad_norm_sq, n_targets, 0, 0},
  * 5 encoder_outputs [B,S_a,H], 6 decoder_outputs [B,T,H] */

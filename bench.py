@@ -19,6 +19,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# HIP multiplexes streams onto 4 hardware queues by default; the step uses the main stream, two engine side streams and (N > 1) the
+# trainer's communication stream plus RCCL's own: with 8 queues none of them is silently serialised behind another
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 

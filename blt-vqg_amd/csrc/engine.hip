@@ -114,8 +114,11 @@ struct bltvqg_engine {
     hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
     // side streams: independent sub-graphs (CNN | posterior encoder | context encoder) run concurrently so that their small
     // launches (40-160 workgroups each) fill the 256 CUs together; fork/join with events (capturable into a hipGraph)
-    // side[2], side[3]: weight-gradient streams (see flush_wgrads)
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Only TWO side streams: HIP multiplexes streams onto 4 hardware queues by default, and a stream that shares a queue with the main
+    // stream is silently serialised behind it (seen: the encoder stacks running after the CNN instead of beside it once the trainer's
+    // communication streams were added).  side[0]: posterior encoder (forward and backward); side[1]: context encoder (forward), the
+    // deferred weight-gradient GEMMs (backward) and the asynchronous optimiser update.
+    hipStream_t side[2] = {nullptr, nullptr};
     hipEvent_t fj[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     // weight-gradient GEMMs of the transformer stacks are off the critical path of backward (nothing downstream reads dW): they are
     // collected while a stack's input-gradient chain is enqueued and then issued on a side stream, where they fill the CUs that the
@@ -997,10 +1000,10 @@ struct bltvqg_engine {
         }
         defer_wgrads = use_streams;
         RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
-        // the decoder's weight gradients run on side[2] from here on, under the rest of backward; bucket 0 (decoder.*) is complete when
+        // the decoder's weight gradients run on side[1] from here on, under the rest of backward; bucket 0 (decoder.*) is complete when
         // that stream gets here
-        RC(flush_wgrads(s, side[2], fj[6]));
-        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], use_streams ? side[2] : s);
+        RC(flush_wgrads(s, side[1], fj[6]));
+        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], use_streams ? side[1] : s);
         // target_embedding[:,0] += image_features (+ z)
         RC(blt_rows_add(dt, d_feats, H, dxT, (long)T * H, nullptr, 0, B, H, 1, s));
         if (phase2) RC(blt_rows_add(dt, d_zproj, H, dxT, (long)T * H, nullptr, 0, B, H, 0, s));
@@ -1047,7 +1050,7 @@ struct bltvqg_engine {
                                  G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s0,
                                  renc.layers[L - 1].y2, relu_ks(), renc.layers[L - 1].gY));
             RC(stack_bwd(renc, dxP, nullptr, nullptr, s0));
-            RC(flush_wgrads(s0, side[3], fj[7]));
+            RC(flush_wgrads(s0, side[1], fj[7]));
             Memb = Mtot;
         }
         // ---- context encoder (main stream) ----
@@ -1058,7 +1061,7 @@ struct bltvqg_engine {
                                  enc.layers[L - 1].y2, relu_ks(), enc.layers[L - 1].gY));
         }
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
-        RC(flush_wgrads(s, side[2], fj[8]));
+        RC(flush_wgrads(s, side[1], fj[8]));
         defer_wgrads = false;
         if (s0 != s) RC(fork(s0, s, fj[5]));
         // ---- shared embedding (rows of the streams that received gradient) ----
@@ -1083,10 +1086,7 @@ struct bltvqg_engine {
             RC(blt_gemm(BLT_F32, g, s));
             RC(blt_colsum(BLT_F32, dfeatpre32, H, B, H, G("encoder_cnn.cnn.fc.bias"), 1, s));
         }
-        if (use_streams) {      // join the weight-gradient streams
-            RC(fork(side[2], s, fj[9]));
-            if (phase2) RC(fork(side[3], s, fj[10]));
-        }
+        if (use_streams) RC(fork(side[1], s, fj[9]));      // join the weight-gradient stream
         if (bucket_ev[1]) (void)hipEventRecord(bucket_ev[1], s);
         if (bucket_ev[2]) (void)hipEventRecord(bucket_ev[2], s);
         last_bwd_phase2 = phase2;
@@ -1189,8 +1189,7 @@ void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (!e) return;
     for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
     for (int i = 0; i < 12; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
-    for (int i = 0; i < 4; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
-    if (e->opt_stream) (void)hipStreamDestroy(e->opt_stream);
+    for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
     if (e->opt_fork) (void)hipEventDestroy(e->opt_fork);
     if (e->opt_done) (void)hipEventDestroy(e->opt_done);
     for (size_t i = 0; i < e->prof_a.size(); ++i) { (void)hipEventDestroy(e->prof_a[i]); (void)hipEventDestroy(e->prof_b[i]); }
@@ -1258,15 +1257,12 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
             blt_set_error("engine_bind: event creation failed");
             return BLT_ERR_HIP;
         }
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
         if (!e->side[i] && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) {
             blt_set_error("engine_bind: stream creation failed");
             return BLT_ERR_HIP;
         }
-    if (!e->opt_stream && hipStreamCreateWithFlags(&e->opt_stream, hipStreamNonBlocking) != hipSuccess) {
-        blt_set_error("engine_bind: stream creation failed");
-        return BLT_ERR_HIP;
-    }
+    e->opt_stream = e->side[1];
     if ((!e->opt_fork && hipEventCreateWithFlags(&e->opt_fork, hipEventDisableTiming) != hipSuccess) ||
         (!e->opt_done && hipEventCreateWithFlags(&e->opt_done, hipEventDisableTiming) != hipSuccess)) {
         blt_set_error("engine_bind: event creation failed");

@@ -27,6 +27,17 @@ int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int l
     return blt_gemm(dtype, g, (hipStream_t)stream);
 }
 
+int bltvqg_linear_layernorm(const void* X, int ldx, const void* W, int ldw, const float* bias, int relu, float drop_p, uint64_t seed,
+                            uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, void* C, int ldc, const float* ln_gamma,
+                            const float* ln_beta, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd, int M, int N, int K, void* stream) {
+    BLT_REQUIRE(X && W && C && ln_out, "linear_layernorm: null pointer");
+    GemmArgs g;
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id; g.C2 = C2; g.ldc2 = ldc2; g.R = R; g.ldr = ldr;
+    g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_eps = ln_eps; g.ln_out = ln_out; g.ln_mean = ln_mean; g.ln_rstd = ln_rstd;
+    return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
+}
+
 static GemmArgs conv_args(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     GemmArgs g;
     const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;

@@ -541,25 +541,53 @@ struct bltvqg_engine {
         return blt_attn_bwd(dt, a, s);
     }
 
-    int ffn_fwd(const std::string& fp_, const void* xn, const void* xres, Layer& y, int M, int stack, int l, hipStream_t s) {
+    // A LayerNorm that directly follows a Linear of the stacks CAN run inside that GEMM's epilogue when a workgroup owns whole rows
+    // (bf16, d_model <= 256; gemm_dma_ln_kernel): set_ln() attaches it, ln_fused() tells the caller to skip its own launch.  Measured
+    // on the B=128 step it does not pay: every workgroup then streams the whole weight matrix, and what the 14 saved launches give
+    // (~5 us each) the slower GEMMs take back (2.91 vs 2.89 ms with 32-row tiles, 2.96 ms with 64-row tiles) — so it is off unless
+    // debug key 7 is 3 (A/B switch); the operator stays exported (bltvqg_linear_layernorm) and tested.
+    bool ln_fused() const { return blt_debug_get(7) == 3 && dt == BLT_BF16 && H <= 256 && H % 8 == 0; }
+    void set_ln(GemmArgs& g, const std::string& ln, void* out, float* m, float* r) {
+        g.ln_gamma = P(ln + ".weight"); g.ln_beta = P(ln + ".bias"); g.ln_out = out; g.ln_mean = m; g.ln_rstd = r; g.ln_eps = 1e-5f;
+    }
+    struct NextLN { std::string name; void* out = nullptr; float *m = nullptr, *r = nullptr; };
+
+    // x2 = xres + dropout(relu(W2 dropout(relu(W1 xn + b1)) + b2)); `next` = the LayerNorm that consumes x2 (next layer's first one or
+    // the stack's final one)
+    int ffn_fwd(const std::string& fp_, const void* xn, const void* xres, Layer& y, int M, int stack, int l, const NextLN& next, hipStream_t s) {
         GemmArgs g = lin(xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, F, M);
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 1);
         RC(blt_gemm(dt, g, s));
         g = lin(y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), y.x2, H, M);
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 2);
         g.C2 = y.y2; g.ldc2 = H; g.R = xres; g.ldr = H;
-        return blt_gemm(dt, g, s);
+        if (ln_fused()) set_ln(g, next.name, next.out, next.m, next.r);
+        RC(blt_gemm(dt, g, s));
+        if (!ln_fused()) RC(blt_layernorm_fwd(dt, y.x2, P(next.name + ".weight"), P(next.name + ".bias"), next.out, next.m, next.r, M, H, 1e-5f, s));
+        return BLT_OK;
     }
 
     int stack_fwd(Stack& st, const void* enc_out, const int* src_ids, hipStream_t s) {
         const int M = st.M, S = st.S;
         const void* x = st.x_in;
+        auto lname = [&](int l) { return st.prefix + (st.dec ? ".dec." : ".enc.") + std::to_string(l) + "."; };
+        {   // the first LayerNorm reads the shared embedding's output: a launch of its own
+            const std::string ln1 = lname(0) + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
+            Layer& y0 = st.layers[0];
+            RC(blt_layernorm_fwd(dt, x, P(ln1 + ".weight"), P(ln1 + ".bias"), y0.xn1, y0.m1, y0.r1, M, H, 1e-5f, s));
+        }
         for (int l = 0; l < L; ++l) {
             Layer& y = st.layers[l];
-            const std::string lp = st.prefix + (st.dec ? ".dec." : ".enc.") + std::to_string(l) + ".";
+            const std::string lp = lname(l);
             const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
-            const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
-            RC(blt_layernorm_fwd(dt, x, P(ln1 + ".weight"), P(ln1 + ".bias"), y.xn1, y.m1, y.r1, M, H, 1e-5f, s));
+            // the LayerNorm behind this layer's FFN: the next layer's first one, or the stack's final one
+            NextLN next;
+            if (l + 1 < L) {
+                next.name = lname(l + 1) + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
+                next.out = st.layers[l + 1].xn1; next.m = st.layers[l + 1].m1; next.r = st.layers[l + 1].r1;
+            } else {
+                next.name = st.prefix + ".layer_norm"; next.out = st.out; next.m = st.mF; next.r = st.rF;
+            }
             // fused QKV projection: query/key/value weights are adjacent in the flat buffer -> one [3H,H] operand
             {
                 int ldw;
@@ -569,16 +597,16 @@ struct bltvqg_engine {
             }
             RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
                         st.dec ? causal_mode : 0, sid(st.id, l, 0), s));
+            const std::string ln2 = lp + (st.dec ? "layer_norm_mha_enc" : "layer_norm_ffn");
             {
                 GemmArgs g = lin(y.ctx, H, a1 + "output_linear.weight", nullptr, y.x1, H, M);
                 g.R = x; g.ldr = H;
+                if (ln_fused()) set_ln(g, ln2, y.xn2, y.m2, y.r2);
                 RC(blt_gemm(dt, g, s));
+                if (!ln_fused()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
             }
-            const void* xr = y.x1;
             if (st.dec) {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
-                const std::string ln2 = lp + "layer_norm_mha_enc";
-                RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
                 RC(blt_gemm(dt, lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M), s));
                 {
                     int ldw;
@@ -586,21 +614,19 @@ struct bltvqg_engine {
                     RC(blt_gemm(dt, mk(enc_out, H, 0, w, ldw, 0, y.kv2, 2 * H, Ma, 2 * H, H), s));
                 }
                 RC(attn_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, src_ids, S, Sa, 0, sid(st.id, l, 3), s));
+                const std::string ln3 = lp + "layer_norm_ffn";
                 GemmArgs g = lin(y.ctx2, H, a2 + "output_linear.weight", nullptr, y.x1b, H, M);
                 g.R = y.x1; g.ldr = H;
+                if (ln_fused()) set_ln(g, ln3, y.xn3, y.m3, y.r3);
                 RC(blt_gemm(dt, g, s));
-                const std::string ln3 = lp + "layer_norm_ffn";
-                RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s));
-                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y, M, st.id, l, s));
+                if (!ln_fused()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y, M, st.id, l, next, s));
             } else {
-                const std::string ln2 = lp + "layer_norm_ffn";
-                RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
-                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn2, xr, y, M, st.id, l, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y, M, st.id, l, next, s));
             }
             x = y.x2;
         }
-        const std::string lnf = st.prefix + ".layer_norm";
-        return blt_layernorm_fwd(dt, x, P(lnf + ".weight"), P(lnf + ".bias"), st.out, st.mF, st.rF, M, H, 1e-5f, s);
+        return BLT_OK;
     }
 
     int conv_fwd(ConvSpec& cs, const void* x, hipStream_t s) {

@@ -720,6 +720,191 @@ extern "C" int bltvqg_debug_read_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------------------------------------
+// Linear (+ bias / ReLU / dropout / residual) with the FOLLOWING LayerNorm fused in: tile 32 rows x 256 columns, so that a workgroup
+// owns complete rows (N <= 256); the four waves sit side by side (each 32 x 64), same LDS-DMA ring as above (3 stages of 4 KB A +
+// 32 KB B).  Every workgroup streams the whole weight matrix, so the row tile is kept small: 84 workgroups at 2.6 k rows (with 64-row
+// tiles only 42 CUs pulled 160-320 KB each and the fused launch was slower than GEMM + LayerNorm).  The stacks' LayerNorms all read the output of such a Linear; as separate launches they were 14 of the ~250 dependent
+// launches of a step, each with its ~5 us launch-to-launch floor.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_dma_ln_kernel(const GemmArgs p) {
+    constexpr int BM = 32, BN = 256, BK = 64, NST = 3, AHEAD = 2;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int CH_A = BM * 8 / 256, CH_B = BN * 8 / 256, PER_TILE = CH_A + CH_B;
+    constexpr int TM = BM / 16, TN = 4, CS = BN + 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.x * BM;
+    const bf16* __restrict__ Ag = (const bf16*)p.A;
+    const bf16* __restrict__ Bg = (const bf16*)p.B;
+    const void* zero = (const void*)g_zero_page;
+
+    long a_off[CH_A], b_off[CH_B];
+    int a_gk[CH_A], b_gk[CH_B];
+#pragma unroll
+    for (int j = 0; j < CH_A; ++j) {
+        const int c = (j * 4 + wave) * 64 + lane;
+        const int row = c >> 3, gc = (c & 7) ^ (row & 7);
+        a_gk[j] = gc * 8;
+        a_off[j] = (m0 + row < p.M) ? (long)(m0 + row) * p.lda + gc * 8 : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < CH_B; ++j) {
+        const int c = (j * 4 + wave) * 64 + lane;
+        const int row = c >> 3, gc = (c & 7) ^ (row & 7);
+        b_gk[j] = gc * 8;
+        b_off[j] = (row < p.N) ? (long)row * p.ldb + gc * 8 : -1;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* a_st = smem + stage * STAGE;
+        char* b_st = a_st + A_BYTES;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int j = 0; j < CH_A; ++j) {
+            const bool ok = (a_off[j] >= 0) && (k0 + a_gk[j] < p.K);
+            dma16(ok ? (const void*)(Ag + a_off[j] + k0) : zero, a_st + (j * 4 + wave) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < CH_B; ++j) {
+            const bool ok = (b_off[j] >= 0) && (k0 + b_gk[j] < p.K);
+            dma16(ok ? (const void*)(Bg + b_off[j] + k0) : zero, b_st + (j * 4 + wave) * 1024);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nk = (p.K + BK - 1) / BK;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt<PER_TILE>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + AHEAD < nk) issue(kt + AHEAD, (kt + AHEAD) % NST);
+        const char* a_st = smem + (kt % NST) * STAGE;
+        const char* b_st = a_st + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM], bfr[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = i * 16 + l15;
+                af[i] = *reinterpret_cast<const bf16x8*>(a_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wave * 64 + j * 16 + l15;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(i * 16 + lg * 4 + r) * CS + wave * 64 + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+
+    // ---- epilogue: 32 column groups of 8 per row -> half a wave per row, 8 rows per pass, 8 passes; the row statistics are 32-lane
+    // butterflies.  Same term order as gemm_epilogue (bias, ReLU, dropout, C2 copy, residual), then LayerNorm of the ROUNDED result.
+    const int cgp = tid & 31, row0 = tid >> 5;
+    const int n = cgp * 8;
+    const bool colok = n < p.N;              // N is a multiple of 8 (checked on the host)
+    static_assert(BM % 8 == 0, "8 rows per epilogue pass");
+    const uint32_t thresh = dropout_threshold(p.drop_p);
+    const float keep_scale = (p.drop_p > 0.f) ? 1.f / (1.f - p.drop_p) : 1.f;
+    const int drop_ld = (p.N + 7) & ~7;
+    float bias[8], gam[8], bet[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bias[e] = 0.f; gam[e] = 0.f; bet[e] = 0.f; }
+    if (colok) {
+        if (p.bias) Vec8<float>::load(p.bias + n, bias);
+        Vec8<float>::load(p.ln_gamma + n, gam);
+        Vec8<float>::load(p.ln_beta + n, bet);
+    }
+    const float inv_n = 1.f / (float)p.N;
+#pragma unroll
+    for (int i = 0; i < BM / 8; ++i) {
+        const int row = row0 + i * 8, m = m0 + row;
+        const bool ok = colok && m < p.M;
+        float v[8], t[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (ok) {
+            const float4 x0 = *reinterpret_cast<const float4*>(&Cs[row * CS + n]);
+            const float4 x1 = *reinterpret_cast<const float4*>(&Cs[row * CS + n + 4]);
+            v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.drop_p > 0.f) {
+                uint32_t w[4];
+                dropout_words(p.seed, p.stream_id, ((uint64_t)m * (uint64_t)drop_ld + (uint64_t)n) >> 3, w);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (dropout_lane(w, e) >= thresh) ? v[e] * keep_scale : 0.f;
+            }
+            if (p.C2) Vec8<bf16>::store((bf16*)p.C2 + (size_t)m * p.ldc2 + n, v);
+            if (p.R) {
+                Vec8<bf16>::load((const bf16*)p.R + (size_t)m * p.ldr + n, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += t[e];
+            }
+            Vec8<bf16>::store((bf16*)p.C + (size_t)m * p.ldc + n, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)(bf16)v[e];       // what a LayerNorm launch would read back
+        }
+        float s1 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s1 += v[e];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mu = s1 * inv_n;
+        float q = 0.f;
+        if (colok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q += d * d; }
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+        const float rs = rsqrtf(q * inv_n + p.ln_eps);
+        if (ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (v[e] - mu) * rs * gam[e] + bet[e];
+            Vec8<bf16>::store((bf16*)p.ln_out + (size_t)m * p.N + n, t);
+            if (cgp == 0) { p.ln_mean[m] = mu; p.ln_rstd[m] = rs; }
+        }
+    }
+}
+
+int launch_dma_ln(const GemmArgs& a, hipStream_t stream) {
+    constexpr int LDS = 3 * (32 * 128 + 256 * 128);
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_dma_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            blt_set_error("gemm: hipFuncSetAttribute(%d) failed", LDS);
+            return BLT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_dma_ln_kernel, dim3(cdiv(a.M, 32)), dim3(256), LDS, stream, a);
+    return blt_check_launch("gemm_dma_ln");
+}
+
 template <int BM, int BN, int LOADER, int NST>
 int launch_dma(const GemmArgs& a, hipStream_t stream) {
     typedef DmaCfg<BM, BN, LOADER, NST> C;
@@ -927,6 +1112,14 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
                 (!a.rowtab || ((uintptr_t)a.rowtab % 16) == 0), "gemm: epilogue operands must be 16-byte aligned");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
     BLT_REQUIRE(!a.a_rowsum || (a.transA && !a.is_conv), "gemm: a_rowsum needs the transA (weight-gradient) form");
+    if (a.ln_out != nullptr) {
+        BLT_REQUIRE(dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv, "gemm: the fused LayerNorm needs bf16 k-contiguous operands");
+        BLT_REQUIRE(a.N <= 256 && a.N % 8 == 0 && a.ln_gamma && a.ln_beta && a.ln_mean && a.ln_rstd, "gemm: fused LayerNorm needs N <= 256, N %% 8 == 0 (N=%d)", a.N);
+        BLT_REQUIRE(!a.out_f32 && !a.accumulate && !a.maskY && !a.rowtab && !a.stat_sum && a.split_k == 0, "gemm: epilogue term not supported with the fused LayerNorm");
+        BLT_REQUIRE(a.ldc % 8 == 0 && (!a.R || a.ldr % 8 == 0) && (!a.C2 || a.ldc2 % 8 == 0) && (!a.bias || ((uintptr_t)a.bias % 16) == 0) &&
+                    ((uintptr_t)a.ln_gamma % 16) == 0 && ((uintptr_t)a.ln_beta % 16) == 0 && ((uintptr_t)a.ln_out % 16) == 0, "gemm: fused LayerNorm operands must be 16-byte aligned");
+        return launch_dma_ln(a, stream);
+    }
     const int splits = blt_gemm_splits(a, dtype);
     if (g_debug[2] && splits == 1 && !a.accumulate && !a.force_tile && g_tuned.find(tune_key(a, dtype)) == g_tuned.end()) {
         int rc = autotune(dtype, a, stream);

@@ -56,6 +56,16 @@ struct GemmArgs {
     ConvGeom cg = {};
     int force_tile = 0;          // 0 = heuristic, 64 or 128
     float* a_rowsum = nullptr;   // transA only: a_rowsum[m] += sum_k op(A)[m,k]  (bias gradient of the weight-gradient form, float atomics)
+    // Fused LayerNorm of the result rows (bf16, k-contiguous operands, N <= 256 so that one workgroup owns whole rows): after the
+    // epilogue above has produced C (rounded to bf16, as a separate LayerNorm launch would read it), ln_out = LN(C) * ln_gamma + ln_beta
+    // and the row statistics are written as well (transformer_layers.py:134,202,256-257,320-322: every LayerNorm of the stacks reads
+    // the output of a Linear + residual)
+    const float* ln_gamma = nullptr;
+    const float* ln_beta = nullptr;
+    void* ln_out = nullptr;
+    float* ln_mean = nullptr;
+    float* ln_rstd = nullptr;
+    float ln_eps = 1e-5f;
 };
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)

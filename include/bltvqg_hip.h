@@ -57,6 +57,15 @@ int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, in
 int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* dbias, int rows,
                         int N, int K, int split_k, void* stream);
 
+/* bf16 Linear with the FOLLOWING LayerNorm in its epilogue (every LayerNorm of the transformer stacks reads the output of a Linear +
+ * residual, transformer_layers.py:134,202,256-257,320-322): C = [dropout(relu(]X W^T + bias[))] (copied to C2 if non-null) + R, rounded
+ * to bf16, then ln_out = LayerNorm(C) * ln_gamma + ln_beta with the row statistics in ln_mean / ln_rstd.  One workgroup owns whole rows:
+ * N <= 256, N % 8 == 0; X [M,ldx], W [N,ldw] k-contiguous. */
+int bltvqg_linear_layernorm(const void* X, int ldx, const void* W, int ldw, const float* bias, int relu, float drop_p, uint64_t seed,
+                            uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, void* C, int ldc, const float* ln_gamma,
+                            const float* ln_beta, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd, int M, int N, int K,
+                            void* stream);
+
 /* NHWC implicit-GEMM convolution y[N,Ho,Wo,Cout] = conv(x[N,Hi,Wi,Cin], w[Cout,KH,KW,Cin]); Cin a power of two >= 8 (bf16)
  * / 4 (fp32).  stat_sum/stat_sq (optional): per-half-tile column partial sums, bltvqg_conv2d_stat_rows() rows of Cout. */
 int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW,

@@ -616,3 +616,42 @@ def test_padded_pitch_elementwise_ops(dtype):
     ref = F.max_pool2d(zr, 3, 2, 1).permute(0, 2, 3, 1)
     assert (pview[:, :Ho, :Wo].float().cpu() - ref).abs().max() < tol * max(1.0, float(ref.abs().max()))
     assert float(pview[:, Ho].abs().max()) == 0.0 and float(pview[:, :, Wo].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2688, 256, 256, True, True), (640, 256, 512, True, False), (77, 200, 96, False, True), (64, 256, 1024, False, False)])
+def test_linear_with_fused_layernorm(shape):
+    """Linear (+bias, +residual) with the following LayerNorm in the GEMM epilogue: C must equal the plain GEMM bit for bit on integer
+    operands, the normalised output / statistics must match LayerNorm of that bf16 C."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    lib = G.lib()
+    M, N, K, use_bias, use_res = shape
+    g = torch.Generator().manual_seed(M + N)
+    X = _ints((M, K), -2, 2, g, torch.float32)
+    W = _ints((N, K), -1, 1, g, torch.float32)
+    bias = _ints((N,), -3, 3, g, torch.float32) if use_bias else None
+    R = _ints((M, N), -4, 4, g, torch.float32) if use_res else None
+    gamma, beta = torch.rand(N, generator=g) + 0.5, torch.randn(N, generator=g)
+    Xd, Wd = X.bfloat16().cuda(), W.bfloat16().cuda()
+    Rd = R.bfloat16().cuda() if use_res else None
+    bd = bias.cuda() if use_bias else None
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
+    gd, btd = gamma.cuda(), beta.cuda()
+    check(lib.bltvqg_linear_layernorm(ptr(Xd), K, ptr(Wd), K, ptr(bd), 0, 0.0, 0, 0, None, 0, ptr(Rd), N, ptr(C), N, ptr(gd), ptr(btd), 1e-5,
+                                      ptr(out), ptr(mean), ptr(rstd), M, N, K, stream_ptr()), "linear_layernorm")
+    torch.cuda.synchronize()
+    ref = X @ W.t()
+    if use_bias:
+        ref = ref + bias
+    if use_res:
+        ref = ref + R
+    refb = ref.bfloat16()
+    assert torch.equal(C.cpu(), refb)
+    ln = F.layer_norm(refb.float(), (N,), gamma, beta, 1e-5)
+    assert (out.float().cpu() - ln).abs().max() < 2e-2 * max(1.0, float(ln.abs().max()))
+    mu = refb.float().mean(1)
+    var = refb.float().var(1, unbiased=False)
+    assert (mean.cpu() - mu).abs().max() < 1e-4 * max(1.0, float(mu.abs().max()))
+    assert ((rstd.cpu() - (var + 1e-5).rsqrt()).abs() / (var + 1e-5).rsqrt()).max() < 1e-4

@@ -198,7 +198,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
-                         "kernel": "gemm_kernel<bf16,*,*,conv> (implicit-GEMM conv of the ResNet-18 stack)",
+                         "kernel": "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), "
+                                   "conv_stem_direct_kernel (1), gemm_dma_kernel<*,*,conv,*> (6: stride-2 / 1x1)",
                          "launches_per_step": conv_launches // max(profiled, 1),
                          "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
                          "profiled_steps": "%d of the %d timed steps (every %dth) carry the HIP events" % (profiled, a.steps, PROFILE_EVERY),

@@ -1076,7 +1076,10 @@ struct bltvqg_engine {
                                  G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s0,
                                  renc.layers[L - 1].y2, relu_ks(), renc.layers[L - 1].gY));
             RC(stack_bwd(renc, dxP, nullptr, nullptr, s0));
-            RC(flush_wgrads(s0, side[1], fj[7]));
+            // the main stream will join s0 at THIS point (it needs the chain's result for the embedding backward); the posterior
+            // encoder's weight gradients then run on s0 behind it, beside the context encoder's on side[1], and are joined at the very end
+            if (s0 != s && hipEventRecord(fj[5], s0) != hipSuccess) { blt_set_error("backward: event record failed"); return BLT_ERR_HIP; }
+            RC(flush_wgrads(s0, s0 != s ? s0 : side[1], fj[7]));
             Memb = Mtot;
         }
         // ---- context encoder (main stream) ----
@@ -1089,7 +1092,7 @@ struct bltvqg_engine {
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
         RC(flush_wgrads(s, side[1], fj[8]));
         defer_wgrads = false;
-        if (s0 != s) RC(fork(s0, s, fj[5]));
+        if (s0 != s && hipStreamWaitEvent(s, fj[5], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
         // ---- shared embedding (rows of the streams that received gradient) ----
         {
             const PInfo& pw = tpi("embedding.1.weight");
@@ -1112,7 +1115,10 @@ struct bltvqg_engine {
             RC(blt_gemm(BLT_F32, g, s));
             RC(blt_colsum(BLT_F32, dfeatpre32, H, B, H, G("encoder_cnn.cnn.fc.bias"), 1, s));
         }
-        if (use_streams) RC(fork(side[1], s, fj[9]));      // join the weight-gradient stream
+        if (use_streams) {      // join the weight-gradient streams
+            RC(fork(side[1], s, fj[9]));
+            if (s0 != s) RC(fork(s0, s, fj[10]));
+        }
         if (bucket_ev[1]) (void)hipEventRecord(bucket_ev[1], s);
         if (bucket_ev[2]) (void)hipEventRecord(bucket_ev[2], s);
         last_bwd_phase2 = phase2;

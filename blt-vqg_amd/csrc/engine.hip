@@ -111,6 +111,7 @@ struct bltvqg_engine {
     float* acc_big;                // fp32 accumulator of the split-K vocabulary dgrad
     void *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
     void *g_b1, *g_b2, *g_b3, *g_b4, *g_cat, *g_mq;   // small [B, *] scratch
+    void *g_rec1, *g_net[2][2];                      // [B, *] gradients that are operands of deferred weight-gradient GEMMs (never reused)
     hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
     // side streams: independent sub-graphs (CNN | posterior encoder | context encoder) run concurrently so that their small
     // launches (40-160 workgroups each) fill the 256 CUs together; fork/join with events (capturable into a hipGraph)
@@ -395,6 +396,8 @@ struct bltvqg_engine {
         d_feats = AT((int64_t)B * H); d_zproj = AT((int64_t)B * H); d_recon = AT((int64_t)B * H); dzl = AT((int64_t)B * ldV);
         const int64_t wide = (int64_t)B * (2 * Z > F ? 2 * Z : F);
         g_b1 = AT(wide); g_b2 = AT(wide); g_b3 = AT(wide); g_b4 = AT(wide); g_cat = AT((int64_t)B * 2 * H); g_mq = AT((int64_t)B * 2 * Z);
+        g_rec1 = AT((int64_t)B * F);
+        for (int n = 0; n < 2; ++n) for (int k = 0; k < 2; ++k) g_net[n][k] = AT((int64_t)B * 2 * Z);
         return off;
     }
 
@@ -747,18 +750,19 @@ struct bltvqg_engine {
         return blt_gemm(dt, lin(h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), out, 2 * Z, B), s);
     }
     // backward of mlp3: dout [B,2Z] -> parameter grads, dx [B,din] (written, or accumulated into dx if acc)
-    int mlp3_bwd(const std::string& net, const void* x, int din, const void* h1, const void* h2, const void* dout, void* dx, int lddx,
+    int mlp3_bwd(const std::string& net, int which, const void* x, int din, const void* h1, const void* h2, const void* dout, void* dx, int lddx,
                  int acc, hipStream_t s) {
-        RC(wgrad(dout, 2 * Z, h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), B, s));
-        GemmArgs g = dgrad(dout, 2 * Z, net + ".6.weight", g_b1, 2 * Z, B);
+        void *gh2 = g_net[which][0], *gh1 = g_net[which][1];      // operands of the deferred weight gradients: buffers of their own
+        RC(wgrad_later(dout, 2 * Z, h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), B, s));
+        GemmArgs g = dgrad(dout, 2 * Z, net + ".6.weight", gh2, 2 * Z, B);
         g.maskY = h2; g.ldm = 2 * Z; g.mask_scale = 1.f;
         RC(blt_gemm(dt, g, s));
-        RC(wgrad(g_b1, 2 * Z, h1, 2 * Z, net + ".3.weight", (net + ".3.bias").c_str(), B, s));
-        g = dgrad(g_b1, 2 * Z, net + ".3.weight", g_b2, 2 * Z, B);
+        RC(wgrad_later(gh2, 2 * Z, h1, 2 * Z, net + ".3.weight", (net + ".3.bias").c_str(), B, s));
+        g = dgrad(gh2, 2 * Z, net + ".3.weight", gh1, 2 * Z, B);
         g.maskY = h1; g.ldm = 2 * Z; g.mask_scale = 1.f;
         RC(blt_gemm(dt, g, s));
-        RC(wgrad(g_b2, 2 * Z, x, din, net + ".0.weight", (net + ".0.bias").c_str(), B, s));
-        g = dgrad(g_b2, 2 * Z, net + ".0.weight", dx, lddx, B);
+        RC(wgrad_later(gh1, 2 * Z, x, din, net + ".0.weight", (net + ".0.bias").c_str(), B, s));
+        g = dgrad(gh1, 2 * Z, net + ".0.weight", dx, lddx, B);
         g.accumulate = acc;
         return blt_gemm(dt, g, s);
     }
@@ -1013,8 +1017,11 @@ struct bltvqg_engine {
     int backward_core(float kld_g, hipStream_t s) {
         pending_wgrads.clear();
         defer_wgrads = false;
+        // every weight gradient from here on is collected and issued on a side stream at the next flush point (their operands live
+        // in buffers that nothing overwrites during this backward pass); only the input-gradient chain stays on `s`
+        defer_wgrads = use_streams;
         // ---- vocabulary projection + decoder ----
-        RC(wgrad(logits, ldV, dec.out, H, "decoder.output.weight", "decoder.output.bias", Mt, s));
+        RC(wgrad_later(logits, ldV, dec.out, H, "decoder.output.weight", "decoder.output.bias", Mt, s));
         void* gA = sA[0];
         RC(dgrad_bigk(logits, ldV, "decoder.output.weight", gA, H, Mt, s));
         void* dxT = (char*)dX_all + (size_t)Ma * H * es;
@@ -1024,7 +1031,6 @@ struct bltvqg_engine {
                                  G("decoder.decoder.layer_norm.weight"), G("decoder.decoder.layer_norm.bias"), Mt, H, s,
                                  dec.layers[L - 1].y2, relu_ks(), dec.layers[L - 1].gY));
         }
-        defer_wgrads = use_streams;
         RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
         // the decoder's weight gradients run on side[1] from here on, under the rest of backward; bucket 0 (decoder.*) is complete when
         // that stream gets here
@@ -1034,30 +1040,30 @@ struct bltvqg_engine {
         RC(blt_rows_add(dt, d_feats, H, dxT, (long)T * H, nullptr, 0, B, H, 1, s));
         if (phase2) RC(blt_rows_add(dt, d_zproj, H, dxT, (long)T * H, nullptr, 0, B, H, 0, s));
         // ---- image reconstructor ----
-        RC(wgrad(d_recon, H, hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", B, s));
+        RC(wgrad_later(d_recon, H, hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", B, s));
         {
-            GemmArgs g = dgrad(d_recon, H, "image_reconstructor.layers.fc1.weight", g_b1, F, B);
+            GemmArgs g = dgrad(d_recon, H, "image_reconstructor.layers.fc1.weight", g_rec1, F, B);
             g.maskY = hrec; g.ldm = F; g.mask_scale = 1.f;
             RC(blt_gemm(dt, g, s));
         }
-        RC(wgrad(g_b1, F, r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", B, s));
-        RC(blt_gemm(dt, dgrad(g_b1, F, "image_reconstructor.layers.fc0.weight", g_b2, H, B), s));   // d r_in
+        RC(wgrad_later(g_rec1, F, r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", B, s));
+        RC(blt_gemm(dt, dgrad(g_rec1, F, "image_reconstructor.layers.fc0.weight", g_b2, H, B), s));   // d r_in
         RC(blt_rows_add(dt, d_enc, (long)Sa * H, g_b2, H, nullptr, 0, B, H, 1, s));
         if (phase2) {
             RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
             // ---- z_classifier ----
-            RC(wgrad(dzl, ldV, zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", B, s));
+            RC(wgrad_later(dzl, ldV, zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", B, s));
             RC(dgrad_bigk(dzl, ldV, "decoder.z_classifier.weight", g_b2, H, B, s));
             RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
             RC(blt_rows_add(dt, d_feats, H, g_b2, H, nullptr, 0, B, H, 1, s));
             // ---- latent projection, reparameterisation + KL, prior / posterior nets ----
-            RC(wgrad(d_zproj, H, zlat, Z, "latent_projection.weight", "latent_projection.bias", B, s));
+            RC(wgrad_later(d_zproj, H, zlat, Z, "latent_projection.weight", "latent_projection.bias", B, s));
             RC(blt_gemm(dt, dgrad(d_zproj, H, "latent_projection.weight", g_b3, Z, B), s));   // dz
             RC(blt_latent_bwd(dt, mlvp, mlvq, eps_dev, g_b3, kld_g, g_b4, g_mq, B, Z, 2 * Z, s));
             // posterior net: d cat(x_p, x)
-            RC(mlp3_bwd("latent_layer.mean_logvar_posterior", cat_in, 2 * H, mlvq_h1, mlvq_h2, g_mq, g_cat, 2 * H, 0, s));
+            RC(mlp3_bwd("latent_layer.mean_logvar_posterior", 0, cat_in, 2 * H, mlvq_h1, mlvq_h2, g_mq, g_cat, 2 * H, 0, s));
             // prior net: d x accumulated into the x half of d cat
-            RC(mlp3_bwd("latent_layer.mean_logvar_prior", (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, g_b4,
+            RC(mlp3_bwd("latent_layer.mean_logvar_prior", 1, (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, g_b4,
                         (char*)g_cat + (size_t)H * es, 2 * H, 1, s));
             RC(blt_rows_add(dt, d_enc, (long)Sa * H, (char*)g_cat + (size_t)H * es, 2 * H, nullptr, 0, B, H, 1, s));
         }

@@ -120,7 +120,8 @@ struct bltvqg_engine {
     // communication streams were added).  side[0]: posterior encoder (forward and backward); side[1]: context encoder (forward), the
     // deferred weight-gradient GEMMs (backward) and the asynchronous optimiser update.
     hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t fj[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fj[16] = {};
+    bool kv_hoisted = false;   // the decoder's encoder-side key/value projections were issued on the branch stream (forward_tail)
     // weight-gradient GEMMs of the transformer stacks are off the critical path of backward (nothing downstream reads dW): they are
     // collected while a stack's input-gradient chain is enqueued and then issued on a side stream, where they fill the CUs that the
     // chain's small latency-bound launches leave idle
@@ -570,6 +571,20 @@ struct bltvqg_engine {
         return BLT_OK;
     }
 
+    // encoder-side key/value projections of every decoder layer ([2H,H] fused operand): they depend on encoder_outputs only, so they
+    // are issued ahead of the decoder stack on the branch stream `sb`; the stack waits for fj[13] before its first cross-attention
+    int dec_kv_fwd(hipStream_t sb) {
+        for (int l = 0; l < L; ++l) {
+            const std::string a2 = dec.prefix + ".dec." + std::to_string(l) + ".multi_head_attention_enc_dec.";
+            int ldw;
+            const void* w = W(a2 + "key_linear.weight", &ldw);
+            RC(blt_gemm(dt, mk(enc.out, H, 0, w, ldw, 0, dec.layers[l].kv2, 2 * H, Ma, 2 * H, H), sb));
+        }
+        if (hipEventRecord(fj[13], sb) != hipSuccess) { blt_set_error("engine_forward: event record failed"); return BLT_ERR_HIP; }
+        kv_hoisted = true;
+        return BLT_OK;
+    }
+
     int stack_fwd(Stack& st, const void* enc_out, const int* src_ids, hipStream_t s) {
         const int M = st.M, S = st.S;
         const void* x = st.x_in;
@@ -611,10 +626,13 @@ struct bltvqg_engine {
             if (st.dec) {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
                 RC(blt_gemm(dt, lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M), s));
-                {
+                if (!kv_hoisted) {
                     int ldw;
                     const void* w = W(a2 + "key_linear.weight", &ldw);
                     RC(blt_gemm(dt, mk(enc_out, H, 0, w, ldw, 0, y.kv2, 2 * H, Ma, 2 * H, H), s));
+                } else if (l == 0 && hipStreamWaitEvent(s, fj[13], 0) != hipSuccess) {
+                    blt_set_error("engine_forward: stream wait failed");
+                    return BLT_ERR_HIP;
                 }
                 RC(attn_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, src_ids, S, Sa, 0, sid(st.id, l, 3), s));
                 const std::string ln3 = lp + "layer_norm_ffn";
@@ -837,7 +855,11 @@ struct bltvqg_engine {
 
     // everything after the image feature exists: latent, decoder, vocabulary projection, reconstructor (all on `s`)
     int forward_tail(const float* eps, hipStream_t s) {
+        kv_hoisted = false;
         RC(blt_rows_add(dt, enc.out, (long)Sa * H, feats, H, nullptr, 0, B, H, 1, s));   // encoder_outputs[:,0] += image_features
+        // Branch stream: everything below that the decoder stack does not need (z_classifier, image reconstructor) or needs only
+        // later (the encoder-side key/value projections of its layers) leaves the critical path; joined at the end of forward.
+        hipStream_t sb = use_streams ? side[0] : s;
         if (phase2) {
             if (hipMemcpyAsync(eps_dev, eps, sizeof(float) * (size_t)B * Z, hipMemcpyDeviceToDevice, s) != hipSuccess) {
                 blt_set_error("engine_forward: eps copy failed");
@@ -846,28 +868,33 @@ struct bltvqg_engine {
             // Latent.forward (transformer_layers.py:41-59): prior(x), posterior(cat(x_p, x))
             RC(blt_copy2d(dt, enc.out, Sa * H, (char*)cat_in + (size_t)H * es, 2 * H, B, H, s));
             RC(blt_copy2d(dt, renc.out, Sp * H, cat_in, 2 * H, B, H, s));
+            if (sb != s) { RC(fork(s, sb, fj[11])); RC(dec_kv_fwd(sb)); }
             RC(mlp3_fwd("latent_layer.mean_logvar_prior", (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, mlvp, s));
             RC(mlp3_fwd("latent_layer.mean_logvar_posterior", cat_in, 2 * H, mlvq_h1, mlvq_h2, mlvq, s));
             RC(blt_latent_fwd(dt, mlvp, mlvq, eps_dev, zlat, stats + 2, B, Z, 2 * Z, s));
             RC(blt_gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
             // target_embedding[:,0] += image_features + z ; z_logit = z_classifier(z + image_features)
             RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, zproj, H, B, H, 1, s));
-            RC(blt_rows_add(dt, zc_in, H, feats, H, zproj, H, B, H, 0, s));
-            RC(blt_gemm(dt, lin(zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", zlogit, ldV, B), s));
-            RC(blt_rows_add(dt, r_in, H, enc.out, (long)Sa * H, zproj, H, B, H, 0, s));
+            if (sb != s) RC(fork(s, sb, fj[12]));            // the branch continues behind z
+            RC(blt_rows_add(dt, zc_in, H, feats, H, zproj, H, B, H, 0, sb));
+            RC(blt_gemm(dt, lin(zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", zlogit, ldV, B), sb));
+            RC(blt_rows_add(dt, r_in, H, enc.out, (long)Sa * H, zproj, H, B, H, 0, sb));
         } else {
             RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, nullptr, 0, B, H, 1, s));
-            RC(blt_copy2d(dt, enc.out, Sa * H, r_in, H, B, H, s));
+            if (sb != s) { RC(fork(s, sb, fj[11])); RC(dec_kv_fwd(sb)); }
+            RC(blt_copy2d(dt, enc.out, Sa * H, r_in, H, B, H, sb));
         }
-        RC(stack_fwd(dec, enc.out, ctx32, s));
-        RC(blt_gemm(dt, lin(dec.out, H, "decoder.output.weight", "decoder.output.bias", logits, ldV, Mt), s));
         // image_reconstructor (mlp.py:49-56): Linear, ReLU, Dropout(0), Linear
         {
             GemmArgs g = lin(r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", hrec, F, B);
             g.relu = 1;
-            RC(blt_gemm(dt, g, s));
-            RC(blt_gemm(dt, lin(hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", recon, H, B), s));
+            RC(blt_gemm(dt, g, sb));
+            RC(blt_gemm(dt, lin(hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", recon, H, B), sb));
         }
+        RC(stack_fwd(dec, enc.out, ctx32, s));
+        kv_hoisted = false;
+        RC(blt_gemm(dt, lin(dec.out, H, "decoder.output.weight", "decoder.output.bias", logits, ldV, Mt), s));
+        if (sb != s) RC(fork(sb, s, fj[14]));
         fwd_done = true;
         return BLT_OK;
     }
@@ -1226,7 +1253,7 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
 void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (!e) return;
     for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
-    for (int i = 0; i < 12; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
+    for (int i = 0; i < 16; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
     for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
     if (e->opt_fork) (void)hipEventDestroy(e->opt_fork);
     if (e->opt_done) (void)hipEventDestroy(e->opt_done);
@@ -1290,7 +1317,7 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
             blt_set_error("engine_bind: event creation failed");
             return BLT_ERR_HIP;
         }
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 16; ++i)
         if (!e->fj[i] && hipEventCreateWithFlags(&e->fj[i], hipEventDisableTiming) != hipSuccess) {
             blt_set_error("engine_bind: event creation failed");
             return BLT_ERR_HIP;

@@ -171,6 +171,18 @@ def main():
     print("[bench] rank %d: %d timed steps in %.3f s" % (rank, a.steps, dt), file=sys.stderr, flush=True)
     conv_ms, conv_launches, conv_flops = eng.profile_read()
     eng.profile_enable(False)
+    # What an event bracket measures on top of the kernel it brackets: empty brackets on the same stream (the two markers' own
+    # latency, ~4-5 us).  It is subtracted per launch below; the raw figure is reported next to it.
+    null_us = 0.0
+    if conv_launches:
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+        tiny = torch.zeros(64, device=dev)
+        for ea, eb in pairs:
+            tiny.add_(1.0)                       # a kernel in front, as in the step (markers behind an idle stream are cheaper)
+            ea.record()
+            eb.record()
+        torch.cuda.synchronize()
+        null_us = sorted(ea.elapsed_time(eb) * 1e3 for ea, eb in pairs)[len(pairs) // 2]
     if dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -179,7 +191,9 @@ def main():
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = B * world * a.steps / dt
-        achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        raw_us = conv_ms * 1e3 / max(conv_launches, 1)
+        launch_us = max(raw_us - null_us, 1e-3)
+        achieved = conv_flops / (launch_us * 1e-6 * max(conv_launches, 1)) / 1e12 if conv_ms > 0 else 0.0
         # HBM bytes per conv launch from the committed PMC passes (profiles/summarize_pmc.py); they were collected for this
         # default workload only, so any other configuration reports null
         traffic = None
@@ -201,9 +215,10 @@ def main():
                          "kernel": "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), "
                                    "conv_stem_direct_kernel (1), gemm_dma_kernel<*,*,conv,*> (6: stride-2 / 1x1)",
                          "launches_per_step": conv_launches // max(profiled, 1),
-                         "avg_launch_us": round(conv_ms * 1e3 / max(conv_launches, 1), 2),
+                         "avg_launch_us": round(launch_us, 2), "avg_bracket_us_raw": round(raw_us, 2),
+                         "empty_bracket_us": round(null_us, 2),
                          "profiled_steps": "%d of the %d timed steps (every %dth) carry the HIP events" % (profiled, a.steps, PROFILE_EVERY),
-                         "kernel_share_of_step": round(conv_ms / max(profiled, 1) / (dt / a.steps * 1e3), 4)},
+                         "kernel_share_of_step": round(launch_us * 1e-3 * (conv_launches // max(profiled, 1)) / (dt / a.steps * 1e3), 4)},
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, phase2, a.cpu_batch, a.cpu_steps)

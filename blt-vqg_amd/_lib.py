@@ -38,6 +38,7 @@ SIGNATURES = {
     "bltvqg_debug_set": (None, [I, I]),
     "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
     "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
+    "bltvqg_layernorm_linear": (I, [P, I, P, P, F, P, P, P, P, I, P, I, F, U64, U32, P, I, P, I, I, I, I, P]),
     "bltvqg_linear_layernorm": (I, [P, I, P, I, P, I, F, U64, U32, P, I, P, I, P, I, P, P, F, P, P, P, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv2d_stat_rows": (I, [I, I, I, I, I, I, I, I]),

@@ -38,6 +38,17 @@ int bltvqg_linear_layernorm(const void* X, int ldx, const void* W, int ldw, cons
     return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
 }
 
+int bltvqg_layernorm_linear(const void* X, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, void* Xn, float* ln_mean,
+                            float* ln_rstd, const void* W, int ldw, const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
+                            const void* R, int ldr, void* C, int ldc, int M, int N, int K, void* stream) {
+    BLT_REQUIRE(X && W && C && Xn, "layernorm_linear: null pointer");
+    GemmArgs g;
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = ldw; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id; g.R = R; g.ldr = ldr;
+    g.lnA_gamma = ln_gamma; g.lnA_beta = ln_beta; g.lnA_eps = ln_eps; g.lnA_out = Xn; g.lnA_mean = ln_mean; g.lnA_rstd = ln_rstd;
+    return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
+}
+
 static GemmArgs conv_args(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     GemmArgs g;
     const int Ho = (Hi + 2 * pad - KH) / stride + 1, Wo = (Wi + 2 * pad - KW) / stride + 1;

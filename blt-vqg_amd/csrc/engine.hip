@@ -555,11 +555,24 @@ struct bltvqg_engine {
         g.ln_gamma = P(ln + ".weight"); g.ln_beta = P(ln + ".bias"); g.ln_out = out; g.ln_mean = m; g.ln_rstd = r; g.ln_eps = 1e-5f;
     }
     struct NextLN { std::string name; void* out = nullptr; float *m = nullptr, *r = nullptr; };
+    // LayerNorm folded into the Linear that consumes it (GemmArgs::lnA_*, gemm_dma_lnA_kernel): every LayerNorm inside the stacks feeds
+    // exactly one GEMM (q|k|v, the cross-attention query, the first FFN layer), so in bf16 with d_model <= 256 none of them needs to be a
+    // launch of its own.  Measured: 14 launches fewer per step and the SAME step time (2.80 ms) — the folded GEMM's load -> normalise ->
+    // MFMA chain is as long as LayerNorm launch + GEMM launch were, which says that these kernels are bound by dependent memory round
+    // trips, not by the launch itself.  Kept as an exported, tested operator (bltvqg_layernorm_linear); the engine uses it only under
+    // debug key 7 = 6 (A/B).
+    bool lnA_on() const { return dt == BLT_BF16 && H <= 256 && H % 8 == 0 && blt_debug_get(7) == 6; }
+    // GEMM input: the normalised tensor `xn`, or — folded — the raw tensor x plus the LayerNorm that produces xn (written as a by-product)
+    void set_lnA(GemmArgs& g, const void* x, const std::string& ln, void* xn, float* m, float* r) {
+        g.A = x; g.lnA_gamma = P(ln + ".weight"); g.lnA_beta = P(ln + ".bias"); g.lnA_out = xn; g.lnA_mean = m; g.lnA_rstd = r; g.lnA_eps = 1e-5f;
+    }
 
-    // x2 = xres + dropout(relu(W2 dropout(relu(W1 xn + b1)) + b2)); `next` = the LayerNorm that consumes x2 (next layer's first one or
-    // the stack's final one)
-    int ffn_fwd(const std::string& fp_, const void* xn, const void* xres, Layer& y, int M, int stack, int l, const NextLN& next, hipStream_t s) {
+    // x2 = xres + dropout(relu(W2 dropout(relu(W1 LN(xres) + b1)) + b2)); ln = the FFN's LayerNorm (output xn, statistics m / r);
+    // `next` = the LayerNorm that consumes x2 (next layer's first one or the stack's final one)
+    int ffn_fwd(const std::string& fp_, const std::string& ln, void* xn, float* m, float* r, const void* xres, Layer& y, int M, int stack, int l,
+                const NextLN& next, bool next_is_final, hipStream_t s) {
         GemmArgs g = lin(xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, F, M);
+        if (lnA_on()) set_lnA(g, xres, ln, xn, m, r);
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 1);
         RC(blt_gemm(dt, g, s));
         g = lin(y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), y.x2, H, M);
@@ -567,7 +580,8 @@ struct bltvqg_engine {
         g.C2 = y.y2; g.ldc2 = H; g.R = xres; g.ldr = H;
         if (ln_fused()) set_ln(g, next.name, next.out, next.m, next.r);
         RC(blt_gemm(dt, g, s));
-        if (!ln_fused()) RC(blt_layernorm_fwd(dt, y.x2, P(next.name + ".weight"), P(next.name + ".bias"), next.out, next.m, next.r, M, H, 1e-5f, s));
+        if (!ln_fused() && (next_is_final || !lnA_on()))
+            RC(blt_layernorm_fwd(dt, y.x2, P(next.name + ".weight"), P(next.name + ".bias"), next.out, next.m, next.r, M, H, 1e-5f, s));
         return BLT_OK;
     }
 
@@ -589,7 +603,7 @@ struct bltvqg_engine {
         const int M = st.M, S = st.S;
         const void* x = st.x_in;
         auto lname = [&](int l) { return st.prefix + (st.dec ? ".dec." : ".enc.") + std::to_string(l) + "."; };
-        {   // the first LayerNorm reads the shared embedding's output: a launch of its own
+        if (!lnA_on()) {   // the first LayerNorm reads the shared embedding's output
             const std::string ln1 = lname(0) + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
             Layer& y0 = st.layers[0];
             RC(blt_layernorm_fwd(dt, x, P(ln1 + ".weight"), P(ln1 + ".bias"), y0.xn1, y0.m1, y0.r1, M, H, 1e-5f, s));
@@ -611,6 +625,7 @@ struct bltvqg_engine {
                 int ldw;
                 const void* w = W(a1 + "query_linear.weight", &ldw);
                 GemmArgs g = mk(y.xn1, H, 0, w, ldw, 0, y.qkv, 3 * H, M, 3 * H, H);
+                if (lnA_on()) set_lnA(g, x, lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha"), y.xn1, y.m1, y.r1);
                 RC(blt_gemm(dt, g, s));
             }
             RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
@@ -621,11 +636,15 @@ struct bltvqg_engine {
                 g.R = x; g.ldr = H;
                 if (ln_fused()) set_ln(g, ln2, y.xn2, y.m2, y.r2);
                 RC(blt_gemm(dt, g, s));
-                if (!ln_fused()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
+                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
             }
             if (st.dec) {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
-                RC(blt_gemm(dt, lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M), s));
+                {
+                    GemmArgs g = lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M);
+                    if (lnA_on()) set_lnA(g, y.x1, ln2, y.xn2, y.m2, y.r2);
+                    RC(blt_gemm(dt, g, s));
+                }
                 if (!kv_hoisted) {
                     int ldw;
                     const void* w = W(a2 + "key_linear.weight", &ldw);
@@ -640,10 +659,10 @@ struct bltvqg_engine {
                 g.R = y.x1; g.ldr = H;
                 if (ln_fused()) set_ln(g, ln3, y.xn3, y.m3, y.r3);
                 RC(blt_gemm(dt, g, s));
-                if (!ln_fused()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s));
-                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y, M, st.id, l, next, s));
+                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", ln3, y.xn3, y.m3, y.r3, y.x1b, y, M, st.id, l, next, l + 1 == L, s));
             } else {
-                RC(ffn_fwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y, M, st.id, l, next, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", ln2, y.xn2, y.m2, y.r2, y.x1, y, M, st.id, l, next, l + 1 == L, s));
             }
             x = y.x2;
         }

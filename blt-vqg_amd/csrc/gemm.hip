@@ -891,6 +891,164 @@ __global__ __launch_bounds__(256) void gemm_dma_ln_kernel(const GemmArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Linear whose input is a LayerNorm: the LayerNorm runs on the A tile in LDS (GemmArgs::lnA_*).  64 x 64 tile, K <= 256: all (<= 4)
+// K-tiles of A and B are DMA'd at once into their own stages (64 KB), then 4 threads per row normalise the row in place — each its
+// 64-column K-tile, the swizzled slots in any order since only sums are needed — and the MFMA loop runs without further loads.
+// Every column tile of a row block repeats the (cheap) normalisation; the first one writes LN(A) and the statistics for backward.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_dma_lnA_kernel(const GemmArgs p) {
+    constexpr int BM = 64, BN = 64, BK = 64, MAXKT = 4, CS = BN + 4;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16* __restrict__ Ag = (const bf16*)p.A;
+    const bf16* __restrict__ Bg = (const bf16*)p.B;
+    const void* zero = (const void*)g_zero_page;
+    const int nk = (p.K + BK - 1) / BK;
+    float* gb = reinterpret_cast<float*>(smem + MAXKT * STAGE);       // gamma[K] | beta[K] (K <= 256)
+
+    // ---- all K-tiles in flight: DMA instruction j of a tile covers chunks (j*4 + wave)*64 + lane, j < 2 for A and for B ----
+#pragma unroll
+    for (int kt = 0; kt < MAXKT; ++kt) {
+        if (kt < nk) {
+            char* a_st = smem + kt * STAGE;
+            char* b_st = a_st + A_BYTES;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int c = (j * 4 + wave) * 64 + lane;
+                const int row = c >> 3, gc = (c & 7) ^ (row & 7);
+                const bool oka = (m0 + row < p.M) && (k0 + gc * 8 < p.K);
+                dma16(oka ? (const void*)(Ag + (size_t)(m0 + row) * p.lda + k0 + gc * 8) : zero, a_st + (j * 4 + wave) * 1024);
+                const bool okb = (n0 + row < p.N) && (k0 + gc * 8 < p.K);
+                dma16(okb ? (const void*)(Bg + (size_t)(n0 + row) * p.ldb + k0 + gc * 8) : zero, b_st + (j * 4 + wave) * 1024);
+            }
+        }
+    }
+    for (int i = tid; i < p.K; i += 256) { gb[i] = p.lnA_gamma[i]; gb[256 + i] = p.lnA_beta[i]; }
+    wait_vmcnt<0>();
+    __syncthreads();
+
+    // ---- LayerNorm of the 64 rows in place.  Wave w owns rows 16w .. 16w+15 in two passes of 8 rows; in a pass lane l reads slot
+    // (l & 7) of row (l >> 3) of every K-tile: one wave instruction covers 8 whole 128-byte rows = 1 KB contiguous (conflict-free; a
+    // thread-per-row-quarter mapping put 32 lanes on one bank group).  The swizzled slot order is irrelevant for the sums.
+    {
+        const int slot = lane & 7;
+        float v[2][MAXKT][8];
+        float mu2[2], rs2[2];
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int r = wave * 16 + ps * 8 + (lane >> 3);
+            float s1 = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < MAXKT; ++kt) {
+                if (kt < nk) {
+                    const bf16x8 x = *reinterpret_cast<const bf16x8*>(smem + kt * STAGE + r * 128 + slot * 16);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { v[ps][kt][e] = (float)x[e]; s1 += v[ps][kt][e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[ps][kt][e] = 0.f;
+                }
+            }
+            s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64); s1 += __shfl_xor(s1, 4, 64);
+            const float mu = s1 / (float)p.K;
+            float qq = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < MAXKT; ++kt) {
+                const int kc = kt * 64 + ((slot ^ (r & 7)) << 3);          // first column of the chunk that sits in this slot
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (kc + e < p.K) { const float d = v[ps][kt][e] - mu; qq += d * d; }
+            }
+            qq += __shfl_xor(qq, 1, 64); qq += __shfl_xor(qq, 2, 64); qq += __shfl_xor(qq, 4, 64);
+            mu2[ps] = mu;
+            rs2[ps] = rsqrtf(qq / (float)p.K + p.lnA_eps);
+        }
+#pragma unroll
+        for (int ps = 0; ps < 2; ++ps) {
+            const int r = wave * 16 + ps * 8 + (lane >> 3);
+            const int m = m0 + r;
+#pragma unroll
+            for (int kt = 0; kt < MAXKT; ++kt) {
+                if (kt < nk) {
+                    const int kc = kt * 64 + ((slot ^ (r & 7)) << 3);
+                    bf16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float y = (kc + e < p.K) ? (v[ps][kt][e] - mu2[ps]) * rs2[ps] * gb[kc + e] + gb[256 + kc + e] : 0.f;
+                        o[e] = (bf16)y;
+                    }
+                    *reinterpret_cast<bf16x8*>(smem + kt * STAGE + r * 128 + slot * 16) = o;
+                    if (tile_n == 0 && m < p.M && kc < p.K) *reinterpret_cast<bf16x8*>((bf16*)p.lnA_out + (size_t)m * p.K + kc) = o;
+                }
+            }
+            if (tile_n == 0 && slot == 0 && m < p.M) { p.lnA_mean[m] = mu2[ps]; p.lnA_rstd[m] = rs2[ps]; }
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lg = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* a_st = smem + kt * STAGE;
+        const char* b_st = a_st + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wm * 32 + i * 16 + l15;
+                af[i] = *reinterpret_cast<const bf16x8*>(a_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wn * 32 + j * 16 + l15;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(wm * 32 + i * 16 + lg * 4 + r) * CS + wn * 32 + j * 16 + l15] = acc[i][j][r];
+    __syncthreads();
+    gemm_epilogue<bf16, BM, BN>(p, Cs, tile_m, m0, n0, tid);
+}
+
+int launch_dma_lnA(const GemmArgs& a, hipStream_t stream) {
+    constexpr int LDS = 4 * (64 * 128 + 64 * 128) + 2 * 256 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_dma_lnA_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+            blt_set_error("gemm: hipFuncSetAttribute(%d) failed", LDS);
+            return BLT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const long tiles = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
+    hipLaunchKernelGGL(gemm_dma_lnA_kernel, dim3((unsigned)tiles), dim3(256), LDS, stream, a);
+    return blt_check_launch("gemm_dma_lnA");
+}
+
 int launch_dma_ln(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = 3 * (32 * 128 + 256 * 128);
     static bool attr_set = false;
@@ -1112,6 +1270,12 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
                 (!a.rowtab || ((uintptr_t)a.rowtab % 16) == 0), "gemm: epilogue operands must be 16-byte aligned");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
     BLT_REQUIRE(!a.a_rowsum || (a.transA && !a.is_conv), "gemm: a_rowsum needs the transA (weight-gradient) form");
+    if (a.lnA_out != nullptr) {
+        BLT_REQUIRE(dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv, "gemm: LayerNorm on A needs bf16 k-contiguous operands");
+        BLT_REQUIRE(a.K <= 256 && a.K % 8 == 0 && a.lnA_gamma && a.lnA_beta && a.lnA_mean && a.lnA_rstd, "gemm: LayerNorm on A needs K <= 256, K %% 8 == 0 (K=%d)", a.K);
+        BLT_REQUIRE(a.split_k == 0 && !a.stat_sum && !a.ln_out && ((uintptr_t)a.lnA_out % 16) == 0, "gemm: unsupported combination with LayerNorm on A");
+        return launch_dma_lnA(a, stream);
+    }
     if (a.ln_out != nullptr) {
         BLT_REQUIRE(dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv, "gemm: the fused LayerNorm needs bf16 k-contiguous operands");
         BLT_REQUIRE(a.N <= 256 && a.N % 8 == 0 && a.ln_gamma && a.ln_beta && a.ln_mean && a.ln_rstd, "gemm: fused LayerNorm needs N <= 256, N %% 8 == 0 (N=%d)", a.N);

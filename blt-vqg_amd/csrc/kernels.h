@@ -60,6 +60,16 @@ struct GemmArgs {
     // epilogue above has produced C (rounded to bf16, as a separate LayerNorm launch would read it), ln_out = LN(C) * ln_gamma + ln_beta
     // and the row statistics are written as well (transformer_layers.py:134,202,256-257,320-322: every LayerNorm of the stacks reads
     // the output of a Linear + residual)
+    // LayerNorm applied to the A operand inside the GEMM (bf16, k-contiguous operands, K <= 256 so that a workgroup's 64 rows of A sit in
+    // LDS whole): A := LN(A) * lnA_gamma + lnA_beta (rounded to bf16, as a separate LayerNorm launch would store it) before the MFMA
+    // loop; the workgroups of the first column tile also write that normalised A (lnA_out, ld = K) and the row statistics, which the
+    // backward needs.  Every LayerNorm of the stacks feeds exactly one Linear (QKV / query / first FFN layer).
+    const float* lnA_gamma = nullptr;
+    const float* lnA_beta = nullptr;
+    void* lnA_out = nullptr;
+    float* lnA_mean = nullptr;
+    float* lnA_rstd = nullptr;
+    float lnA_eps = 1e-5f;
     const float* ln_gamma = nullptr;
     const float* ln_beta = nullptr;
     void* ln_out = nullptr;

@@ -66,6 +66,13 @@ int bltvqg_linear_layernorm(const void* X, int ldx, const void* W, int ldw, cons
                             const float* ln_beta, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd, int M, int N, int K,
                             void* stream);
 
+/* bf16 LayerNorm folded into the Linear that consumes it (every LayerNorm inside the transformer stacks feeds exactly one Linear:
+ * q|k|v, the cross-attention query, the first FFN layer): Xn = LayerNorm(X) * ln_gamma + ln_beta (rounded to bf16, written [M,K] with the
+ * row statistics, which backward needs) is formed on the A tile in LDS, C = [dropout(relu(]Xn W^T + bias[))] + R.  K <= 256, K % 8 == 0. */
+int bltvqg_layernorm_linear(const void* X, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, void* Xn, float* ln_mean,
+                            float* ln_rstd, const void* W, int ldw, const float* bias, int relu, float drop_p, uint64_t seed,
+                            uint32_t stream_id, const void* R, int ldr, void* C, int ldc, int M, int N, int K, void* stream);
+
 /* NHWC implicit-GEMM convolution y[N,Ho,Wo,Cout] = conv(x[N,Hi,Wi,Cin], w[Cout,KH,KW,Cin]); Cin a power of two >= 8 (bf16)
  * / 4 (fp32).  stat_sum/stat_sq (optional): per-half-tile column partial sums, bltvqg_conv2d_stat_rows() rows of Cout. */
 int bltvqg_conv2d(int dtype, const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW,

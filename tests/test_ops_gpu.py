@@ -655,3 +655,35 @@ def test_linear_with_fused_layernorm(shape):
     var = refb.float().var(1, unbiased=False)
     assert (mean.cpu() - mu).abs().max() < 1e-4 * max(1.0, float(mu.abs().max()))
     assert ((rstd.cpu() - (var + 1e-5).rsqrt()).abs() / (var + 1e-5).rsqrt()).max() < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2688, 768, 256, False), (640, 512, 256, True), (77, 256, 200, True), (130, 96, 64, False)])
+def test_layernorm_folded_into_consumer_linear(shape):
+    """bltvqg_layernorm_linear: LayerNorm on the A tile in LDS.  The normalised activations / statistics must match a LayerNorm launch
+    and the product must equal the plain GEMM of those (bf16-rounded) activations."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    lib = G.lib()
+    M, N, K, use_bias = shape
+    g = torch.Generator().manual_seed(M + K)
+    X = (torch.randn(M, K, generator=g) * 1.5 + 0.3).bfloat16()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).bfloat16()
+    bias = torch.randn(N, generator=g) if use_bias else None
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    Xd, Wd = X.cuda(), W.cuda()
+    bd = bias.cuda() if use_bias else None
+    Xn = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+    mean, rstd = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
+    check(lib.bltvqg_layernorm_linear(ptr(Xd), K, ptr(gamma.cuda()), ptr(beta.cuda()), 1e-5, ptr(Xn), ptr(mean), ptr(rstd), ptr(Wd), K, ptr(bd),
+                                      0, 0.0, 0, 0, None, 0, ptr(C), N, M, N, K, stream_ptr()), "layernorm_linear")
+    torch.cuda.synchronize()
+    ln = F.layer_norm(X.float(), (K,), gamma, beta, 1e-5)
+    assert (Xn.float().cpu() - ln).abs().max() < 2e-2 * max(1.0, float(ln.abs().max()))
+    mu, var = X.float().mean(1), X.float().var(1, unbiased=False)
+    assert (mean.cpu() - mu).abs().max() < 1e-4 and ((rstd.cpu() - (var + 1e-5).rsqrt()).abs() / (var + 1e-5).rsqrt()).max() < 1e-4
+    # the GEMM consumed exactly the Xn it wrote
+    ref = Xn.float().cpu() @ W.float().t()
+    if use_bias:
+        ref = ref + bias
+    assert (C.float().cpu() - ref).abs().max() < 2e-2 * max(1.0, float(ref.abs().max()))

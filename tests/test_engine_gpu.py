@@ -276,3 +276,56 @@ def test_overlapped_optimizer_matches_synchronous(dtype):
     for a, b in zip(l_sync, l_async):
         for k in ("rec", "img", "kld", "aux", "grad_norm"):
             assert abs(a[k] - b[k]) <= 2e-4 * max(1.0, abs(a[k])), (k, a[k], b[k])
+
+
+def test_full_size_properties_batch_permutation_and_gradient_linearity():
+    """Size-independent properties at the BENCH size (BASELINE configs[1]: 2-layer d_model 256, batch 128, 224x224, bf16), where the
+    oracle is too slow to be the checker:
+      * permuting the batch permutes every per-sample output (train-mode BatchNorm statistics, the only cross-sample coupling, are
+        permutation invariant) and leaves the losses unchanged;
+      * the backward is linear in the output gradient: doubling d(output) doubles every parameter gradient (exact in bf16 / fp32 up
+        to the float-atomic accumulation order)."""
+    import bltvqg_amd.synthetic as synthetic
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import init_reference_style
+    B, V, Z = 128, 8000, 256
+    c = make_config(B, 256, 512, Z, 300, 2, 4, V, dtype=1, attention_dropout=0.0, relu_dropout=0.0)
+    e = StepEngine(c)
+    e.allocate()
+    init_reference_style(e, seed=3)
+    b = synthetic.make_batch(B, V, Z, seed=77)
+    d = {k: v.cuda() for k, v in b.items()}
+    eps = torch.randn(B, Z, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(1)).cuda()
+
+    def fwd(idx):
+        e.forward(d["images"][idx], d["answers"][idx], d["posteriors"][idx], d["questions"][idx], eps[idx], True, 0)
+        out, zl, feats = e.read(0).clone(), e.read(1).clone(), e.read(2).clone()
+        e.loss_backward(0.5)
+        st = e.stats()
+        torch.cuda.synchronize()
+        return out, zl, feats, st
+
+    ident = torch.arange(B, device="cuda")
+    o0, z0, f0, s0 = fwd(ident)
+    o1, z1, f1, s1 = fwd(perm)
+    assert torch.isfinite(o0).all() and torch.isfinite(f0).all()
+    assert rel_err(f1.cpu(), f0[perm].cpu()) < 2e-2          # bf16 BatchNorm partial sums are formed in a different order
+    assert rel_err(o1.cpu(), o0[perm].cpu()) < 2e-2
+    assert rel_err(z1.cpu(), z0[perm].cpu()) < 2e-2
+    for k in ("rec", "img", "kld", "aux"):
+        assert abs(s0[k] - s1[k]) <= 2e-3 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
+    assert s0["n_targets"] == s1["n_targets"]
+
+    # linearity of the backward in d(output)
+    e.forward(d["images"], d["answers"], d["posteriors"], d["questions"], eps, True, 0)
+    g = torch.Generator(device="cuda").manual_seed(9)
+    dout = torch.randn(B, c.len_target, V, device="cuda", generator=g) * 1e-3
+    e.backward_external(d_output=dout)
+    g1 = e.flat_grad.clone()
+    dout2 = 2.0 * dout
+    e.backward_external(d_output=dout2)
+    g2 = e.flat_grad.clone()
+    torch.cuda.synchronize()
+    assert float(g1.abs().max()) > 0
+    assert rel_err(g2.cpu(), 2.0 * g1.cpu()) < 1e-4

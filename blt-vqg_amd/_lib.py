@@ -96,6 +96,8 @@ SIGNATURES = {
     "bltvqg_engine_optimizer_step": (I, [P, F, F, F, F, F, P]),
     "bltvqg_engine_optimizer_step_async": (I, [P, F, F, F, F, F, P]),
     "bltvqg_engine_optimizer_wait": (I, [P, P]),
+    "bltvqg_engine_adam_steps": (I, [P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "bltvqg_engine_set_adam_steps": (I, [P, ctypes.c_int32, ctypes.c_int32]),
     "bltvqg_engine_read": (I, [P, I, P, P]),
     "bltvqg_engine_dropout_stream_id": (U32, [I, I, I]),
     "bltvqg_engine_profile_enable": (I, [P, I]),

@@ -1395,6 +1395,18 @@ int bltvqg_engine_optimizer_step_async(bltvqg_engine* e, float lr, float max_nor
     BLT_REQUIRE(e, "engine_optimizer_step_async: null engine");
     return e->optimizer_step(lr, max_norm, beta1, beta2, eps, (hipStream_t)stream, true);
 }
+int bltvqg_engine_adam_steps(const bltvqg_engine* e, int32_t* steps_main_host, int32_t* steps_late_host) {
+    BLT_REQUIRE(e && steps_main_host && steps_late_host, "engine_adam_steps: bad args");
+    *steps_main_host = e->step_main;
+    *steps_late_host = e->step_late;
+    return BLT_OK;
+}
+int bltvqg_engine_set_adam_steps(bltvqg_engine* e, int32_t steps_main, int32_t steps_late) {
+    BLT_REQUIRE(e && steps_main >= 0 && steps_late >= 0, "engine_set_adam_steps: bad args");
+    e->step_main = steps_main;
+    e->step_late = steps_late;
+    return BLT_OK;
+}
 int bltvqg_engine_optimizer_wait(bltvqg_engine* e, void* stream) {
     BLT_REQUIRE(e, "engine_optimizer_wait: null engine");
     if (!e->opt_pending) return BLT_OK;

@@ -161,6 +161,15 @@ class StepEngine(object):
         fn = self.lib.bltvqg_engine_optimizer_step_async if overlap else self.lib.bltvqg_engine_optimizer_step
         check(fn(self.h, float(lr), float(max_norm), float(beta1), float(beta2), float(eps), stream_ptr()), "engine_optimizer_step")
 
+    def adam_steps(self):
+        """(steps taken by the always-trained region, by the latent-phase-only region): Adam's bias-correction counters."""
+        a, b = ctypes.c_int32(), ctypes.c_int32()
+        check(self.lib.bltvqg_engine_adam_steps(self.h, ctypes.byref(a), ctypes.byref(b)), "engine_adam_steps")
+        return a.value, b.value
+
+    def set_adam_steps(self, main, late):
+        check(self.lib.bltvqg_engine_set_adam_steps(self.h, int(main), int(late)), "engine_set_adam_steps")
+
     def optimizer_wait(self):
         """Orders the current stream behind a pending overlapped optimiser update (no-op otherwise)."""
         check(self.lib.bltvqg_engine_optimizer_wait(self.h, stream_ptr()), "engine_optimizer_wait")

@@ -133,6 +133,11 @@ class TrainIQ(_Base):
         eng = self.model.engine(images, context, posteriors, questions)
         if self._dp is None or self._dp.e is not eng:
             self._dp = DataParallelStep(eng, dist)
+        if getattr(self, "_pending_adam", None) is not None:      # optimiser state of a loaded checkpoint (fused path)
+            ad, self._pending_adam = self._pending_adam, None
+            eng.adam_m.copy_(ad["m"].to(eng.adam_m.device))
+            eng.adam_v.copy_(ad["v"].to(eng.adam_v.device))
+            eng.set_adam_steps(*ad["steps"])
         phase2 = self.latent_transformer
         eps = None
         if phase2:
@@ -152,6 +157,38 @@ class TrainIQ(_Base):
             self.args.kl_ceiling * self._last_w * st["kld"] + self.args.aux_ceiling * st["aux"] if self.latent_transformer else 0.0)
         st["ppl"] = math.exp(min(st["rec"], 100))
         return st
+
+    # ---- checkpoints -----------------------------------------------------------------------------------
+    # The reference saves through Lightning (train_iq.py:277-309, trainer.save_checkpoint): a torch-pickled dict whose "state_dict"
+    # holds the LightningModule's tensors under "model.<IQ key>" (the 260 keys of tests/golden/state_keys_small.txt, aliases
+    # included) next to "epoch" / "global_step" / optimizer and scheduler state.  save_checkpoint writes that layout (tensors and
+    # plain Python scalars only); load_checkpoint reads it — from this class or from the reference — with the SAFE loader only
+    # (torch.load(weights_only=True)): a file that needs arbitrary unpickling (e.g. an argparse.Namespace under "hyper_parameters") is
+    # refused by torch with a message naming the offending global, and is not loaded any other way.
+    def save_checkpoint(self, path):
+        sd = {"model." + k: v.detach().float().cpu().clone() for k, v in self.model.state_dict().items()}
+        ckpt = {"epoch": 0, "global_step": int(self.iter), "pytorch-lightning_version": "1.1.8", "state_dict": sd,
+                "blt_vqg": {"iter": int(self.iter), "kliter": int(self.kliter), "latent_transformer": bool(self.latent_transformer)}}
+        eng = getattr(self, "_last_engine", None)
+        if eng is not None:      # fused path: Adam moments of the flat buffer (the autograd path keeps them in its torch optimizer)
+            eng.optimizer_wait()
+            ckpt["blt_vqg"]["adam"] = {"m": eng.adam_m.detach().cpu().clone(), "v": eng.adam_v.detach().cpu().clone(),
+                                       "steps": [int(x) for x in eng.adam_steps()]}
+        torch.save(ckpt, path)
+
+    def load_checkpoint(self, path, strict=True):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()
+              if not k.startswith("criterion") and not k.startswith("image_recon_criterion")}
+        res = self.model.load_state_dict(sd, strict=strict)
+        meta = ckpt.get("blt_vqg", {}) if isinstance(ckpt, dict) else {}
+        self.iter = int(meta.get("iter", ckpt.get("global_step", 0) if isinstance(ckpt, dict) else 0))
+        self.kliter = int(meta.get("kliter", max(0, self.iter - getattr(self.args, "num_pretraining_steps", 0))))
+        self.latent_transformer = bool(meta.get("latent_transformer", self.iter >= getattr(self.args, "num_pretraining_steps", 1 << 62)))
+        self.model.switch_GVT_train_mode(self.latent_transformer)
+        self._pending_adam = meta.get("adam")
+        return res
 
     def fit(self, loader, max_steps, log_every=100, dist=None):
         """Minimal stand-in for pl.Trainer(max_steps=..., gradient_clip_val=5).fit (reference train_iq.py:372-374)."""

@@ -240,6 +240,9 @@ int bltvqg_engine_optimizer_step(bltvqg_engine* e, float lr, float max_norm, flo
 int bltvqg_engine_optimizer_step_async(bltvqg_engine* e, float lr, float max_norm, float beta1, float beta2, float eps,
                                        void* stream);
 int bltvqg_engine_optimizer_wait(bltvqg_engine* e, void* stream);
+/* Adam step counters (bias correction) of the always-trained and the latent-phase-only parameter regions: checkpoint / resume */
+int bltvqg_engine_adam_steps(const bltvqg_engine* e, int32_t* steps_main_host, int32_t* steps_late_host);
+int bltvqg_engine_set_adam_steps(bltvqg_engine* e, int32_t steps_main, int32_t steps_late);
 /* outputs, converted to contiguous fp32: what = 0 output [B,T,V], 1 z_logit [B,V], 2 image_features [B,H],
  * 3 reconstructed [B,H], 4 stats float[8] = {loss_rec, loss_img, kld, loss_aux, grad_norm_sq, n_targets, 0, 0},
  * 5 encoder_outputs [B,S_a,H], 6 decoder_outputs [B,T,H] */

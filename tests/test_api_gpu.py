@@ -2,6 +2,7 @@
 the losses with torch criteria and calls backward) and TrainIQ.training_step / fused_training_step, against the CPU oracle."""
 from types import SimpleNamespace
 
+import os
 import numpy as np
 import pytest
 import torch
@@ -151,3 +152,62 @@ def test_decode_greedy_token_ids_bit_exact(name, phase2):
                            eps=batch["eps"].cuda())
     ptag = "p2" if phase2 else "p1"
     assert rel_err(out.detach().cpu(), z[ptag + ".output"]) < 2e-4
+
+
+def test_checkpoint_roundtrip_and_lightning_layout(tmp_path):
+    """TrainIQ.save_checkpoint writes the reference's (Lightning) checkpoint layout — "state_dict" with the module's
+    tensors under "model.<IQ key>" — and load_checkpoint reads it back with the safe loader (weights_only=True); resuming from the
+    checkpoint reproduces the uninterrupted run (parameters, Adam moments and step counters, phase flags)."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    import bltvqg_amd.synthetic as synthetic
+    z, cfg, state, _ = load_golden("tiny")
+    B, hw = 4, 64
+    batches = [synthetic.make_batch(B, cfg.vocab_size, cfg.latent_dim, seed=500 + i, image_hw=hw) for i in range(4)]
+    for b in batches:
+        b["eps"] = torch.randn(B, cfg.latent_dim, generator=torch.Generator().manual_seed(7))
+
+    def fresh():
+        t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg, num_pretraining_steps=1))
+        t.model.load_state_dict(_full_state(t.model, state))
+        return t.to("cuda")
+
+    a = fresh()
+    for b in batches[:2]:
+        a.fused_training_step(b)
+    path = str(tmp_path / "blt.ckpt")
+    a.save_checkpoint(path)
+    for b in batches[2:]:
+        a.fused_training_step(b)
+    ref = {k: v.detach().float().cpu() for k, v in a.model.state_dict().items()}
+
+    raw = torch.load(path, map_location="cpu", weights_only=True)          # nothing in the file needs unpickling of code
+    want_keys = set(open(os.path.join(os.path.dirname(__file__), "golden", "state_keys_small.txt")).read().split())
+    got_keys = set(k[len("model."):] for k in raw["state_dict"] if k.startswith("model."))
+    assert len(got_keys) == len(raw["state_dict"])
+    if len(want_keys) == len(got_keys):        # same layer count as the fixture: the key sets must be identical
+        assert got_keys == want_keys
+    assert raw["global_step"] == 2
+
+    r = fresh()
+    r.load_checkpoint(path)
+    assert r.iter == 2 and r.kliter == a.kliter - 2 and r.latent_transformer is True
+    for b in batches[2:]:
+        r.fused_training_step(b)
+    got = {k: v.detach().float().cpu() for k, v in r.model.state_dict().items()}
+    lr_sum = 4e-3        # generous bound on two Noam steps at this width (Adam moves noise-level elements by +-lr)
+    for k in ref:
+        assert (got[k] - ref[k]).abs().max() <= 2.5 * lr_sum, k
+        if ref[k].ndim == 2 and ref[k].numel() > 1000 and float((ref[k] - state.get(k, ref[k])).abs().max()) > 0 and k in state:
+            assert rel_err(got[k] - state[k], ref[k] - state[k]) < 0.05, (k, rel_err(got[k] - state[k], ref[k] - state[k]))
+    assert r.iter == a.iter and r.kliter == a.kliter
+
+    # a checkpoint shaped like the reference's own (extra Lightning entries, criterion buffers absent): tensors load, the rest is ignored
+    lit = {"epoch": 3, "global_step": 7, "pytorch-lightning_version": "1.1.8", "state_dict": raw["state_dict"], "optimizer_states": [],
+           "lr_schedulers": []}
+    p2 = str(tmp_path / "lightning.ckpt")
+    torch.save(lit, p2)
+    q = fresh()
+    q.load_checkpoint(p2)
+    assert q.iter == 7 and q.latent_transformer is True
+    w = q.model.state_dict()["decoder.output.weight"].float().cpu()
+    assert torch.equal(w, raw["state_dict"]["model.decoder.output.weight"])

@@ -357,20 +357,31 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const T* __restric
 // non-zero)
 template <typename T, typename TO>
 __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, TO* __restrict__ y, int N, int HW, int C, int count) {
+    // four adjacent lanes share one (image, 8-channel chunk) and split its positions: 4x the loads in flight of a thread-per-chunk walk
+    // (this kernel is pure load latency: 49-64 positions per output)
     const int cpr = C >> 3;
     const long total = (long)N * cpr;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % cpr);
-        const long n = i / cpr;
-        float a[8];
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long i = gid >> 2;
+    const int part = (int)(gid & 3);
+    float a[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = 0.f;
-        for (int p = 0; p < HW; ++p) {
+    for (int e = 0; e < 8; ++e) a[e] = 0.f;
+    const bool ok = i < total;
+    const int cc = ok ? (int)(i % cpr) : 0;
+    const long n = ok ? i / cpr : 0;
+    if (ok) {
+#pragma unroll 4
+        for (int p = part; p < HW; p += 4) {
             float v[8];
             Vec8<T>::load(x + (n * HW + p) * C + cc * 8, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) a[e] += v[e];
         }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] += __shfl_xor(a[e], 1, 64); a[e] += __shfl_xor(a[e], 2, 64); }
+    if (ok && part == 0) {
         const float inv = 1.f / (float)count;
 #pragma unroll
         for (int e = 0; e < 8; ++e) a[e] *= inv;
@@ -378,30 +389,51 @@ __global__ __launch_bounds__(256) void avgpool_kernel(const T* __restrict__ x, T
     }
 }
 
-// BatchNorm1d over the batch dimension: block = 64 columns x 4 row-lanes (coalesced across columns), LDS reduction.
+// BatchNorm1d over the batch dimension (B <= 16 * BN1D_RPT rows): block = 16 columns x 16 row lanes, every thread keeps its rows of a
+// column in registers, so the tensor is read once with all loads in flight (the kernels are pure latency: [128, 256] tensors) and the
+// batch reductions go through LDS.
+constexpr int BN1D_RPT = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void bn1d_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        T* __restrict__ y, float* __restrict__ mean, float* __restrict__ rstd,
                                                        float* __restrict__ rmean, float* __restrict__ rvar, int B, int C, float eps, float momentum) {
-    __shared__ float sh[4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ float sh[16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     const bool ok = c < C;
+    float v[BN1D_RPT];
     float s = 0.f;
-    if (ok) for (int b = ry; b < B; b += 4) s += to_f32(x[(long)b * C + c]);
+#pragma unroll
+    for (int i = 0; i < BN1D_RPT; ++i) {
+        const int b = ry + 16 * i;
+        v[i] = (ok && b < B) ? to_f32(x[(long)b * C + c]) : 0.f;
+        s += v[i];
+    }
     sh[ry][cx] = s;
     __syncthreads();
-    const float mu = (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) / (float)B;
+    float mu = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mu += sh[r][cx];
+    mu /= (float)B;
     __syncthreads();
     float q = 0.f;
-    if (ok) for (int b = ry; b < B; b += 4) { const float d = to_f32(x[(long)b * C + c]) - mu; q += d * d; }
+#pragma unroll
+    for (int i = 0; i < BN1D_RPT; ++i)
+        if (ry + 16 * i < B) { const float d = v[i] - mu; q += d * d; }
     sh[ry][cx] = q;
     __syncthreads();
-    const float var = (sh[0][cx] + sh[1][cx] + sh[2][cx] + sh[3][cx]) / (float)B;
+    float var = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) var += sh[r][cx];
+    var /= (float)B;
     const float rs = rsqrtf(var + eps);
     if (!ok) return;
     const float g = gamma[c], be = beta[c];
-    for (int b = ry; b < B; b += 4) y[(long)b * C + c] = from_f32<T>((to_f32(x[(long)b * C + c]) - mu) * rs * g + be);
+#pragma unroll
+    for (int i = 0; i < BN1D_RPT; ++i) {
+        const int b = ry + 16 * i;
+        if (b < B) y[(long)b * C + c] = from_f32<T>((v[i] - mu) * rs * g + be);
+    }
     if (ry == 0) {
         mean[c] = mu;
         rstd[c] = rs;
@@ -417,30 +449,35 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn1d_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, const float* __restrict__ gamma,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd, T* __restrict__ dx,
                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int C) {
-    __shared__ float sh[2][4][64];
-    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cx;
+    __shared__ float sh[2][16][17];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
     const bool ok = c < C;
     const float mu = ok ? mean[c] : 0.f, rs = ok ? rstd[c] : 0.f, g = ok ? gamma[c] : 0.f;
+    float d[BN1D_RPT], xh[BN1D_RPT];
     float s1 = 0.f, s2 = 0.f;
-    if (ok)
-        for (int b = ry; b < B; b += 4) {
-            const float d = to_f32(dy[(long)b * C + c]);
-            s1 += d;
-            s2 += d * (to_f32(x[(long)b * C + c]) - mu) * rs;
-        }
+#pragma unroll
+    for (int i = 0; i < BN1D_RPT; ++i) {
+        const int b = ry + 16 * i;
+        const bool in = ok && b < B;
+        d[i] = in ? to_f32(dy[(long)b * C + c]) : 0.f;
+        xh[i] = in ? (to_f32(x[(long)b * C + c]) - mu) * rs : 0.f;
+        s1 += d[i];
+        s2 += d[i] * xh[i];
+    }
     sh[0][ry][cx] = s1;
     sh[1][ry][cx] = s2;
     __syncthreads();
-    s1 = sh[0][0][cx] + sh[0][1][cx] + sh[0][2][cx] + sh[0][3][cx];
-    s2 = sh[1][0][cx] + sh[1][1][cx] + sh[1][2][cx] + sh[1][3][cx];
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s1 += sh[0][r][cx]; s2 += sh[1][r][cx]; }
     if (!ok) return;
     if (ry == 0) { dgamma[c] = s2; dbeta[c] = s1; }
     const float inv = 1.f / (float)B;
-    for (int b = ry; b < B; b += 4) {
-        const float d = to_f32(dy[(long)b * C + c]);
-        const float xh = (to_f32(x[(long)b * C + c]) - mu) * rs;
-        dx[(long)b * C + c] = from_f32<T>(g * rs * (d - s1 * inv - xh * s2 * inv));
+#pragma unroll
+    for (int i = 0; i < BN1D_RPT; ++i) {
+        const int b = ry + 16 * i;
+        if (b < B) dx[(long)b * C + c] = from_f32<T>(g * rs * (d[i] - s1 * inv - xh[i] * s2 * inv));
     }
 }
 
@@ -566,10 +603,11 @@ int blt_bn_relu_maxpool_pp(int dtype, const void* x, const float* scale, const f
 
 static int avgpool_impl(int dtype, const void* x, void* y, int N, int HW, int C, int count, int out_f32, hipStream_t s) {
     BLT_REQUIRE(x && y && C % 8 == 0 && N > 0 && HW > 0 && count > 0, "avgpool: bad args");
-    const long n = (long)N * (C / 8);
-    if (dtype == BLT_F32) hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const float*)x, (float*)y, N, HW, C, count);
-    else if (out_f32) hipLaunchKernelGGL((avgpool_kernel<bf16, float>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (float*)y, N, HW, C, count);
-    else hipLaunchKernelGGL((avgpool_kernel<bf16, bf16>), dim3(ew_grid(n)), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, HW, C, count);
+    const long n = (long)N * (C / 8) * 4;           // four lanes per output chunk
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (dtype == BLT_F32) hipLaunchKernelGGL((avgpool_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)x, (float*)y, N, HW, C, count);
+    else if (out_f32) hipLaunchKernelGGL((avgpool_kernel<bf16, float>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (float*)y, N, HW, C, count);
+    else hipLaunchKernelGGL((avgpool_kernel<bf16, bf16>), dim3(grid), dim3(256), 0, s, (const bf16*)x, (bf16*)y, N, HW, C, count);
     return blt_check_launch("avgpool");
 }
 int blt_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, int out_f32, hipStream_t s) {
@@ -583,17 +621,19 @@ int blt_avgpool_pp(int dtype, const void* x, void* y, int N, int H, int W, int C
 int blt_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                  float* running_mean, float* running_var, int B, int C, float eps, float momentum, hipStream_t s) {
     BLT_REQUIRE(x && gamma && beta && y && mean && rstd && B > 0 && C > 0, "bn1d_fwd: bad args");
+    BLT_REQUIRE(B <= 16 * BN1D_RPT, "bn1d_fwd: batch %d > %d", B, 16 * BN1D_RPT);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn1d_fwd_kernel<float>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum),
-               hipLaunchKernelGGL(bn1d_fwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum));
+               hipLaunchKernelGGL(bn1d_fwd_kernel<float>, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum),
+               hipLaunchKernelGGL(bn1d_fwd_kernel<bf16>, dim3(cdiv(C, 16)), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, running_mean, running_var, B, C, eps, momentum));
     return blt_check_launch("bn1d_fwd");
 }
 
 int blt_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                  void* dx, float* dgamma, float* dbeta, int B, int C, hipStream_t s) {
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta && B > 0 && C > 0, "bn1d_bwd: bad args");
+    BLT_REQUIRE(B <= 16 * BN1D_RPT, "bn1d_bwd: batch %d > %d", B, 16 * BN1D_RPT);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(bn1d_bwd_kernel<float>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, B, C),
-               hipLaunchKernelGGL(bn1d_bwd_kernel<bf16>, dim3(cdiv(C, 64)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, B, C));
+               hipLaunchKernelGGL(bn1d_bwd_kernel<float>, dim3(cdiv(C, 16)), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (float*)dx, dgamma, dbeta, B, C),
+               hipLaunchKernelGGL(bn1d_bwd_kernel<bf16>, dim3(cdiv(C, 16)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, dgamma, dbeta, B, C));
     return blt_check_launch("bn1d_bwd");
 }

@@ -135,6 +135,7 @@ int bltvqg_bn_apply(int dtype, const void* x, const float* scale, const float* s
 int bltvqg_bn_relu_maxpool(int dtype, const void* x, const float* scale, const float* shift, void* y, int N, int Hi, int Wi,
                            int C, void* stream);
 int bltvqg_avgpool(int dtype, const void* x, void* y, int N, int HW, int C, void* stream);
+/* BatchNorm1d over the batch dimension (encoder_cnn.py:21,34), B <= 512 rows: a thread keeps its rows of a column in registers */
 int bltvqg_bn1d_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                     float* running_mean, float* running_var, int B, int C, float eps, float momentum, void* stream);
 int bltvqg_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,

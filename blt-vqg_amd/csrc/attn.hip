@@ -14,19 +14,34 @@ namespace {
 // four waves per (batch, head): the tile is tiny, so the kernel is bound by LDS / global latency, not throughput — more waves
 // per workgroup (sharing one LDS image) hide it
 constexpr int ATT_THREADS = 256;
+// LDS row stride of a head slice (floats): d + 4 keeps rows 16-byte aligned, so the dot products and the P.V / dS.K products read
+// float4s (4x fewer LDS instructions than the d + 1 layout, which these latency-bound kernels feel directly); a stride of d + 4
+// floats still walks the banks from row to row
+__host__ __device__ __forceinline__ int att_dp(int d) { return ((d + 3) & ~3) + 4; }
+__device__ __forceinline__ float dot_rows(const float* a, const float* b, int d) {
+    float acc = 0.f;
+    if ((d & 3) == 0) {
+        for (int c = 0; c < d; c += 4) {
+            const float4 x = *reinterpret_cast<const float4*>(a + c), y = *reinterpret_cast<const float4*>(b + c);
+            acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+    } else {
+        for (int c = 0; c < d; ++c) acc += a[c] * b[c];
+    }
+    return acc;
+}
 
 // head slice [Tn, d] of a packed projection -> fp32 LDS rows of d+1 floats; 16-byte global loads when the layout allows
 template <typename T>
 __device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int b, int Tn, int h, int d, float* dst, int lane) {
-    const int dp = d + 1;
+    const int dp = att_dp(d);
     if ((d & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)src) & 15) == 0) {
         const int d8 = d >> 3;
         for (int idx = lane; idx < Tn * d8; idx += ATT_THREADS) {
             const int i = idx / d8, c = (idx - i * d8) * 8;
             float v[8];
             Vec8<T>::load(src + (size_t)(b * Tn + i) * ld + h * d + c, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) dst[i * dp + c + e] = v[e];
+            Vec8<float>::store(dst + i * dp + c, v);          // rows are 16-byte aligned (dp % 4 == 0)
         }
         return;
     }
@@ -52,8 +67,9 @@ __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, in
             for (int e = 0; e < 8; ++e) acc[e] = 0.f;
             for (int r = 0; r < nRed; ++r) {
                 const float w = TRANS ? Wt[r * tp + o] : Wt[o * tp + r];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w * X[r * dp + c + e];
+                const float4 x0 = *reinterpret_cast<const float4*>(X + r * dp + c), x1 = *reinterpret_cast<const float4*>(X + r * dp + c + 4);
+                acc[0] += w * x0.x; acc[1] += w * x0.y; acc[2] += w * x0.z; acc[3] += w * x0.w;
+                acc[4] += w * x1.x; acc[5] += w * x1.y; acc[6] += w * x1.z; acc[7] += w * x1.w;
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] *= scale;
@@ -73,28 +89,42 @@ __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, in
 // (transformer_layers.py:504-506), so a fully masked row becomes uniform, exactly like the reference.
 __device__ __forceinline__ void scores_softmax(const AttnArgs& a, int b, const float* Qs, const float* Ks, float* Pn,
                                                int lane) {
-    const int dp = a.d + 1, tp = a.Tk + 1;
+    const int dp = att_dp(a.d), tp = a.Tk + 1;
     for (int idx = lane; idx < a.Tq * a.Tk; idx += ATT_THREADS) {
         const int i = idx / a.Tk, j = idx - i * a.Tk;
-        float acc = 0.f;
-        for (int c = 0; c < a.d; ++c) acc += Qs[i * dp + c] * Ks[j * dp + c];
+        const float acc = dot_rows(Qs + i * dp, Ks + j * dp, a.d);
         const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal == 1 && j > i);
         // causal == 2: a future key does not exist for this query (greedy decoding re-runs the decoder on the PREFIX, iq.py:134-141),
         // so it is excluded from the softmax instead of being filled with -1e18 (matters only for fully pad-masked rows)
         Pn[i * tp + j] = (a.causal == 2 && j > i) ? -INFINITY : (masked ? -1e18f : acc * a.scale);
     }
     __syncthreads();
-    if (lane < a.Tq) {
+    // softmax: 8 lanes per row (rows of <= 64 keys: up to 8 keys per lane), 32 rows per pass
+    for (int row0 = 0; row0 < a.Tq; row0 += ATT_THREADS / 8) {
+        const int row = row0 + (lane >> 3), sub = lane & 7;
+        const bool rok = row < a.Tq;
+        float v[8];
         float m = -INFINITY;
-        for (int j = 0; j < a.Tk; ++j) m = fmaxf(m, Pn[lane * tp + j]);
-        float s = 0.f;
-        for (int j = 0; j < a.Tk; ++j) {
-            const float e = __expf(Pn[lane * tp + j] - m);
-            Pn[lane * tp + j] = e;
-            s += e;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = sub + 8 * k;
+            v[k] = (rok && j < a.Tk) ? Pn[row * tp + j] : -INFINITY;
+            m = fmaxf(m, v[k]);
         }
+        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            v[k] = (rok && sub + 8 * k < a.Tk) ? __expf(v[k] - m) : 0.f;
+            s += v[k];
+        }
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
         const float inv = 1.f / s;
-        for (int j = 0; j < a.Tk; ++j) Pn[lane * tp + j] *= inv;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = sub + 8 * k;
+            if (rok && j < a.Tk) Pn[row * tp + j] = v[k] * inv;
+        }
     }
     __syncthreads();
 }
@@ -104,7 +134,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnArgs a)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    const int dp = a.d + 1, tp = a.Tk + 1;
+    const int dp = att_dp(a.d), tp = a.Tk + 1;
     float* Qs = sm;
     float* Ks = Qs + a.Tq * dp;
     float* Vs = Ks + a.Tk * dp;
@@ -132,7 +162,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const AttnArgs a)
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lane = threadIdx.x;
     const int b = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
-    const int dp = a.d + 1, tp = a.Tk + 1;
+    const int dp = att_dp(a.d), tp = a.Tk + 1;
     float* Qs = sm;
     float* Ks = Qs + a.Tq * dp;
     float* Vs = Ks + a.Tk * dp;
@@ -150,8 +180,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const AttnArgs a)
     const float ks = (a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
     for (int idx = lane; idx < a.Tq * a.Tk; idx += ATT_THREADS) {
         const int i = idx / a.Tk, j = idx - i * a.Tk;
-        float g = 0.f;
-        for (int c = 0; c < a.d; ++c) g += dOs[i * dp + c] * Vs[j * dp + c];
+        const float g = dot_rows(dOs + i * dp, Vs + j * dp, a.d);
         bool keep = true;
         if (a.drop_p > 0.f) keep = dropout_keep(a.seed, a.stream_id, ((uint64_t)blockIdx.x * a.Tq + i) * a.Tk + j, thresh);
         Pd[i * tp + j] = keep ? Pn[i * tp + j] * ks : 0.f;
@@ -185,7 +214,7 @@ int check(const AttnArgs& a, bool bwd) {
 }
 
 size_t lds_bytes(const AttnArgs& a, bool bwd) {
-    const size_t dp = a.d + 1, tp = a.Tk + 1;
+    const size_t dp = att_dp(a.d), tp = a.Tk + 1;
     size_t f = (size_t)a.Tq * dp + 2 * (size_t)a.Tk * dp + (size_t)a.Tq * tp;
     if (bwd) f += (size_t)a.Tq * dp + 2 * (size_t)a.Tq * tp;
     return f * sizeof(float);

@@ -187,14 +187,30 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const AttnArgs a)
         dS[i * tp + j] = keep ? g * ks : 0.f;      // d(Pn)
     }
     __syncthreads();
-    if (lane < a.Tq) {
+    // softmax backward, 8 lanes per row like the forward: delta = sum_j dP * P, dS = P * (dP - delta) * scale
+    for (int row0 = 0; row0 < a.Tq; row0 += ATT_THREADS / 8) {
+        const int row = row0 + (lane >> 3), sub = lane & 7;
+        const bool rok = row < a.Tq;
+        float pv[8], gv[8];
         float delta = 0.f;
-        for (int j = 0; j < a.Tk; ++j) delta += dS[lane * tp + j] * Pn[lane * tp + j];
-        for (int j = 0; j < a.Tk; ++j) {
-            // masked_fill REPLACES the logit, so no gradient reaches a masked position — this matters for a fully
-            // masked row, whose probabilities are uniform (non-zero) rather than 0
-            const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal != 0 && j > lane);
-            dS[lane * tp + j] = masked ? 0.f : Pn[lane * tp + j] * (dS[lane * tp + j] - delta) * a.scale;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = sub + 8 * k;
+            const bool in = rok && j < a.Tk;
+            pv[k] = in ? Pn[row * tp + j] : 0.f;
+            gv[k] = in ? dS[row * tp + j] : 0.f;
+            delta += pv[k] * gv[k];
+        }
+        delta += __shfl_xor(delta, 1, 64); delta += __shfl_xor(delta, 2, 64); delta += __shfl_xor(delta, 4, 64);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = sub + 8 * k;
+            if (rok && j < a.Tk) {
+                // masked_fill REPLACES the logit, so no gradient reaches a masked position — this matters for a fully
+                // masked row, whose probabilities are uniform (non-zero) rather than 0
+                const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal != 0 && j > row);
+                dS[row * tp + j] = masked ? 0.f : pv[k] * (gv[k] - delta) * a.scale;
+            }
         }
     }
     __syncthreads();

@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbltvqg_hip.so")
+# BLTVQG_LIB: load another build of the SAME library (A/B timing of kernel changes on one GPU box); there is still no fallback
+LIB_PATH = os.environ.get("BLTVQG_LIB") or os.path.join(_HERE, "libbltvqg_hip.so")
 
 F32, BF16 = 0, 1
 

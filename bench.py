@@ -118,6 +118,12 @@ def main():
     from bltvqg_amd.engine import StepEngine, make_config
     from bltvqg_amd.trainer import DataParallelStep, init_reference_style
 
+    # A/B switches of the kernels (bltvqg_debug_set): BLT_DEBUG="key=value,key=value"
+    if os.environ.get("BLT_DEBUG"):
+        from bltvqg_amd import _lib as _l
+        for kv in os.environ["BLT_DEBUG"].split(","):
+            k, v = kv.split("=")
+            _l.load().bltvqg_debug_set(int(k), int(v))
     cfg = dict(CONFIGS[a.config])
     B = a.batch or cfg.pop("batch")
     cfg.pop("batch", None)

@@ -500,7 +500,7 @@ def _pp_pack(x_nhwc, dtype):
     return buf, body
 
 
-@pytest.mark.parametrize("geom", [(64, 64, 56, 56, 2), (128, 128, 28, 28, 3), (256, 256, 14, 14, 2), (512, 512, 7, 7, 5),
+@pytest.mark.parametrize("geom", [(64, 64, 56, 56, 2), (64, 64, 56, 56, 13), (64, 64, 24, 40, 37), (128, 128, 28, 28, 3), (256, 256, 14, 14, 2), (512, 512, 7, 7, 5),
                                   (64, 128, 9, 13, 1), (128, 64, 20, 33, 2), (192, 64, 5, 62, 1)])
 def test_conv3x3_pp_exact_integer_and_stats(geom):
     """The LDS-patch 3x3 convolution (csrc/conv_pp.hip) against F.conv2d on integer data: exact outputs at every real pixel, exact

@@ -73,6 +73,22 @@ def active_buckets(buckets, phase2):
     return [(i, off, n) for i, (off, n, late) in enumerate(buckets) if phase2 or not late]
 
 
+def comm_plan(buckets, phase2):
+    """The collectives of one step as (bucket ids to wait for, offset, count).  Bucket 0 (decoder) is final early and goes alone, under
+    the encoder backward; the remaining active buckets become final together at the end of backward and are adjacent in the flat
+    buffer, so they travel as ONE collective (each extra one costs a launch and a ring latency on the exposed tail)."""
+    act = active_buckets(buckets, phase2)
+    plan = [([act[0][0]], act[0][1], act[0][2])]
+    rest = act[1:]
+    if rest:
+        contiguous = all(rest[k][1] + rest[k][2] == rest[k + 1][1] for k in range(len(rest) - 1))
+        if contiguous:
+            plan.append(([b[0] for b in rest], rest[0][1], sum(b[2] for b in rest)))
+        else:
+            plan.extend(([b[0]], b[1], b[2]) for b in rest)
+    return plan
+
+
 def allreduce_bucket(dist, flat_grad, off, n):
     """Mean of one contiguous gradient bucket across ranks, in place (RCCL has AVG; gloo — used by the CPU tests — only SUM)."""
     view = flat_grad[off:off + n]
@@ -107,8 +123,9 @@ class DataParallelStep(object):
     def reduce_gradients(self, phase2):
         e, dist = self.e, self.dist
         main = torch.cuda.current_stream(e.device)
-        for i, off, n in active_buckets(self.buckets, phase2):
-            e.bucket_wait(i, self.comm)          # the side stream waits for the engine's "bucket i is final" event
+        for ids, off, n in comm_plan(self.buckets, phase2):
+            for i in ids:
+                e.bucket_wait(i, self.comm)      # the side stream waits for the engine's "bucket i is final" event(s)
             with torch.cuda.stream(self.comm):
                 allreduce_bucket(dist, e.flat_grad, off, n)
         if not self.overlap_optimizer:

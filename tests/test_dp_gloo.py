@@ -27,7 +27,7 @@ def _worker(rank, world, port, out):
     from bltvqg_amd.engine import StepEngine, make_config
     from bltvqg_amd.iq import IQ
     from bltvqg_amd.train_iq import SyntheticVocabulary
-    from bltvqg_amd.trainer import active_buckets, allreduce_bucket, shard_seed
+    from bltvqg_amd.trainer import active_buckets, allreduce_bucket, comm_plan, shard_seed
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,6 +50,15 @@ def _worker(rank, world, port, out):
                 assert torch.allclose(g[lo:], want[lo:], rtol=1e-6)
             else:   # untouched before the phase switch
                 assert torch.equal(g[lo:], torch.full((n - lo,), float(rank + 1)) + torch.arange(lo, n, dtype=torch.float32) * 1e-3 * (rank + 1))
+            # the step's actual collectives (DataParallelStep.reduce_gradients): decoder bucket alone, the rest merged into one
+            plan = comm_plan(buckets, phase2)
+            assert len(plan) == 2 and plan[0] == ([0], buckets[0][0], buckets[0][1])
+            assert plan[1][0] == ([1, 2] if phase2 else [1]) and plan[1][1] == buckets[1][0]
+            assert plan[1][2] == (buckets[1][1] + buckets[2][1] if phase2 else buckets[1][1])
+            g2 = torch.full((n,), float(rank + 1)) + torch.arange(n, dtype=torch.float32) * 1e-3 * (rank + 1)
+            for ids, off, cnt in plan:
+                allreduce_bucket(dist, g2, off, cnt)
+            assert torch.equal(g2, g)
             res[phase2] = True
         # identical initial weights on every rank (same seed), different data shards
         args = SimpleNamespace(emb_dim=20, hidden_dim=64, latent_dim=64, pwffn_dim=128, num_layers=1, num_heads=4, device="cpu", emb_file=None,

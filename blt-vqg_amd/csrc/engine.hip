@@ -112,6 +112,8 @@ struct bltvqg_engine {
     void *d_enc, *d_renc, *dX_all, *dE, *d_feats, *d_zproj, *d_recon, *dzl;
     void *g_b1, *g_b2, *g_b3, *g_b4, *g_cat, *g_mq;   // small [B, *] scratch
     void *g_rec1, *g_net[2][2];                      // [B, *] gradients that are operands of deferred weight-gradient GEMMs (never reused)
+    void *g_rin, *g_zc;                              // d(reconstructor input), d(z_classifier input): produced on the branch stream
+    float* acc_big2;                                 // split-K accumulator of the z_classifier dgrad (branch stream)
     hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
     // side streams: independent sub-graphs (CNN | posterior encoder | context encoder) run concurrently so that their small
     // launches (40-160 workgroups each) fill the 256 CUs together; fork/join with events (capturable into a hipGraph)
@@ -398,6 +400,8 @@ struct bltvqg_engine {
         const int64_t wide = (int64_t)B * (2 * Z > F ? 2 * Z : F);
         g_b1 = AT(wide); g_b2 = AT(wide); g_b3 = AT(wide); g_b4 = AT(wide); g_cat = AT((int64_t)B * 2 * H); g_mq = AT((int64_t)B * 2 * Z);
         g_rec1 = AT((int64_t)B * F);
+        g_rin = AT((int64_t)B * H); g_zc = AT((int64_t)B * H);
+        acc_big2 = AF((int64_t)B * H);
         for (int n = 0; n < 2; ++n) for (int k = 0; k < 2; ++k) g_net[n][k] = AT((int64_t)B * 2 * Z);
         return off;
     }
@@ -500,7 +504,8 @@ struct bltvqg_engine {
 
     // dX = dY W with a vocabulary-sized contraction (K = V): few output tiles and a long K loop, so the K range is split over
     // workgroups into an fp32 scratch (atomics) and cast back; falls through to the plain kernel in fp32 mode / small V
-    int dgrad_bigk(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M, hipStream_t s) {
+    int dgrad_bigk(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M, hipStream_t s, float* acc_buf = nullptr,
+                   size_t acc_floats = 0) {
         if (dt != BLT_BF16 || tpi(wname).dims[0] < 2048) return blt_gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
         // enough rows to fill the chip with 64x64 tiles (the decoder's output projection: 40 x 4 tiles, 125 K-tiles each on a deep ring):
         // the k-contiguous form through the transposed shadow needs no fp32 scratch, memset or cast
@@ -512,8 +517,8 @@ struct bltvqg_engine {
             const PInfo& p = tpi(wname);
             g = mk(dY, ldy, 0, w, ldw, 1, dX, ldx, M, p.dims[1], p.dims[0]);
         }
-        float* acc = acc_big;
-        if ((size_t)M * g.N > (size_t)(Mp > Mt ? Mp : Mt) * H) return blt_gemm(dt, g, s);
+        float* acc = acc_buf ? acc_buf : acc_big;
+        if ((size_t)M * g.N > (acc_buf ? acc_floats : (size_t)(Mp > Mt ? Mp : Mt) * H)) return blt_gemm(dt, g, s);
         if (hipMemsetAsync(acc, 0, (size_t)M * g.N * 4, s) != hipSuccess) { blt_set_error("dgrad_bigk: memset failed"); return BLT_ERR_HIP; }
         g.C = acc; g.ldc = g.N; g.out_f32 = 1; g.split_k = 16;
         { const int rc_ = blt_gemm(dt, g, s); if (rc_) return rc_; }
@@ -1066,6 +1071,23 @@ struct bltvqg_engine {
         // every weight gradient from here on is collected and issued on a side stream at the next flush point (their operands live
         // in buffers that nothing overwrites during this backward pass); only the input-gradient chain stays on `s`
         defer_wgrads = use_streams;
+        // ---- branch stream: the reconstructor's and z_classifier's input gradients depend on the loss kernels only; they run on side[0]
+        // under the decoder chain and are summed into the row-0 gradients behind it (row0_sums) ----
+        hipStream_t sbr = use_streams ? side[0] : s;
+        if (sbr != s) RC(fork(s, sbr, fj[15]));
+        RC(wgrad_later(d_recon, H, hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", B, s));
+        {
+            GemmArgs g = dgrad(d_recon, H, "image_reconstructor.layers.fc1.weight", g_rec1, F, B);
+            g.maskY = hrec; g.ldm = F; g.mask_scale = 1.f;
+            RC(blt_gemm(dt, g, sbr));
+        }
+        RC(wgrad_later(g_rec1, F, r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", B, s));
+        RC(blt_gemm(dt, dgrad(g_rec1, F, "image_reconstructor.layers.fc0.weight", g_rin, H, B), sbr));   // d r_in
+        if (phase2) {
+            RC(wgrad_later(dzl, ldV, zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", B, s));
+            RC(dgrad_bigk(dzl, ldV, "decoder.z_classifier.weight", g_zc, H, B, sbr, acc_big2, (size_t)B * H));
+        }
+        if (sbr != s && hipEventRecord(fj[12], sbr) != hipSuccess) { blt_set_error("backward: event record failed"); return BLT_ERR_HIP; }
         // ---- vocabulary projection + decoder ----
         RC(wgrad_later(logits, ldV, dec.out, H, "decoder.output.weight", "decoder.output.bias", Mt, s));
         void* gA = sA[0];
@@ -1078,30 +1100,14 @@ struct bltvqg_engine {
                                  dec.layers[L - 1].y2, relu_ks(), dec.layers[L - 1].gY));
         }
         RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
+        if (sbr != s && hipStreamWaitEvent(s, fj[12], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
         // the decoder's weight gradients run on side[1] from here on, under the rest of backward; bucket 0 (decoder.*) is complete when
         // that stream gets here
         RC(flush_wgrads(s, side[1], fj[6]));
         if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], use_streams ? side[1] : s);
-        // target_embedding[:,0] += image_features (+ z)
-        RC(blt_rows_add(dt, d_feats, H, dxT, (long)T * H, nullptr, 0, B, H, 1, s));
-        if (phase2) RC(blt_rows_add(dt, d_zproj, H, dxT, (long)T * H, nullptr, 0, B, H, 0, s));
-        // ---- image reconstructor ----
-        RC(wgrad_later(d_recon, H, hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", B, s));
-        {
-            GemmArgs g = dgrad(d_recon, H, "image_reconstructor.layers.fc1.weight", g_rec1, F, B);
-            g.maskY = hrec; g.ldm = F; g.mask_scale = 1.f;
-            RC(blt_gemm(dt, g, s));
-        }
-        RC(wgrad_later(g_rec1, F, r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", B, s));
-        RC(blt_gemm(dt, dgrad(g_rec1, F, "image_reconstructor.layers.fc0.weight", g_b2, H, B), s));   // d r_in
-        RC(blt_rows_add(dt, d_enc, (long)Sa * H, g_b2, H, nullptr, 0, B, H, 1, s));
+        // target_embedding[:,0] += image_features (+ z); r_in = encoder row 0 (+ z); zc_in = z + image_features
+        RC(blt_row0_sums(dt, dxT, (long)T * H, g_rin, phase2 ? g_zc : nullptr, d_feats, phase2 ? d_zproj : nullptr, d_enc, (long)Sa * H, B, H, s));
         if (phase2) {
-            RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
-            // ---- z_classifier ----
-            RC(wgrad_later(dzl, ldV, zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", B, s));
-            RC(dgrad_bigk(dzl, ldV, "decoder.z_classifier.weight", g_b2, H, B, s));
-            RC(blt_rows_add(dt, d_zproj, H, g_b2, H, nullptr, 0, B, H, 1, s));
-            RC(blt_rows_add(dt, d_feats, H, g_b2, H, nullptr, 0, B, H, 1, s));
             // ---- latent projection, reparameterisation + KL, prior / posterior nets ----
             RC(wgrad_later(d_zproj, H, zlat, Z, "latent_projection.weight", "latent_projection.bias", B, s));
             RC(blt_gemm(dt, dgrad(d_zproj, H, "latent_projection.weight", g_b3, Z, B), s));   // dz

@@ -163,6 +163,9 @@ int blt_prep_tokens(const long long* ctx, const long long* post, const long long
 int blt_rows_add(int dtype, void* y, long ystride, const void* a, long astride, const void* c, long cstride, int B, int n,
                  int accumulate, hipStream_t s);
 // y = dy * (ymask != 0) * scale
+// d_feats += dx0 + g_zc; d_zproj = dx0 + g_rin + g_zc (if non-null); d_enc[:,0] += g_rin   (misc.hip: the row-0 injections' backward)
+int blt_row0_sums(int dtype, const void* dx0, long sdx, const void* g_rin, const void* g_zc, void* d_feats, void* d_zproj, void* d_enc, long senc,
+                  int B, int n, hipStream_t s);
 int blt_mask_scale(int dtype, const void* dy, const void* ymask, void* y, long n, float scale, hipStream_t s);
 // out[n] (+)= sum_m x[m, n]
 int blt_colsum(int dtype, const void* x, int ld, long M, int N, float* out, int accumulate, hipStream_t s);

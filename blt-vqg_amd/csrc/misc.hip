@@ -99,6 +99,26 @@ __global__ void rows_add_kernel(T* __restrict__ y, long ys, const T* __restrict_
     }
 }
 
+// The gradient bookkeeping of the "row 0" injections (iq.py:95-105: image feature and z are ADDED to token 0 of the decoder input, z +
+// encoder row 0 feed the reconstructor, z + feature feed z_classifier) in one launch instead of six rows_add launches:
+//   d_feats += dx0 + g_zc ;  d_zproj = dx0 + g_rin + g_zc (latent phase) ;  d_enc[:,0] += g_rin
+// dx0 = d(decoder input)[:,0], g_rin = d(reconstructor input), g_zc = d(z_classifier input); null pointers drop their terms.
+template <typename T>
+__global__ void row0_sums_kernel(const T* __restrict__ dx0, long sdx, const T* __restrict__ g_rin, const T* __restrict__ g_zc, T* __restrict__ d_feats,
+                                 T* __restrict__ d_zproj, T* __restrict__ d_enc, long senc, int B, int n) {
+    const long total = (long)B * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / n;
+        const int j = (int)(i - b * n);
+        const float x = to_f32(dx0[b * sdx + j]);
+        const float r = g_rin ? to_f32(g_rin[i]) : 0.f;
+        const float z = g_zc ? to_f32(g_zc[i]) : 0.f;
+        d_feats[i] = from_f32<T>(to_f32(d_feats[i]) + x + z);
+        if (d_zproj) d_zproj[i] = from_f32<T>(x + r + z);
+        if (g_rin) d_enc[b * senc + j] = from_f32<T>(to_f32(d_enc[b * senc + j]) + r);
+    }
+}
+
 template <typename T>
 __global__ void mask_scale_kernel(const T* __restrict__ dy, const T* __restrict__ ym, T* __restrict__ y, long nchunks, float scale) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nchunks; i += (long)gridDim.x * blockDim.x) {
@@ -629,6 +649,19 @@ int blt_rows_add(int dtype, void* y, long ys, const void* a, long as, const void
     if (dtype == BLT_F32) hipLaunchKernelGGL(rows_add_kernel<float>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (float*)y, ys, (const float*)a, as, (const float*)c, cs, B, n, accumulate);
     else hipLaunchKernelGGL(rows_add_kernel<bf16>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (bf16*)y, ys, (const bf16*)a, as, (const bf16*)c, cs, B, n, accumulate);
     return blt_check_launch("rows_add");
+}
+
+int blt_row0_sums(int dtype, const void* dx0, long sdx, const void* g_rin, const void* g_zc, void* d_feats, void* d_zproj, void* d_enc, long senc,
+                  int B, int n, hipStream_t s) {
+    CHECK_DTYPE(dtype, "row0_sums");
+    BLT_REQUIRE(dx0 && d_feats && (g_rin == nullptr || d_enc != nullptr) && B > 0 && n > 0, "row0_sums: bad args");
+    if (dtype == BLT_F32)
+        hipLaunchKernelGGL(row0_sums_kernel<float>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (const float*)dx0, sdx, (const float*)g_rin,
+                           (const float*)g_zc, (float*)d_feats, (float*)d_zproj, (float*)d_enc, senc, B, n);
+    else
+        hipLaunchKernelGGL(row0_sums_kernel<bf16>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (const bf16*)dx0, sdx, (const bf16*)g_rin,
+                           (const bf16*)g_zc, (bf16*)d_feats, (bf16*)d_zproj, (bf16*)d_enc, senc, B, n);
+    return blt_check_launch("row0_sums");
 }
 
 int blt_mask_scale(int dtype, const void* dy, const void* ym, void* y, long n, float scale, hipStream_t s) {

@@ -1063,6 +1063,18 @@ struct bltvqg_engine {
         return BLT_OK;
     }
 
+    // CNN head: BatchNorm1d -> fc backward in fp32 (the backbone itself is frozen, encoder_cnn.py:18-19); bias gradient from the GEMM's dY
+    // staging registers
+    int cnn_head_bwd(hipStream_t s) {
+        RC(blt_cast_rows(dt, d_feats, H, BLT_F32, dfeats32, H, B, H, s));
+        RC(blt_bn1d_bwd(BLT_F32, dfeats32, featpre, P("encoder_cnn.bn.weight"), bn1_mean, bn1_rstd, dfeatpre32, G("encoder_cnn.bn.weight"),
+                        G("encoder_cnn.bn.bias"), B, H, s));
+        const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
+        GemmArgs g = mk(dfeatpre32, H, 1, pooled, 512, 1, grad + pw.off, 512, H, 512, B);
+        g.accumulate = 1; g.a_rowsum = G("encoder_cnn.cnn.fc.bias");
+        return blt_gemm(BLT_F32, g, s);
+    }
+
     // Everything downstream of the loss-gradient seeds: `logits` holds d(output), dzl holds d(z_logit) (phase 2),
     // d_feats holds the direct gradient of image_features, d_recon that of the reconstruction.
     int backward_core(float kld_g, hipStream_t s) {
@@ -1121,6 +1133,9 @@ struct bltvqg_engine {
         }
         // encoder_outputs[:,0] += image_features
         RC(blt_rows_add(dt, d_feats, H, d_enc, (long)Sa * H, nullptr, 0, B, H, 1, s));
+        // d(image feature) is final here, long before the encoder chains are: the CNN head's backward (BatchNorm1d -> fc) goes to the
+        // weight-gradient stream now instead of closing the chain
+        if (use_streams) { RC(fork(s, side[1], fj[13])); RC(cnn_head_bwd(side[1])); }
         int Memb = Ma + Mt;
         hipStream_t s0 = (use_streams && phase2) ? side[0] : s;
         if (phase2) {
@@ -1151,28 +1166,22 @@ struct bltvqg_engine {
         RC(flush_wgrads(s, side[1], fj[8]));
         defer_wgrads = false;
         if (s0 != s && hipStreamWaitEvent(s, fj[5], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
-        // ---- shared embedding (rows of the streams that received gradient) ----
+        // ---- shared embedding (rows of the streams that received gradient): weight + bias gradient to the side stream, the gradient of
+        // the embedding table stays here (it closes the chain) ----
         {
             const PInfo& pw = tpi("embedding.1.weight");
             GemmArgs g = mk(dX_all, H, 1, emb_rows, Epad, 1, grad + pw.off, E, H, E, Memb);
-            g.out_f32 = 1; g.split_k = 32;
-            RC(blt_gemm(dt, g, s));
-            RC(blt_colsum(dt, dX_all, H, Memb, H, G("embedding.1.bias"), 1, s));
+            g.out_f32 = 1; g.split_k = 32; g.a_rowsum = G("embedding.1.bias");
+            defer_wgrads = use_streams;
+            RC(wgrad_later(g, s));
+            RC(flush_wgrads(s, side[1], fj[8]));
+            defer_wgrads = false;
             int ldw;
             const void* w = W("embedding.1.weight", &ldw);
             RC(blt_gemm(dt, mk(dX_all, H, 0, w, ldw, 1, dE, Epad, Memb, E, H), s));
             RC(blt_embed_scatter(dt, dE, Epad, ids_all, G("embedding.0.weight"), Memb, E, 0, s));
         }
-        // ---- CNN head: BatchNorm1d -> fc (the backbone itself is frozen, encoder_cnn.py:18-19) ----
-        RC(blt_cast_rows(dt, d_feats, H, BLT_F32, dfeats32, H, B, H, s));
-        RC(blt_bn1d_bwd(BLT_F32, dfeats32, featpre, P("encoder_cnn.bn.weight"), bn1_mean, bn1_rstd, dfeatpre32, G("encoder_cnn.bn.weight"),
-                        G("encoder_cnn.bn.bias"), B, H, s));
-        {
-            const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
-            GemmArgs g = mk(dfeatpre32, H, 1, pooled, 512, 1, grad + pw.off, 512, H, 512, B);
-            RC(blt_gemm(BLT_F32, g, s));
-            RC(blt_colsum(BLT_F32, dfeatpre32, H, B, H, G("encoder_cnn.cnn.fc.bias"), 1, s));
-        }
+        if (!use_streams) RC(cnn_head_bwd(s));
         if (use_streams) {      // join the weight-gradient streams
             RC(fork(side[1], s, fj[9]));
             if (s0 != s) RC(fork(s0, s, fj[10]));
@@ -1191,14 +1200,17 @@ struct bltvqg_engine {
         BLT_REQUIRE(bound && fwd_done, "engine_loss_backward: forward has not run");
         if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
         RC(zero_grads(s));
-        // train_iq.py:81-103
-        RC(blt_ce_fwd_bwd(dt, logits, ldV, tgt32, Mt, V, counters, 1.f, stats + 0, 1, s));
-        RC(blt_mse_fwd_bwd(dt, feats, recon, (long)B * H, c.image_recon_lambda, stats + 1, d_feats, d_recon, s));
+        // train_iq.py:81-103.  The token cross-entropy (41 MB of logits) leads the decoder chain; the image-reconstruction MSE and the
+        // bag-of-words CE only feed the branch stream's work (backward_core) and run there, beside it.
+        hipStream_t sbr = use_streams ? side[0] : s;
+        if (sbr != s) RC(fork(s, sbr, fj[11]));
+        RC(blt_mse_fwd_bwd(dt, feats, recon, (long)B * H, c.image_recon_lambda, stats + 1, d_feats, d_recon, sbr));
         float kld_g = 0.f;
         if (phase2) {
-            RC(blt_bow_ce_fwd_bwd(dt, zlogit, ldV, tgt32, B, T, V, counters, c.aux_ceiling, stats + 3, dzl, s));
+            RC(blt_bow_ce_fwd_bwd(dt, zlogit, ldV, tgt32, B, T, V, counters, c.aux_ceiling, stats + 3, dzl, sbr));
             kld_g = c.kl_ceiling * kl_weight;
         }
+        RC(blt_ce_fwd_bwd(dt, logits, ldV, tgt32, Mt, V, counters, 1.f, stats + 0, 1, s));
         return backward_core(kld_g, s);
     }
 

@@ -79,6 +79,9 @@ SIGNATURES = {
     "bltvqg_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, I, P]),
     "bltvqg_dropout_mask": (I, [U64, U32, L, I, I, F, P, P]),
     "bltvqg_cast": (I, [I, P, I, I, P, I, L, I, P]),
+    "bltvqg_image_store_u8": (I, [P, P, L, P]),
+    "bltvqg_batch_rows": (I, [P, P, P, P, I, L, P, I, I, I, P, P, P, P, P, P]),
+    "bltvqg_batch_images": (I, [P, L, I, P, L, P, P, P, I, I, I, ctypes.POINTER(ctypes.c_float), P, P, P]),
     "bltvqg_engine_create": (P, [ctypes.POINTER(Config)]),
     "bltvqg_engine_destroy": (None, [P]),
     "bltvqg_engine_num_params": (I, [P, I]),

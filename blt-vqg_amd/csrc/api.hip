@@ -245,4 +245,22 @@ int bltvqg_cast(int dtype_src, const void* src, int ld_src, int dtype_dst, void*
     return blt_cast_rows(dtype_src, src, ld_src, dtype_dst, dst, ld_dst, (long)rows, cols, (hipStream_t)stream);
 }
 
+int bltvqg_image_store_u8(const float* images, uint8_t* out, int64_t count, void* stream) {
+    return blt_image_store_u8(images, out, (long)count, (hipStream_t)stream);
+}
+int bltvqg_batch_rows(const int32_t* questions, const int32_t* answers, const int32_t* answer_types, const int32_t* cat_word_ids, int n_cat,
+                      int64_t n_rows, const int64_t* index, int B, int q_len, int a_len, int64_t* out_questions, int64_t* out_posteriors,
+                      int64_t* out_answers, int64_t* out_answer_types, int64_t* out_types_for_input, void* stream) {
+    BLT_REQUIRE(q_len >= 2 && a_len >= 2, "batch_rows: rows shorter than 2 tokens");
+    return blt_batch_rows(questions, answers, answer_types, cat_word_ids, n_cat, (long)n_rows, (const long*)index, B, q_len, a_len,
+                          (long*)out_questions, (long*)out_posteriors, (long*)out_answers, (long*)out_answer_types, (long*)out_types_for_input,
+                          (hipStream_t)stream);
+}
+int bltvqg_batch_images(const uint8_t* table, int64_t n_images, int S, const int32_t* image_indices, int64_t n_rows, const int64_t* index,
+                        const int32_t* boxes, const int32_t* coeffs, int KS, int B, int osz, const float* mean_std, float* out,
+                        uint8_t* out_u8, void* stream) {
+    return blt_batch_images(table, (long)n_images, S, image_indices, (long)n_rows, (const long*)index, boxes, coeffs, KS, B, osz, mean_std, out,
+                            out_u8, (hipStream_t)stream);
+}
+
 }  // extern "C"

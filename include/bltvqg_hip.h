@@ -176,6 +176,31 @@ int bltvqg_dropout_mask(uint64_t seed, uint32_t stream_id, int64_t rows, int col
 int bltvqg_cast(int dtype_src, const void* src, int ld_src, int dtype_dst, void* dst, int ld_dst, int64_t rows, int cols,
                 void* stream);
 
+/* ---------------- batch producer ----------------
+ * Replaces, for a store that lives in HBM, what the reference does per sample on host workers: IQDataset.__getitem__
+ * (utils/data_loader.py:45-129), collate_fn's stacking (utils/data_loader.py:150-163) and the image transform
+ * (train_iq.py:264-272).  All pointers are device pointers unless noted. */
+/* ToTensor -> ToPILImage on a stored float HWC image (train_iq.py:265-266): out[i] = byte(255 * images[i]), fp32 product, truncation,
+ * wrap modulo 256 (|255 x| < 2^31).  images 16-B aligned, out 4-B aligned. */
+int bltvqg_image_store_u8(const float* images, uint8_t* out, int64_t count, void* stream);
+/* Token rows of the samples index[0..B) (data_loader.py:59-86,115-116), int64 like collate_fn's .long():
+ * questions [B,q_len], posteriors [B,q_len+1], answers [B,a_len+1], answer_types [B] (category WORD ids),
+ * answer_types_for_input [B,3].  Stored tables are int32: questions [n_rows,q_len], answers [n_rows,a_len], answer_types [n_rows]
+ * (index into cat_word_ids[n_cat], the vocabulary ids of the sorted category names, data_loader.py:42,78-79).  An index outside
+ * [0,n_rows) yields all-zero rows. */
+int bltvqg_batch_rows(const int32_t* questions, const int32_t* answers, const int32_t* answer_types, const int32_t* cat_word_ids, int n_cat,
+                      int64_t n_rows, const int64_t* index, int B, int q_len, int a_len, int64_t* out_questions, int64_t* out_posteriors,
+                      int64_t* out_answers, int64_t* out_answer_types, int64_t* out_types_for_input, void* stream);
+/* Images of the samples index[0..B): gather table[image_indices[index[b]]] (uint8 HWC [n_images,S,S,3]), crop boxes[b] =
+ * (top,left,h,w), resize to osz x osz as Pillow's resize(BILINEAR) does for 8-bit images (horizontal pass rounded to 8 bits, then
+ * vertical, 22-bit fixed-point weights), /255, (x-mean)/std -> out fp32 [B,3,osz,osz]; out_u8 (optional) receives the resized bytes
+ * [B,osz,osz,3].  coeffs int32 [B,2,osz,2+KS] = per output column (then row): first source pixel inside the crop, tap count, KS
+ * weights — from blt-vqg_amd/batch.py::resample_coeffs; NULL / KS 0 when every box is osz x osz (copy).  mean_std: 6 HOST floats
+ * (mean rgb, std rgb).  Out-of-range indices/boxes produce the transform of a black pixel; no out-of-bounds access is possible. */
+int bltvqg_batch_images(const uint8_t* table, int64_t n_images, int S, const int32_t* image_indices, int64_t n_rows, const int64_t* index,
+                        const int32_t* boxes, const int32_t* coeffs, int KS, int B, int osz, const float* mean_std, float* out,
+                        uint8_t* out_u8, void* stream);
+
 /* ---------------- train-step engine ---------------- */
 
 typedef struct bltvqg_config {

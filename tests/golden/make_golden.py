@@ -5,7 +5,7 @@ Imports the real reference model (`/root/reference/models/*.py`) with three offl
 forward/backward in both training phases with dropout disabled and an injected eps, and stores
 inputs + reference outputs as small .npz files next to this script.  No reference source is copied.
 
-    python tests/golden/make_golden.py
+    python tests/golden/make_golden.py [config names]
 """
 import importlib.util
 import os
@@ -160,6 +160,9 @@ CONFIGS = {
     # small = BASELINE.json configs[0] model (2-layer, d_model 256) at B=8, 224x224: summaries only
     "small": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=256, latent_dim=256, pwffn_dim=512, num_layers=2, num_heads=4,
                                       vocab_size=8000), B=8, hw=224, seed=13, full=False),
+    # big = BASELINE.json configs[2..3] model (6-layer, d_model 512, 8 heads, F 2048) at B=4, 224x224: summaries only
+    "big": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=512, latent_dim=512, pwffn_dim=2048, num_layers=6, num_heads=8,
+                                    vocab_size=8000), B=4, hw=224, seed=14, full=False),
 }
 
 
@@ -168,7 +171,10 @@ def main():
     torch.manual_seed(0)
     np.random.seed(0)
     hp = O.default_hp()
+    only = sys.argv[1:]                  # `python make_golden.py big` regenerates one fixture
     for name, c in CONFIGS.items():
+        if only and name not in only:
+            continue
         cfg = c["cfg"]
         spec = O.iq_spec(cfg)
         state = synth_state(spec, seed=c["seed"])

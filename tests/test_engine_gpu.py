@@ -134,10 +134,12 @@ def test_engine_bf16_within_stated_tolerance(name, phase2):
     assert worst[0] < 0.35, worst
 
 
-def test_engine_small_cfg_fp32_matches_reference_golden():
-    """BASELINE.json configs[0] model (2-layer, d_model 256, 224x224 images, V=8000) at B=8: summary fixture."""
+@pytest.mark.parametrize("name", ["small", "big"])
+def test_engine_small_cfg_fp32_matches_reference_golden(name):
+    """BASELINE.json configs[0..1] model (2-layer, d_model 256, 224x224 images, V=8000) at B=8 and configs[2..3] model (6-layer,
+    d_model 512, 8 heads, F 2048) at B=4: summary fixtures produced by the reference."""
     from oracle import iq_oracle as O
-    z, cfg, state, batch = load_golden("small")
+    z, cfg, state, batch = load_golden(name)
     B, hw = int(z["meta_cfg"][7]), int(z["meta_cfg"][8])
     e = _engine(cfg, B, hw, 0)
     e.load_state(state)
@@ -162,10 +164,11 @@ def test_engine_small_cfg_fp32_matches_reference_golden():
             assert abs(got - g) <= 3e-3 * max(g, 1e-6) + 1e-6, (n, got, g)
 
 
-def test_engine_small_cfg_bf16_within_stated_tolerance():
-    """bf16 engine on the 224x224 fixture: loss within 2 % (relative) of the reference, sampled logits within 5 %."""
+@pytest.mark.parametrize("name", ["small", "big"])
+def test_engine_small_cfg_bf16_within_stated_tolerance(name):
+    """bf16 engine on the 224x224 fixtures: loss within 2 % (relative) of the reference, sampled logits within 5 %."""
     from oracle import iq_oracle as O
-    z, cfg, state, batch = load_golden("small")
+    z, cfg, state, batch = load_golden(name)
     B, hw = int(z["meta_cfg"][7]), int(z["meta_cfg"][8])
     e = _engine(cfg, B, hw, 1)
     for phase2 in (False, True):
@@ -177,7 +180,7 @@ def test_engine_small_cfg_bf16_within_stated_tolerance():
         err = rel_err(r["output"].reshape(-1)[idx], z[tag + ".output_sample"])
         st = r["stats"]
         total = st["rec"] + 0.1 * st["img"] + (0.5 * kl_w * st["kld"] + st["aux"] if phase2 else 0.0)
-        print("bf16 small %s: logits rel %.4f, feats rel %.4f, loss %.4f vs %.4f" % (tag, err, rel_err(r["feats"], z[tag + ".feats"]), total,
+        print("bf16 " + name + " %s: logits rel %.4f, feats rel %.4f, loss %.4f vs %.4f" % (tag, err, rel_err(r["feats"], z[tag + ".feats"]), total,
                                                                                     float(z[tag + ".loss"])))
         assert err < 5e-2
         assert abs(total - float(z[tag + ".loss"])) < 2e-2 * float(z[tag + ".loss"])

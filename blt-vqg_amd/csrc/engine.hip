@@ -70,6 +70,9 @@ struct bltvqg_engine {
     int B, H, F, Z, E, L, NH, V, Sa, Sp, T;
     int Ma, Mp, Mt, Mtot, Epad, ldV, dh;
     int imgHp = 0, imgWp = 0;   // zero-bordered NHWC4 input image of the 7x7/2 stem
+    bool regions = false;       // BASELINE configs[4]: the image input is [B, num_regions, region_dim] precomputed features
+    int FD = 512;               // width of the pooled feature the trainable head projects (512 = ResNet-18, region_dim in region mode)
+    std::string fcw, fcb;       // the head's projection: encoder_cnn.cnn.fc.* (encoder_cnn.py:20) or encoder_cnn.region_proj.*
     std::vector<PInfo> tp, fp;
     std::map<std::string, int> ti, fi;
     int64_t tsize = 0, late_off = 0, fsize = 0, ws_bytes = 0;
@@ -228,8 +231,8 @@ struct bltvqg_engine {
         add_t("embedding.1.weight", H, E, 0);
         add_t("embedding.1.bias", H, 0, 0);
         add_t("embedding.0.weight", V, E, 0);
-        add_t("encoder_cnn.cnn.fc.weight", H, 512, 0);
-        add_t("encoder_cnn.cnn.fc.bias", H, 0, 0);
+        add_t(fcw, H, FD, 0);
+        add_t(fcb, H, 0, 0);
         add_t("encoder_cnn.bn.weight", H, 0, 0);
         add_t("encoder_cnn.bn.bias", H, 0, 0);
         bucket_off[1] = bucket_len[0]; bucket_len[1] = tsize - bucket_len[0]; bucket_late[1] = 0;
@@ -254,7 +257,7 @@ struct bltvqg_engine {
         // ---- transposed-shadow table: every weight that appears as the B operand of an input-gradient GEMM ----
         auto ends_with = [](const std::string& a, const char* suf) { const size_t n = strlen(suf); return a.size() >= n && a.compare(a.size() - n, n, suf) == 0; };
         for (const PInfo& p : tp) {
-            if (p.ndim != 2 || p.name == "embedding.0.weight" || p.name == "encoder_cnn.cnn.fc.weight") continue;
+            if (p.ndim != 2 || p.name == "embedding.0.weight" || p.name == fcw) continue;
             int rows = p.dims[0];
             const bool encdec = p.name.find("multi_head_attention_enc_dec.") != std::string::npos;
             if (ends_with(p.name, "value_linear.weight")) continue;                       // part of a fused group
@@ -276,6 +279,11 @@ struct bltvqg_engine {
             add_f(n + ".running_var", C, 0, 0, 0, 1);
         };
         const std::string R = "encoder_cnn.cnn.";
+        if (regions) {      // BASELINE configs[4]: precomputed region features, no backbone
+            add_f("encoder_cnn.bn.running_mean", H, 0, 0, 0, 1);
+            add_f("encoder_cnn.bn.running_var", H, 0, 0, 0, 1);
+            return;
+        }
         int hi = c.image_h, wi = c.image_w;
         auto add_conv = [&](const std::string& wn, const std::string& bn, int cin, int cout, int k, int s, int p, int h, int w) {
             add_f(wn, cout, cin, k, k, 4);
@@ -332,7 +340,7 @@ struct bltvqg_engine {
         stats = AF(8);
         eps_dev = AF((int64_t)B * Z);
         // CNN
-        img = AT((int64_t)B * imgHp * imgWp * 4);
+        img = regions ? nullptr : AT((int64_t)B * imgHp * imgWp * 4);
         int64_t max_stat = 0;
         for (auto& cs : convs) {
             cs.wpacked = AT((int64_t)cs.Cout * cs.K * (cs.Cin < 8 ? 8 : cs.K) * cs.CinPad);
@@ -351,12 +359,12 @@ struct bltvqg_engine {
         }
         stat_sum = AF(max_stat); stat_sq = AF(max_stat);
         stat_tmp = (double*)A((int64_t)blt_bn_scratch_doubles(512) * 8);
-        {
+        if (!regions) {
             const int ph = (convs[0].Ho + 2 - 3) / 2 + 1, pw = (convs[0].Wo + 2 - 3) / 2 + 1;
             char* base_ = (char*)AT((BLT_PP_GUARD_FRONT + blt_pp_pixels(B, ph, pw) + BLT_PP_GUARD_TAIL) * 64);
             pool0 = base_ + (size_t)BLT_PP_GUARD_FRONT * 64 * es;
         }
-        pooled = AF((int64_t)B * 512);
+        pooled = AF((int64_t)B * FD);
         featpre = AF((int64_t)B * H); feats32 = AF((int64_t)B * H); dfeats32 = AF((int64_t)B * H); dfeatpre32 = AF((int64_t)B * H);
         feats = AT((int64_t)B * H);
         bn1_mean = AF(H); bn1_rstd = AF(H);
@@ -418,6 +426,10 @@ struct bltvqg_engine {
             imgWp = c.image_w + 6 > 2 * (wo - 1) + 8 ? c.image_w + 6 : 2 * (wo - 1) + 8;
             imgWp = (imgWp + 1) / 2 * 2;
         }
+        regions = c.num_regions > 0;
+        FD = regions ? c.region_dim : 512;
+        fcw = regions ? "encoder_cnn.region_proj.weight" : "encoder_cnn.cnn.fc.weight";
+        fcb = regions ? "encoder_cnn.region_proj.bias" : "encoder_cnn.cnn.fc.bias";
         build_params();
         enc.prefix = "answer_encoder.encoder"; enc.id = 0; enc.S = Sa; enc.M = Ma;
         renc.prefix = "answer_encoder.r_encoder"; renc.id = 1; renc.scr = 1; renc.S = Sp; renc.M = Mp;
@@ -726,7 +738,15 @@ struct bltvqg_engine {
                                cs.Ho, cs.Wo, cs.Cout, relu, s);
     }
 
+    // Image feature.  Image mode: EncoderCNN.forward (encoder_cnn.py:30-35).  Region mode (BASELINE configs[4], SURVEY A2': no
+    // reference symbol): mean_r(Linear(D->H)(x_r)) -> the same BatchNorm1d; the mean commutes with the Linear, so the regions are
+    // pooled first and the projection runs on [B, D] (36x fewer flops, same function).
     int cnn_fwd(const float* images, hipStream_t s) {
+        if (regions) {
+            RC(sync_opt(s));
+            RC(blt_avgpool(BLT_F32, images, pooled, B, c.num_regions, FD, 1, s));
+            return cnn_head_fwd(s);
+        }
         if (frozen_dirty) {
             for (auto& cs : convs)
                 RC(blt_conv_pack_w(dt, FZ(cs.wname), cs.wpacked, cs.Cout, cs.Cin, cs.K, cs.K, cs.CinPad, cs.Cin < 8 ? 8 : cs.K, s));
@@ -765,10 +785,14 @@ struct bltvqg_engine {
         // across the batch, so bf16 rounding of these tiny [B,512]/[B,H] tensors would be amplified into the image feature.
         RC(sync_opt(s));      // the head (fc + BatchNorm1d) is trainable: behind a pending asynchronous optimiser update
         RC(blt_avgpool_pp(dt, x, pooled, B, convs.back().Ho, convs.back().Wo, 512, 1, s));
+        return cnn_head_fwd(s);
+    }
+
+    int cnn_head_fwd(hipStream_t s) {
         {
-            const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
-            GemmArgs g = mk(pooled, 512, 0, train + pw.off, 512, 0, featpre, H, B, H, 512);
-            g.bias = P("encoder_cnn.cnn.fc.bias");
+            const PInfo& pw = tpi(fcw);
+            GemmArgs g = mk(pooled, FD, 0, train + pw.off, FD, 0, featpre, H, B, H, FD);
+            g.bias = P(fcb);
             RC(blt_gemm(BLT_F32, g, s));
         }
         if (bn_train) {
@@ -1069,9 +1093,9 @@ struct bltvqg_engine {
         RC(blt_cast_rows(dt, d_feats, H, BLT_F32, dfeats32, H, B, H, s));
         RC(blt_bn1d_bwd(BLT_F32, dfeats32, featpre, P("encoder_cnn.bn.weight"), bn1_mean, bn1_rstd, dfeatpre32, G("encoder_cnn.bn.weight"),
                         G("encoder_cnn.bn.bias"), B, H, s));
-        const PInfo& pw = tpi("encoder_cnn.cnn.fc.weight");
-        GemmArgs g = mk(dfeatpre32, H, 1, pooled, 512, 1, grad + pw.off, 512, H, 512, B);
-        g.accumulate = 1; g.a_rowsum = G("encoder_cnn.cnn.fc.bias");
+        const PInfo& pw = tpi(fcw);
+        GemmArgs g = mk(dfeatpre32, H, 1, pooled, FD, 1, grad + pw.off, FD, H, FD, B);
+        g.accumulate = 1; g.a_rowsum = G(fcb);
         return blt_gemm(BLT_F32, g, s);
     }
 
@@ -1278,9 +1302,10 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
     if (c.batch <= 0 || c.hidden_dim <= 0 || c.hidden_dim % 8 != 0 || c.num_heads <= 0 || c.hidden_dim % c.num_heads != 0 ||
         c.pwffn_dim % 8 != 0 || c.latent_dim % 8 != 0 || c.emb_dim <= 0 || c.num_layers <= 0 || c.vocab_size < 6 ||
         c.len_context <= 0 || c.len_context > 64 || c.len_posterior <= 0 || c.len_posterior > 64 || c.len_target < 2 || c.len_target > 64 ||
-        c.image_h < 32 || c.image_w < 32 || (c.dtype != BLT_F32 && c.dtype != BLT_BF16) || c.hidden_dim > 2048 ||
+        (c.num_regions <= 0 && (c.image_h < 32 || c.image_w < 32)) || c.num_regions < 0 ||
+        (c.num_regions > 0 && (c.region_dim < 8 || c.region_dim % 8 != 0)) || (c.dtype != BLT_F32 && c.dtype != BLT_BF16) || c.hidden_dim > 2048 ||
         c.attention_dropout < 0.f || c.attention_dropout >= 1.f || c.relu_dropout < 0.f || c.relu_dropout >= 1.f) {
-        blt_set_error("engine_create: unsupported configuration (need H,F,Z %% 8 == 0, H %% heads == 0, H <= 2048, sequence lengths <= 64, images >= 32x32)");
+        blt_set_error("engine_create: unsupported configuration (need H,F,Z %% 8 == 0, H %% heads == 0, H <= 2048, sequence lengths <= 64, images >= 32x32 or region_dim %% 8 == 0)");
         return nullptr;
     }
     if (c.emb_dim % 4 != 0) { blt_set_error("engine_create: emb_dim must be a multiple of 4"); return nullptr; }

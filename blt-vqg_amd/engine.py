@@ -17,12 +17,13 @@ F32, BF16 = _lib.F32, _lib.BF16
 
 def make_config(batch, hidden_dim, pwffn_dim, latent_dim, emb_dim, num_layers, num_heads, vocab_size, len_context=5,
                 len_posterior=21, len_target=20, image_hw=(224, 224), dtype=BF16, attention_dropout=0.1, relu_dropout=0.1,
-                kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1):
+                kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1, num_regions=0, region_dim=0):
+    """num_regions > 0: bottom-up feature mode (BASELINE configs[4]) — `images` is [B, num_regions, region_dim] fp32."""
     return Config(batch=batch, hidden_dim=hidden_dim, pwffn_dim=pwffn_dim, latent_dim=latent_dim, emb_dim=emb_dim,
                   num_layers=num_layers, num_heads=num_heads, vocab_size=vocab_size, len_context=len_context,
                   len_posterior=len_posterior, len_target=len_target, image_h=image_hw[0], image_w=image_hw[1], dtype=dtype,
                   attention_dropout=attention_dropout, relu_dropout=relu_dropout, kl_ceiling=kl_ceiling,
-                  aux_ceiling=aux_ceiling, image_recon_lambda=image_recon_lambda)
+                  aux_ceiling=aux_ceiling, image_recon_lambda=image_recon_lambda, num_regions=num_regions, region_dim=region_dim)
 
 
 class ParamInfo(object):
@@ -126,7 +127,8 @@ class StepEngine(object):
     def forward(self, images, context, posterior, target, eps=None, phase2=False, seed=0):
         c = self.cfg
         assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
-        assert tuple(images.shape) == (c.batch, 3, c.image_h, c.image_w), images.shape
+        expect = (c.batch, c.num_regions, c.region_dim) if c.num_regions > 0 else (c.batch, 3, c.image_h, c.image_w)
+        assert tuple(images.shape) == expect, (tuple(images.shape), expect)
         for t, n in ((context, c.len_context), (posterior, c.len_posterior), (target, c.len_target)):
             assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and tuple(t.shape) == (c.batch, n), (t.shape, n)
         if eps is not None:

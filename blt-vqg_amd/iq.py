@@ -83,7 +83,9 @@ class _IQFunction(torch.autograd.Function):
 class IQ(nn.Module):
     """Information-maximising VQG model (reference models/iq.py:22).  `args` is the reference's namespace: emb_dim, hidden_dim,
     latent_dim, pwffn_dim, num_layers, num_heads, device, emb_file, root_dir (+ optional: precision in {"bf16","fp32"},
-    attention_dropout, relu_dropout, resnet_weights = path of a torchvision resnet18 state dict)."""
+    attention_dropout, relu_dropout, resnet_weights = path of a torchvision resnet18 state dict; num_regions + region_dim > 0 =
+    bottom-up feature mode, BASELINE configs[4]: `images` is then a [B, num_regions, region_dim] tensor of precomputed region
+    features and `encoder_cnn` holds `region_proj` + `bn` instead of the ResNet — the reference has no such mode, SURVEY A2')."""
 
     def __init__(self, latent_transformer, vocab, args, num_att_layers=2):
         super().__init__()
@@ -118,7 +120,8 @@ class IQ(nn.Module):
         cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size, Sa, Sp, T,
                           (h, w), self._dtype, float(getattr(a, "attention_dropout", 0.1)), float(getattr(a, "relu_dropout", 0.1)),
                           float(getattr(a, "kl_ceiling", 0.5)), float(getattr(a, "aux_ceiling", 1.0)),
-                          float(getattr(a, "image_recon_lambda", 0.1)))
+                          float(getattr(a, "image_recon_lambda", 0.1)), int(getattr(a, "num_regions", 0) or 0),
+                          int(getattr(a, "region_dim", 0) or 0))
         e = StepEngine(cfg, device if allocate else "cpu")
         return e
 
@@ -200,7 +203,8 @@ class IQ(nn.Module):
     def _engine_for(self, images, answers, response, target):
         if not images.is_cuda:
             raise RuntimeError("IQ.forward runs on MI355X only (libbltvqg_hip.so); there is no CPU fallback. Move the batch to the GPU.")
-        key = (images.shape[0], answers.shape[1], response.shape[1], target.shape[1], images.shape[2], images.shape[3], images.device.index)
+        h, w = (images.shape[2], images.shape[3]) if images.dim() == 4 else (0, 0)       # region mode: [B, regions, dim]
+        key = (images.shape[0], answers.shape[1], response.shape[1], target.shape[1], h, w, images.device.index)
         eng = self._engines.get(key)
         if eng is None:
             eng = self._make_engine(*key[:6], device=images.device)
@@ -244,12 +248,14 @@ class IQ(nn.Module):
             raise RuntimeError("IQ.decode_greedy runs on MI355X only (libbltvqg_hip.so); there is no CPU fallback.")
         T = max_decode_length + 1
         B = images.shape[0]
-        key = ("decode", B, answers.shape[1], T, images.shape[2], images.shape[3], images.device.index)
+        h, w = (images.shape[2], images.shape[3]) if images.dim() == 4 else (0, 0)
+        key = ("decode", B, answers.shape[1], T, h, w, images.device.index)
         eng = self._engines.get(key)
         if eng is None:
             a = self.args
             cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size,
-                              answers.shape[1], 21, T, (images.shape[2], images.shape[3]), self._dtype, 0.0, 0.0)
+                              answers.shape[1], 21, T, (h, w), self._dtype, 0.0, 0.0, num_regions=int(getattr(a, "num_regions", 0) or 0),
+                              region_dim=int(getattr(a, "region_dim", 0) or 0))
             eng = StepEngine(cfg, images.device)
             if self._primary is None:
                 eng.allocate()

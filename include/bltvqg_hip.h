@@ -213,6 +213,11 @@ typedef struct bltvqg_config {
     int32_t dtype;          /* BLTVQG_F32 or BLTVQG_BF16 */
     float attention_dropout, relu_dropout;   /* 0.1 / 0.1 in the reference (transformer_layers.py:97,164) */
     float kl_ceiling, aux_ceiling, image_recon_lambda;
+    /* Bottom-up feature mode (BASELINE.json configs[4]; SURVEY A2': the reference has no implementation): num_regions > 0 makes the
+     * `images` argument of forward / decode_greedy a fp32 [B, num_regions, region_dim] tensor of precomputed region features and
+     * replaces the ResNet by mean_r(Linear(region_dim -> H)(x_r)) -> the same BatchNorm1d (parameters encoder_cnn.region_proj.{weight,
+     * bias}, encoder_cnn.bn.*); image_h / image_w are ignored.  0 = image mode.  region_dim % 8 == 0. */
+    int32_t num_regions, region_dim;
 } bltvqg_config;
 
 typedef struct bltvqg_engine bltvqg_engine;

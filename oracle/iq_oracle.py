@@ -63,10 +63,14 @@ def iq_spec(cfg):
     spec["embedding.0.weight"] = (V, E)
     spec["embedding.1.weight"] = (H, E)
     spec["embedding.1.bias"] = (H,)
-    for k, s in resnet18_spec().items():
-        spec["encoder_cnn.cnn." + k] = s
-    spec["encoder_cnn.cnn.fc.weight"] = (H, 512)
-    spec["encoder_cnn.cnn.fc.bias"] = (H,)
+    if getattr(cfg, "num_regions", 0) > 0:       # BASELINE configs[4] / SURVEY A2': precomputed region features, no backbone
+        spec["encoder_cnn.region_proj.weight"] = (H, cfg.region_dim)
+        spec["encoder_cnn.region_proj.bias"] = (H,)
+    else:
+        for k, s in resnet18_spec().items():
+            spec["encoder_cnn.cnn." + k] = s
+        spec["encoder_cnn.cnn.fc.weight"] = (H, 512)
+        spec["encoder_cnn.cnn.fc.bias"] = (H,)
     for k, s in (("weight", (H,)), ("bias", (H,)), ("running_mean", (H,)), ("running_var", (H,)), ("num_batches_tracked", ())):
         spec["encoder_cnn.bn." + k] = s
     for net, din in (("mean_logvar_prior", H), ("mean_logvar_posterior", 2 * H)):
@@ -271,8 +275,14 @@ def resnet18_features(P, pre, x, train=True, buffers_out=None):
 
 def encoder_cnn(P, images, train=True, buffers_out=None):
     """EncoderCNN.forward encoder_cnn.py:30-35: resnet -> fc(512->H) -> BatchNorm1d(momentum 0.01)."""
-    pooled = resnet18_features(P, "encoder_cnn.cnn.", images, train, buffers_out)
-    f = F.linear(pooled, P["encoder_cnn.cnn.fc.weight"], P["encoder_cnn.cnn.fc.bias"])
+    if "encoder_cnn.region_proj.weight" in P:
+        # Bottom-up path (BASELINE configs[4]).  NO reference symbol exists (SURVEY A2'): the build's definition, as the survey proposes,
+        # is mean over the regions of Linear(D -> H)(x_r), then the same BatchNorm1d.  images: [B, regions, D].  Parity for this path is
+        # against this restatement only ("parity unpinned").
+        f = F.linear(images, P["encoder_cnn.region_proj.weight"], P["encoder_cnn.region_proj.bias"]).mean(dim=1)
+    else:
+        pooled = resnet18_features(P, "encoder_cnn.cnn.", images, train, buffers_out)
+        f = F.linear(pooled, P["encoder_cnn.cnn.fc.weight"], P["encoder_cnn.cnn.fc.bias"])
     rm, rv = P["encoder_cnn.bn.running_mean"].clone(), P["encoder_cnn.bn.running_var"].clone()
     y = F.batch_norm(f, rm, rv, P["encoder_cnn.bn.weight"], P["encoder_cnn.bn.bias"], train, 0.01, 1e-5)
     if train and buffers_out is not None:

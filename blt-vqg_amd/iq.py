@@ -56,7 +56,7 @@ class _IQFunction(torch.autograd.Function):
         model._step_seed += 1
         eng.forward(images.contiguous().float(), answers.contiguous(), response.contiguous(), target.contiguous(),
                     None if eps is None else eps.contiguous().float(), phase2, model._base_seed + model._step_seed)
-        ctx.eng, ctx.phase2, ctx.names = eng, phase2, model._train_names
+        ctx.eng, ctx.phase2, ctx.names, ctx.was_training = eng, phase2, model._train_names, bool(model.training)
         output = eng.read(0)
         feats, recon = eng.read(2), eng.read(3)
         if phase2:
@@ -70,6 +70,9 @@ class _IQFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out, d_zl, d_kld, d_feats, d_recon):
         eng = ctx.eng
+        if not ctx.was_training:
+            raise RuntimeError("backward through a model.eval() forward is not implemented (BatchNorm backward is the train-mode one); "
+                               "call model.train() for training steps")
         f = lambda t: None if t is None else t.contiguous().float()   # noqa: E731
         eng.backward_external(f(d_out), f(d_zl) if ctx.phase2 else None, float(d_kld) if (ctx.phase2 and d_kld is not None) else 0.0,
                               f(d_feats), f(d_recon))
@@ -115,10 +118,13 @@ class IQ(nn.Module):
             self._load_embeddings(args)
 
     # ---- construction helpers -----------------------------------------------------------------------------------
-    def _make_engine(self, B, Sa, Sp, T, h, w, allocate=True, device="cuda"):
+    def _make_engine(self, B, Sa, Sp, T, h, w, allocate=True, device="cuda", training=True):
         a = self.args
+        # module.eval() (Lightning's validation loop): nn.Dropout is the identity
+        p_attn = float(getattr(a, "attention_dropout", 0.1)) if training else 0.0
+        p_relu = float(getattr(a, "relu_dropout", 0.1)) if training else 0.0
         cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size, Sa, Sp, T,
-                          (h, w), self._dtype, float(getattr(a, "attention_dropout", 0.1)), float(getattr(a, "relu_dropout", 0.1)),
+                          (h, w), self._dtype, p_attn, p_relu,
                           float(getattr(a, "kl_ceiling", 0.5)), float(getattr(a, "aux_ceiling", 1.0)),
                           float(getattr(a, "image_recon_lambda", 0.1)), int(getattr(a, "num_regions", 0) or 0),
                           int(getattr(a, "region_dim", 0) or 0))
@@ -204,10 +210,11 @@ class IQ(nn.Module):
         if not images.is_cuda:
             raise RuntimeError("IQ.forward runs on MI355X only (libbltvqg_hip.so); there is no CPU fallback. Move the batch to the GPU.")
         h, w = (images.shape[2], images.shape[3]) if images.dim() == 4 else (0, 0)       # region mode: [B, regions, dim]
-        key = (images.shape[0], answers.shape[1], response.shape[1], target.shape[1], h, w, images.device.index)
+        # train / eval engines differ in dropout (config) and BatchNorm mode; they share the parameter buffers
+        key = (images.shape[0], answers.shape[1], response.shape[1], target.shape[1], h, w, images.device.index, bool(self.training))
         eng = self._engines.get(key)
         if eng is None:
-            eng = self._make_engine(*key[:6], device=images.device)
+            eng = self._make_engine(*key[:6], device=images.device, training=self.training)
             if self._primary is None:
                 eng.allocate()
                 self._primary = eng
@@ -215,6 +222,7 @@ class IQ(nn.Module):
             else:
                 eng.allocate(share_from=self._primary)
             self._engines[key] = eng
+            eng.set_bn_train(self.training)      # eval: BatchNorm2d / BatchNorm1d use their running statistics and do not update them
         if not self._aliased():
             self._adopt(self._primary)
         return eng

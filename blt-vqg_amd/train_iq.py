@@ -45,6 +45,7 @@ class TrainIQ(_Base):
         self.image_recon_criterion = nn.MSELoss()
         self._optimizer = None
         self._dp = None
+        self.val_metrics = {k: [] for k in ("loss", "img", "ppl", "kld", "aux", "elbo", "rec")}      # train_iq.py:45-51
 
     # ---- reference surface ------------------------------------------------------------------------------------------
     def _device(self):
@@ -107,6 +108,21 @@ class TrainIQ(_Base):
         self.custom_optimizer(self.iter)
         self.iter += 1
         return loss
+
+    def validation_step(self, batch, batch_idx=0):
+        """reference train_iq.py:133-157 (Lightning runs it under model.eval() and torch.no_grad(): no dropout, BatchNorm from the
+        running statistics, nothing updated)."""
+        with torch.no_grad():
+            output, z_logit, kld_loss, image_recon = self(batch)
+            target = batch["questions"].to(output.device)
+            loss, loss_rec, loss_img, ppl, kld, aux, elbo = self.calculate_losses(output, image_recon, kld_loss, z_logit, target)
+        for k, v in (("loss", loss.item()), ("img", self.args.image_recon_lambda * loss_img), ("ppl", ppl), ("kld", kld), ("aux", aux),
+                     ("elbo", elbo), ("rec", loss_rec)):
+            self.val_metrics[k].append(v)
+        for k, v in (("val_loss", loss.item()), ("val_loss_rec", loss_rec), ("val_img_loss", loss_img), ("val_ppl", ppl),
+                     ("val_kld_loss", kld), ("val_aux", aux), ("val_elbo", elbo)):
+            self.log(k, v)
+        return batch
 
     def custom_optimizer(self, step, warmup_steps=4000):
         """Noam schedule written into the optimizer (reference train_iq.py:252-257)."""

@@ -211,3 +211,44 @@ def test_checkpoint_roundtrip_and_lightning_layout(tmp_path):
     assert q.iter == 7 and q.latent_transformer is True
     w = q.model.state_dict()["decoder.output.weight"].float().cpu()
     assert torch.equal(w, raw["state_dict"]["model.decoder.output.weight"])
+
+
+@pytest.mark.parametrize("phase2", [False, True])
+def test_eval_mode_forward_and_validation_step(phase2):
+    """model.eval() (what Lightning's validation loop does, train_iq.py:133-157): dropout off and BatchNorm2d/1d from the running
+    statistics, nothing updated — against the oracle's eval-mode forward (the mode the greedy-decode fixtures pin)."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    from oracle import iq_oracle as O
+    z, cfg, state, batch = load_golden("tiny")
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg, attention_dropout=0.1, relu_dropout=0.1))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")
+    if phase2:
+        t.latent_transformer = True
+        t.model.switch_GVT_train_mode(True)
+    t.eval()
+    b = {k: v.cuda() for k, v in batch.items()}
+    before = {k: v.detach().clone() for k, v in t.model.state_dict().items()}
+    P = O.clone_params(state, requires_grad=False)
+    with torch.no_grad():
+        out, z_logit, kld, (feats, recon), _ = O.iq_forward(P, cfg, batch["images"], batch["answers"], batch["posteriors"], batch["questions"],
+                                                           phase2, batch["eps"], None, 0.0, False, None)
+        ref_loss, ref_stats = O.calculate_losses(out, (feats, recon), kld, z_logit, batch["questions"], phase2, 0, O.default_hp())
+    output, zl, k, image_recon = t(b)
+    assert rel_err(output.cpu(), out) < 2e-4
+    assert rel_err(image_recon[0].cpu(), feats) < 2e-4
+    assert np.array_equal(output.argmax(-1).cpu().numpy(), out.argmax(-1).numpy())
+    t.validation_step(b, 0)
+    t.validation_step(b, 1)
+    assert len(t.val_metrics["loss"]) == 2 and t.val_metrics["loss"][0] == t.val_metrics["loss"][1]      # no dropout noise
+    assert abs(t.val_metrics["rec"][0] - ref_stats["rec"]) < 1e-4
+    assert abs(t.val_metrics["loss"][0] - float(ref_loss)) < 1e-3 * max(1.0, abs(float(ref_loss)) * 0.05)      # phase 2: the KL term of this synthetic state is ~1e12
+    assert "val_loss" in t.logged and "val_elbo" in t.logged
+    after = t.model.state_dict()
+    for kk, v in before.items():
+        assert torch.equal(after[kk], v), kk                       # running statistics, num_batches_tracked, parameters untouched
+    with pytest.raises(RuntimeError):                              # training through an eval-mode forward is refused, not silently wrong
+        t(b)[0].sum().backward()
+    t.train()
+    t(b)[0].sum().backward()                                       # and train mode still works on the same model
+    assert t.model.get_parameter("decoder.output.weight").grad is not None

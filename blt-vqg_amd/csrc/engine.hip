@@ -70,6 +70,9 @@ struct bltvqg_engine {
     int B, H, F, Z, E, L, NH, V, Sa, Sp, T;
     int Ma, Mp, Mt, Mtot, Epad, ldV, dh;
     int imgHp = 0, imgWp = 0;   // zero-bordered NHWC4 input image of the 7x7/2 stem
+    float* ln_pool = nullptr;
+    size_t ln_pool_floats = 0, ln_pool_used = 0;
+    std::vector<LnRed> pending_ln;
     bool regions = false;       // BASELINE configs[4]: the image input is [B, num_regions, region_dim] precomputed features
     int FD = 512;               // width of the pooled feature the trainable head projects (512 = ResNet-18, region_dim in region mode)
     std::string fcw, fcb;       // the head's projection: encoder_cnn.cnn.fc.* (encoder_cnn.py:20) or encoder_cnn.region_proj.*
@@ -411,6 +414,10 @@ struct bltvqg_engine {
         g_rin = AT((int64_t)B * H); g_zc = AT((int64_t)B * H);
         acc_big2 = AF((int64_t)B * H);
         for (int n = 0; n < 2; ++n) for (int k = 0; k < 2; ++k) g_net[n][k] = AT((int64_t)B * 2 * Z);
+        // per-workgroup dgamma / dbeta partial sums of every LayerNorm backward of a step (ln_bwd)
+        ln_pool_floats = ((size_t)(2 * L + 1) * (blt_layernorm_bwd_grid(Ma, H) + blt_layernorm_bwd_grid(Mp, H)) +
+                          (size_t)(3 * L + 1) * blt_layernorm_bwd_grid(Mt, H)) * 2 * H;
+        ln_pool = AF((int64_t)ln_pool_floats);
         return off;
     }
 
@@ -507,11 +514,34 @@ struct bltvqg_engine {
     }
     // issue the collected weight-gradient GEMMs on `to`, ordered after everything enqueued on `from` so far
     int flush_wgrads(hipStream_t from, hipStream_t to, hipEvent_t ev) {
-        if (pending_wgrads.empty()) return BLT_OK;
+        if (pending_wgrads.empty() && pending_ln.empty()) return BLT_OK;
         int rc = fork(from, to, ev);
         for (size_t i = 0; i < pending_wgrads.size() && !rc; ++i) rc = blt_gemm(dt, pending_wgrads[i], to);
         pending_wgrads.clear();
+        for (size_t i = 0; i < pending_ln.size() && !rc; i += BLT_LN_RED_MAX) {
+            LnRedArgs a;
+            a.n = (int)((pending_ln.size() - i < BLT_LN_RED_MAX) ? pending_ln.size() - i : BLT_LN_RED_MAX);
+            for (int k = 0; k < a.n; ++k) a.e[k] = pending_ln[i + k];
+            rc = blt_ln_param_reduce(a, to);
+        }
+        pending_ln.clear();
         return rc;
+    }
+
+    // LayerNorm backward; with deferred weight gradients its dgamma / dbeta go the same way: the launch on the dependent chain only
+    // stores per-workgroup partial sums, one reduce launch per flush adds them on the side stream
+    int ln_bwd(const void* dy, const void* x, const std::string& ln, const float* mean, const float* rstd, const void* dres, void* dx, long M,
+               hipStream_t s, const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr) {
+        float* part = nullptr;
+        const int grid = blt_layernorm_bwd_grid(M, H);
+        if (defer_wgrads && blt_debug_get(7) != 4 && ln_pool && ln_pool_used + (size_t)grid * 2 * H <= ln_pool_floats) {
+            part = ln_pool + ln_pool_used;
+            ln_pool_used += (size_t)grid * 2 * H;
+            LnRed e; e.part = part; e.dgamma = G(ln + ".weight"); e.dbeta = G(ln + ".bias"); e.nblocks = grid; e.cols = H;
+            pending_ln.push_back(e);
+        }
+        return blt_layernorm_bwd(dt, dy, x, P(ln + ".weight"), mean, rstd, dres, dx, G(ln + ".weight"), G(ln + ".bias"), M, H, s, maskY, mask_scale,
+                                 out2, part);
     }
 
     // dX = dY W with a vocabulary-sized contraction (K = V): few output tiles and a long K loop, so the K range is split over
@@ -1020,7 +1050,7 @@ struct bltvqg_engine {
         RC(blt_gemm(dt, g, s));
         RC(wgrad_later(y.gF, F, xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), M, s));
         RC(blt_gemm(dt, dgrad(y.gF, F, fp_ + "layers.0.weight", gB, H, M), s));
-        return blt_layernorm_bwd(dt, gB, xres, P(ln + ".weight"), m, r, dx_in, dx_out, G(ln + ".weight"), G(ln + ".bias"), M, H, s);
+        return ln_bwd(gB, xres, ln, m, r, dx_in, dx_out, M, s);
     }
 
     // `dx` holds d(stack output before the final LayerNorm) on entry and d(stack input) on exit; the gradients in between live in the
@@ -1057,7 +1087,7 @@ struct bltvqg_engine {
                     RC(blt_gemm(dt, g, s));
                 }
                 const std::string ln2 = lp + "layer_norm_mha_enc";
-                RC(blt_layernorm_bwd(dt, gC, y.x1, P(ln2 + ".weight"), y.m2, y.r2, cur, y.dx2, G(ln2 + ".weight"), G(ln2 + ".bias"), M, H, s));
+                RC(ln_bwd(gC, y.x1, ln2, y.m2, y.r2, cur, y.dx2, M, s));
                 cur = y.dx2;
             } else {
                 RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, cur, y.dx1, M, st.scr, s));
@@ -1081,7 +1111,7 @@ struct bltvqg_engine {
             // ... and, for the layer below, the masked gradient that opens its FFN backward (ffn_bwd)
             const void* nmask = (l > 0) ? st.layers[l - 1].y2 : nullptr;
             void* ngY = (l > 0) ? st.layers[l - 1].gY : nullptr;
-            RC(blt_layernorm_bwd(dt, gB, x, P(ln1 + ".weight"), y.m1, y.r1, cur, out, G(ln1 + ".weight"), G(ln1 + ".bias"), M, H, s, nmask, relu_ks(), ngY));
+            RC(ln_bwd(gB, x, ln1, y.m1, y.r1, cur, out, M, s, nmask, relu_ks(), ngY));
             cur = out;
         }
         return BLT_OK;
@@ -1103,6 +1133,8 @@ struct bltvqg_engine {
     // d_feats holds the direct gradient of image_features, d_recon that of the reconstruction.
     int backward_core(float kld_g, hipStream_t s) {
         pending_wgrads.clear();
+        pending_ln.clear();
+        ln_pool_used = 0;
         defer_wgrads = false;
         // every weight gradient from here on is collected and issued on a side stream at the next flush point (their operands live
         // in buffers that nothing overwrites during this backward pass); only the input-gradient chain stays on `s`
@@ -1131,9 +1163,8 @@ struct bltvqg_engine {
         void* dxT = (char*)dX_all + (size_t)Ma * H * es;
         {
             const void* xL = dec.layers[L - 1].x2;
-            RC(blt_layernorm_bwd(dt, gA, xL, P("decoder.decoder.layer_norm.weight"), dec.mF, dec.rF, nullptr, dxT,
-                                 G("decoder.decoder.layer_norm.weight"), G("decoder.decoder.layer_norm.bias"), Mt, H, s,
-                                 dec.layers[L - 1].y2, relu_ks(), dec.layers[L - 1].gY));
+            RC(ln_bwd(gA, xL, "decoder.decoder.layer_norm", dec.mF, dec.rF, nullptr, dxT, Mt, s, dec.layers[L - 1].y2, relu_ks(),
+                      dec.layers[L - 1].gY));
         }
         RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
         if (sbr != s && hipStreamWaitEvent(s, fj[12], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
@@ -1169,9 +1200,8 @@ struct bltvqg_engine {
             RC(blt_rows_add(dt, d_renc, (long)Sp * H, g_cat, 2 * H, nullptr, 0, B, H, 0, s0));
             void* dxP = (char*)dX_all + (size_t)(Ma + Mt) * H * es;
             const void* xL = renc.layers[L - 1].x2;
-            RC(blt_layernorm_bwd(dt, d_renc, xL, P("answer_encoder.r_encoder.layer_norm.weight"), renc.mF, renc.rF, nullptr, dxP,
-                                 G("answer_encoder.r_encoder.layer_norm.weight"), G("answer_encoder.r_encoder.layer_norm.bias"), Mp, H, s0,
-                                 renc.layers[L - 1].y2, relu_ks(), renc.layers[L - 1].gY));
+            RC(ln_bwd(d_renc, xL, "answer_encoder.r_encoder.layer_norm", renc.mF, renc.rF, nullptr, dxP, Mp, s0, renc.layers[L - 1].y2, relu_ks(),
+                      renc.layers[L - 1].gY));
             RC(stack_bwd(renc, dxP, nullptr, nullptr, s0));
             // the main stream will join s0 at THIS point (it needs the chain's result for the embedding backward); the posterior
             // encoder's weight gradients then run on s0 behind it, beside the context encoder's on side[1], and are joined at the very end
@@ -1182,9 +1212,8 @@ struct bltvqg_engine {
         // ---- context encoder (main stream) ----
         {
             const void* xL = enc.layers[L - 1].x2;
-            RC(blt_layernorm_bwd(dt, d_enc, xL, P("answer_encoder.encoder.layer_norm.weight"), enc.mF, enc.rF, nullptr, dX_all,
-                                 G("answer_encoder.encoder.layer_norm.weight"), G("answer_encoder.encoder.layer_norm.bias"), Ma, H, s,
-                                 enc.layers[L - 1].y2, relu_ks(), enc.layers[L - 1].gY));
+            RC(ln_bwd(d_enc, xL, "answer_encoder.encoder.layer_norm", enc.mF, enc.rF, nullptr, dX_all, Ma, s, enc.layers[L - 1].y2, relu_ks(),
+                      enc.layers[L - 1].gY));
         }
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
         RC(flush_wgrads(s, side[1], fj[8]));

@@ -100,9 +100,16 @@ int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
                       long rows, int cols, float eps, hipStream_t s);
 // dx = LNbwd(dy) (+ dres if non-null); dgamma/dbeta are ACCUMULATED (+=) with float atomics
 // optional second output out2 = (maskY != 0) ? dx * mask_scale : 0 (the ReLU/dropout backward that consumes dx, fused)
+// partials (optional, blt_layernorm_bwd_grid(rows, cols) * 2 * cols floats): the workgroups' dgamma / dbeta sums are stored there
+// instead of being added to dgamma / dbeta; blt_ln_param_reduce adds them later (one launch for many LayerNorms, off the chain)
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
-                      const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr);
+                      const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr, float* partials = nullptr);
+int blt_layernorm_bwd_grid(long rows, int cols);
+#define BLT_LN_RED_MAX 24
+struct LnRed { const float* part; float* dgamma; float* dbeta; int nblocks; int cols; };
+struct LnRedArgs { LnRed e[BLT_LN_RED_MAX]; int n; };
+int blt_ln_param_reduce(const LnRedArgs& a, hipStream_t s);
 
 // BatchNorm2d (train mode) on NHWC: finalize partial sums -> scale/shift (+ running stat update)
 int blt_bn_finalize(const float* psum, const float* psq, int nparts, int C, long count, const float* gamma,

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                            const float* __restrict__ rstd, const T* dres,
                                                            T* dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, long rows, int cols,
-                                                           const T* __restrict__ maskY, float mask_scale, T* __restrict__ out2) {
+                                                           const T* __restrict__ maskY, float mask_scale, T* __restrict__ out2,
+                                                           float* __restrict__ partials) {
     const int lane = threadIdx.x & 63;
     const int nch = cols >> 3;
     const int lpr = (nch <= 32) ? 32 : 64, rpw = 64 / lpr;
@@ -150,7 +151,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                 const int col = 64 * 8 * j + i;
                 if (col < cols) {
                     const float t = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-                    atomicAdd((pass == 0 ? dgamma : dbeta) + col, t);
+                    // partials: one row of dgamma and one of dbeta per workgroup, summed later by ln_param_reduce_kernel (off the
+                    // dependent chain) instead of gridDim.x same-address atomics per column at the tail of this launch
+                    if (partials != nullptr) partials[((size_t)blockIdx.x * 2 + pass) * cols + col] = t;
+                    else atomicAdd((pass == 0 ? dgamma : dbeta) + col, t);
                 }
             }
         }
@@ -508,20 +512,55 @@ int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
     return blt_check_launch("layernorm_fwd");
 }
 
+int blt_layernorm_bwd_grid(long rows, int cols) {
+    const int rpw = (cols <= 256) ? 2 : 1;
+    int grid = cdiv(rows, 4 * rpw * 2);
+    if (grid > 512) grid = 512;
+    return grid < 1 ? 1 : grid;
+}
+
+// dgamma[c] += sum_b part[(b*2+0)*cols + c], dbeta[c] += sum_b part[(b*2+1)*cols + c] for up to BLT_LN_RED_MAX LayerNorms per launch
+__global__ __launch_bounds__(256) void ln_param_reduce_kernel(const LnRedArgs a) {
+    const LnRed e = a.e[blockIdx.x];
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= 2 * e.cols) return;
+    const int pass = j / e.cols, col = j - pass * e.cols;
+    const float* p = e.part + (size_t)pass * e.cols + col;
+    const size_t stride = (size_t)2 * e.cols;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < e.nblocks; b += 4) {
+        s0 += p[(size_t)b * stride]; s1 += p[(size_t)(b + 1) * stride]; s2 += p[(size_t)(b + 2) * stride]; s3 += p[(size_t)(b + 3) * stride];
+    }
+    for (; b < e.nblocks; ++b) s0 += p[(size_t)b * stride];
+    float* dst = (pass == 0 ? e.dgamma : e.dbeta) + col;
+    *dst += (s0 + s1) + (s2 + s3);
+}
+
+int blt_ln_param_reduce(const LnRedArgs& a, hipStream_t s) {
+    BLT_REQUIRE(a.n > 0 && a.n <= BLT_LN_RED_MAX, "ln_param_reduce: bad count");
+    int maxc = 0;
+    for (int i = 0; i < a.n; ++i) {
+        BLT_REQUIRE(a.e[i].part && a.e[i].dgamma && a.e[i].dbeta && a.e[i].nblocks > 0 && a.e[i].cols > 0, "ln_param_reduce: bad entry");
+        if (a.e[i].cols > maxc) maxc = a.e[i].cols;
+    }
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3(a.n, cdiv(2 * maxc, 256)), dim3(256), 0, s, a);
+    return blt_check_launch("ln_param_reduce");
+}
+
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
-                      const void* maskY, float mask_scale, void* out2) {
+                      const void* maskY, float mask_scale, void* out2, float* partials) {
     BLT_REQUIRE((maskY == nullptr) == (out2 == nullptr), "layernorm_bwd: maskY and out2 go together");
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_bwd: bad dtype");
     BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_bwd: bad cols=%d", cols);
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
-    const int rpw = (cols <= 256) ? 2 : 1;      // rows a wave carries at once
-    int grid = cdiv(rows, 4 * rpw * 2);          // ~2 row-iterations per wave: latency-bound, yet few enough blocks for the dgamma/dbeta atomics
-    if (grid > 512) grid = 512;
+    // ~2 row-iterations per wave (rows <= 256 columns: two rows per wave): latency-bound, yet few enough blocks for the dgamma/dbeta atomics
+    int grid = blt_layernorm_bwd_grid(rows, cols);
     if (grid < 1) grid = 1;
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols, (const float*)maskY, mask_scale, (float*)out2),
-               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols, (const bf16*)maskY, mask_scale, (bf16*)out2));
+               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols, (const float*)maskY, mask_scale, (float*)out2, partials),
+               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols, (const bf16*)maskY, mask_scale, (bf16*)out2, partials));
     return blt_check_launch("layernorm_bwd");
 }
 

@@ -44,7 +44,7 @@ def region_features(B, R, D, seed):
     g = torch.Generator().manual_seed(int(seed) + 77)
     x = torch.relu(torch.randn(B, R, D, generator=g) + 0.3 * torch.randn(B, 1, D, generator=g))
     return (x * (0.5 + torch.rand(B, 1, 1, generator=g))).contiguous()
-PROFILE_EVERY = 5
+PROFILE_EVERY = 10
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 
 

@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="small", choices=sorted(CONFIGS))
+    ap.add_argument("--h2d", action="store_true",
+                    help="PCIe-inclusive variant (NOT the headline value): the batch lives in pinned host memory and is copied to the GPU "
+                         "every step on a copy stream, one step ahead (the reference's boundary hands over host tensors, train_iq.py:67-79)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--phase", type=int, default=2, choices=[1, 2], help="1 = pre-training (latent off), 2 = latent on")
@@ -157,10 +160,37 @@ def main():
     d = {k: v.to(dev) for k, v in batch.items() if k in ("images", "answers", "posteriors", "questions")}
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
 
+    keys = ("images", "answers", "posteriors", "questions")
+    if a.h2d:
+        host = {k: batch[k].contiguous().pin_memory() for k in keys}
+        bufs = [{k: torch.empty_like(d[k]) for k in keys} for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        ready = [torch.cuda.Event(), torch.cuda.Event()]       # buffer filled
+        free = [torch.cuda.Event(), torch.cuda.Event()]        # buffer consumed by its step
+
+        def upload(slot):
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(free[slot])
+                for k in keys:
+                    bufs[slot][k].copy_(host[k], non_blocking=True)
+                ready[slot].record(copy_stream)
+
+        for ev in free:
+            ev.record()
+        upload(0)
+
     def one_step(i):
         eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
-        step.run(d["images"], d["answers"], d["posteriors"], d["questions"], eps, phase2, seed=1000 + i,
+        cur = d
+        if a.h2d:
+            slot = i % 2
+            upload(slot ^ 1)                                   # next step's batch crosses PCIe underneath this step
+            torch.cuda.current_stream().wait_event(ready[slot])
+            cur = bufs[slot]
+        step.run(cur["images"], cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=1000 + i,
                  kl_weight=0.5, lr=1e-4, max_norm=5.0)
+        if a.h2d:
+            free[i % 2].record()
 
     print("[bench] rank %d: engine ready (workspace %.2f GB), warming up" % (rank, eng.workspace_bytes / 1e9), file=sys.stderr, flush=True)
     if a.autotune:
@@ -227,7 +257,8 @@ def main():
         out = {
             "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": a.dtype,
+            "data": "synthetic, pinned host batch copied over PCIe every step (one step ahead)" if a.h2d else "synthetic",
             "config": {"workload": "IQ train step (fwd+loss+bwd+clip+Adam), %s cfg: %d-layer d_model=%d, per-GPU batch %d, %s, "
                                    "T=20/S_a=5/S_p=21, V=%d, phase %d, dropout 0.1" % (
                                        a.config, cfg["num_layers"], cfg["hidden_dim"], B,

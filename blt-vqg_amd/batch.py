@@ -3,7 +3,8 @@
 The reference feeds the step from 8 host workers: `IQDataset.__getitem__` builds token rows per sample and pushes a stored float
 HWC image through ToTensor -> ToPILImage -> RandomResizedCrop(224, scale (1.0,1.2)) -> ToTensor -> Normalize; `collate_fn` sorts the
 samples by category and stacks them (`utils/data_loader.py:45-129,132-175`, `train_iq.py:264-272`).  At this engine's step rate
-that pipeline (602 KB of float pixels per sample) cannot keep up over PCIe, while 288 GB of HBM hold the whole image table once the
+that pipeline would have to process 29 GB/s of float pixels (602 KB per sample) on the host and ship them over PCIe (a finished pinned batch
+alone costs the step 9 %, `bench.py --h2d`), while 288 GB of HBM hold the whole image table once the
 deterministic ToTensor -> ToPILImage round trip has been applied (bytes, 150 KB per image).  So:
 
   * `IQStore`              the reference's HDF5 datasets as arrays (`utils/store_dataset.py:75-87`: questions, answers, answer_types,

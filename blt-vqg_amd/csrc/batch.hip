@@ -1,7 +1,7 @@
 // Batch producer kernels (reference utils/data_loader.py:45-129 and the transforms.Compose at train_iq.py:264-272).
 //
-// MI355X-first: at the train step's rate (tens of thousands of pairs/s) a host pipeline of float HWC images cannot feed the GPU
-// (602 KB per stored image is > PCIe bandwidth at 48 k pairs/s), and 288 GB of HBM hold the whole VQA image table once the
+// MI355X-first: at the train step's rate (tens of thousands of pairs/s) a host pipeline of float HWC images has to move 29 GB/s
+// (602 KB per stored image; a finished pinned batch over PCIe alone costs the step 9 %), and 288 GB of HBM hold the whole VQA image table once the
 // reference's ToTensor -> ToPILImage round trip has been applied to it (that round trip is deterministic per image and produces
 // bytes: 150 KB per image).  So the store lives in HBM as uint8 HWC, and one batch is an index gather + crop + Pillow-exact
 // antialiased bilinear resample + /255 + Normalize, written as the fp32 NCHW tensor IQ.forward takes.  Integer work throughout up

@@ -83,6 +83,9 @@ SIGNATURES = {
     "bltvqg_image_store_u8": (I, [P, P, L, P]),
     "bltvqg_batch_rows": (I, [P, P, P, P, I, L, P, I, I, I, P, P, P, P, P, P]),
     "bltvqg_batch_images": (I, [P, L, I, P, L, P, P, P, I, I, I, ctypes.POINTER(ctypes.c_float), P, P, P]),
+    "bltvqg_batch_images_packed": (I, [P, L, I, P, L, P, P, P, I, I, I, ctypes.POINTER(ctypes.c_float), I, P, I, I, I, I, P]),
+    "bltvqg_engine_image_input": (I, [P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                      ctypes.POINTER(ctypes.c_int)]),
     "bltvqg_engine_create": (P, [ctypes.POINTER(Config)]),
     "bltvqg_engine_destroy": (None, [P]),
     "bltvqg_engine_num_params": (I, [P, I]),

@@ -177,8 +177,11 @@ class DeviceBatchProducer(object):
                 return
             yield idx
 
-    def batch(self, indices, boxes=None, return_u8=False):
-        """One collated batch (reference dict keys and order) for the given sample indices; tensors live on the device."""
+    def batch(self, indices, boxes=None, return_u8=False, engine=None):
+        """One collated batch (reference dict keys and order) for the given sample indices; tensors live on the device.
+        engine: a bound StepEngine of matching batch / image size — the images are then written straight into its packed stem input
+        (no fp32 NCHW tensor, no img_pack launch; bit-identical) and `images` is None: call `engine.forward(None, ...)` /
+        `DataParallelStep.run(None, ...)` next."""
         idx = np.asarray(indices, np.int64)
         if idx.ndim != 1 or len(idx) == 0 or idx.min() < 0 or idx.max() >= self.n_rows:
             raise IndexError("DeviceBatchProducer.batch: indices out of range")
@@ -208,8 +211,13 @@ class DeviceBatchProducer(object):
         d_packed = self._h2d(packed)
         d_idx = d_packed[:2 * B].view(torch.int64)
         d_box = d_packed[2 * B:].view(B, 4)
+        if engine is not None:
+            c = engine.cfg
+            if (c.batch, c.image_h, c.image_w, c.num_regions) != (B, osz, osz, 0) or return_u8:
+                raise ValueError("DeviceBatchProducer.batch: engine shape %s does not match the batch (%d, %d, %d)" %
+                                 ((c.batch, c.image_h, c.image_w), B, osz, osz))
         out = {
-            "images": torch.empty((B, 3, osz, osz), dtype=torch.float32, device=dev),
+            "images": None if engine is not None else torch.empty((B, 3, osz, osz), dtype=torch.float32, device=dev),
             "image_ids": tuple(self.h_image_ids[idx].tolist()),
             "questions": torch.empty((B, self.q_len), dtype=torch.int64, device=dev),
             "posteriors": torch.empty((B, self.q_len + 1), dtype=torch.int64, device=dev),
@@ -222,6 +230,12 @@ class DeviceBatchProducer(object):
                                          int(self.cat_word_ids.numel()), self.n_rows, ptr(d_idx), B, self.q_len, self.a_len,
                                          ptr(out["questions"]), ptr(out["posteriors"]), ptr(out["answers"]), ptr(out["answer_types"]),
                                          ptr(out["answer_types_for_input"]), stream_ptr()), "batch_rows")
+        if engine is not None:
+            p_img, hp, wp, edt = engine.image_input()
+            check(self.lib.bltvqg_batch_images_packed(ptr(self.table), self.n_images, self.S, ptr(self.image_indices), self.n_rows, ptr(d_idx),
+                                                      ptr(d_box), ptr(coeffs), KS, B, osz, self.mean_std, edt, p_img, hp, wp, 3, 3,
+                                                      stream_ptr()), "batch_images_packed")
+            return out
         u8 = torch.empty((B, osz, osz, 3), dtype=torch.uint8, device=dev) if return_u8 else None
         check(self.lib.bltvqg_batch_images(ptr(self.table), self.n_images, self.S, ptr(self.image_indices), self.n_rows, ptr(d_idx),
                                            ptr(d_box), ptr(coeffs), KS, B, osz, self.mean_std, ptr(out["images"]), ptr(u8),

@@ -262,5 +262,11 @@ int bltvqg_batch_images(const uint8_t* table, int64_t n_images, int S, const int
     return blt_batch_images(table, (long)n_images, S, image_indices, (long)n_rows, (const long*)index, boxes, coeffs, KS, B, osz, mean_std, out,
                             out_u8, (hipStream_t)stream);
 }
+int bltvqg_batch_images_packed(const uint8_t* table, int64_t n_images, int S, const int32_t* image_indices, int64_t n_rows,
+                               const int64_t* index, const int32_t* boxes, const int32_t* coeffs, int KS, int B, int osz, const float* mean_std,
+                               int dtype, void* out, int Hp, int Wp, int pad_top, int pad_left, void* stream) {
+    return blt_batch_images_packed(table, (long)n_images, S, image_indices, (long)n_rows, (const long*)index, boxes, coeffs, KS, B, osz, mean_std,
+                                   dtype, out, Hp, Wp, pad_top, pad_left, (hipStream_t)stream);
+}
 
 }  // extern "C"

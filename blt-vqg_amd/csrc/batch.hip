@@ -97,15 +97,9 @@ __device__ __forceinline__ int clip8(int v) {
 // One thread per output pixel (3 channels).  Identity crops (h == w == out: the only case the reference's scale=(1.0,1.2) leaves for
 // a stored 224x224 image) copy; everything else runs Pillow's two passes — horizontal with rounding to 8 bits, then vertical — with
 // the host-computed fixed-point weights, recomputing the <= KS horizontal results a pixel needs (the source rows sit in L2).
-__global__ void batch_images_kernel(BatchImgArgs a) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long per = (long)a.osz * a.osz;
-    if (i >= per * a.B) return;
-    const int b = (int)(i / per);
-    const int oy = (int)((i - (long)b * per) / a.osz);
-    const int ox = (int)(i - (long)b * per - (long)oy * a.osz);
+__device__ __forceinline__ void batch_sample_pixel(const BatchImgArgs& a, int b, int oy, int ox, int* px) {
     long r = a.index[b];
-    int px[3] = {0, 0, 0};
+    px[0] = px[1] = px[2] = 0;
     const int top = a.boxes[b * 4 + 0], left = a.boxes[b * 4 + 1], h = a.boxes[b * 4 + 2], w = a.boxes[b * 4 + 3];
     bool ok = r >= 0 && r < a.n_rows && top >= 0 && left >= 0 && h > 0 && w > 0 && top + h <= a.S && left + w <= a.S;
     long img = ok ? (long)a.image_indices[r] : 0;
@@ -137,6 +131,17 @@ __global__ void batch_images_kernel(BatchImgArgs a) {
             px[0] = clip8(acc[0]); px[1] = clip8(acc[1]); px[2] = clip8(acc[2]);
         }
     }
+}
+
+__global__ void batch_images_kernel(BatchImgArgs a) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)a.osz * a.osz;
+    if (i >= per * a.B) return;
+    const int b = (int)(i / per);
+    const int oy = (int)((i - (long)b * per) / a.osz);
+    const int ox = (int)(i - (long)b * per - (long)oy * a.osz);
+    int px[3];
+    batch_sample_pixel(a, b, oy, ox, px);
     float* o = a.out + ((long)b * 3 * a.osz + oy) * a.osz + ox;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -148,6 +153,55 @@ __global__ void batch_images_kernel(BatchImgArgs a) {
         uint8_t* u = a.out_u8 + i * 3;
         u[0] = (uint8_t)px[0]; u[1] = (uint8_t)px[1]; u[2] = (uint8_t)px[2];
     }
+}
+
+// Same transform written straight into the train-step engine's stem input (bltvqg_engine_image_input): zero-bordered NHWC4
+// [B, Hp, Wp, 4] in the engine's dtype, image at (pad_top, pad_left), channel 3 = 0 — what bltvqg_img_pack makes of the fp32 NCHW
+// tensor, without that tensor (77 MB written + read per batch of 128) and without the img_pack launch.  One thread per packed pixel.
+template <typename T>
+__global__ void batch_images_packed_kernel(BatchImgArgs a, T* __restrict__ out, int Hp, int Wp, int pt, int pl) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per = (long)Hp * Wp;
+    if (i >= per * a.B) return;
+    const int b = (int)(i / per);
+    const int y = (int)((i - (long)b * per) / Wp) - pt;
+    const int x = (int)((i - (long)b * per) % Wp) - pl;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)y < (unsigned)a.osz && (unsigned)x < (unsigned)a.osz) {
+        int px[3];
+        batch_sample_pixel(a, b, y, x, px);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)px[c], 255.0f), a.mean[c]), a.stdv[c]);
+    }
+    T* o = out + i * 4;
+    if constexpr (sizeof(T) == 2) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+        bf16x4 w;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = (__bf16)v[c];
+        *reinterpret_cast<bf16x4*>(o) = w;
+    } else {
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+int blt_batch_images_packed(const uint8_t* table, long n_images, int S, const int* image_indices, long n_rows, const long* index,
+                            const int* boxes, const int* coeffs, int KS, int B, int osz, const float* mean_std, int dtype, void* out, int Hp,
+                            int Wp, int pad_top, int pad_left, hipStream_t s) {
+    BLT_REQUIRE(table && image_indices && index && boxes && mean_std && out, "batch_images_packed: null pointer");
+    BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "batch_images_packed: bad dtype");
+    BLT_REQUIRE(n_images > 0 && n_rows > 0 && S > 0 && B > 0 && osz > 0 && KS >= 0 && KS <= 64, "batch_images_packed: bad sizes");
+    BLT_REQUIRE(pad_top >= 0 && pad_left >= 0 && Hp >= osz + pad_top && Wp >= osz + pad_left, "batch_images_packed: image does not fit the packed buffer");
+    BLT_REQUIRE(coeffs || KS == 0, "batch_images_packed: KS > 0 needs a coefficient table");
+    BLT_REQUIRE(((uintptr_t)out % 16) == 0, "batch_images_packed: output must be 16-byte aligned");
+    BatchImgArgs a;
+    a.table = table; a.image_indices = image_indices; a.index = index; a.boxes = boxes; a.coeffs = coeffs; a.out = nullptr; a.out_u8 = nullptr;
+    a.n_images = n_images; a.n_rows = n_rows; a.S = S; a.B = B; a.osz = osz; a.KS = KS;
+    for (int c = 0; c < 3; ++c) { a.mean[c] = mean_std[c]; a.stdv[c] = mean_std[3 + c]; }
+    const long n = (long)B * Hp * Wp;
+    if (dtype == BLT_BF16) hipLaunchKernelGGL(batch_images_packed_kernel<bf16>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, a, (bf16*)out, Hp, Wp, pad_top, pad_left);
+    else hipLaunchKernelGGL(batch_images_packed_kernel<float>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, s, a, (float*)out, Hp, Wp, pad_top, pad_left);
+    return blt_check_launch("batch_images_packed");
 }
 
 int blt_image_store_u8(const float* images, uint8_t* out, long count, hipStream_t s) {

@@ -782,7 +782,7 @@ struct bltvqg_engine {
                 RC(blt_conv_pack_w(dt, FZ(cs.wname), cs.wpacked, cs.Cout, cs.Cin, cs.K, cs.K, cs.CinPad, cs.Cin < 8 ? 8 : cs.K, s));
             frozen_dirty = false;
         }
-        RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 4, 3, 3, imgHp, imgWp, s));
+        if (images) RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 4, 3, 3, imgHp, imgWp, s));      // NULL: the caller filled `img`
         size_t ci = 0;
         ConvSpec& c1 = convs[ci++];
         RC(conv_fwd(c1, img, s));
@@ -866,7 +866,7 @@ struct bltvqg_engine {
     int forward(const float* images, const int64_t* ctx, const int64_t* post, const int64_t* tgt, const float* eps, int p2,
                 uint64_t seed_, hipStream_t s) {
         BLT_REQUIRE(bound, "engine_forward: engine not bound");
-        BLT_REQUIRE(images && ctx && post && tgt, "engine_forward: null input");
+        BLT_REQUIRE((images || !regions) && ctx && post && tgt, "engine_forward: null input");
         BLT_REQUIRE(!p2 || eps, "engine_forward: eps required in phase 2");
         phase2 = p2; seed = seed_; fwd_done = false;
         // with an optimiser update still in flight only the streams that read trainable parameters wait for it (below)
@@ -985,7 +985,7 @@ struct bltvqg_engine {
     int decode_greedy(const float* images, const int64_t* ctx, const float* eps, int p2, int train_bn, int* tokens, int* top_idx, float* top_val,
                       hipStream_t s) {
         BLT_REQUIRE(bound, "engine_decode_greedy: engine not bound");
-        BLT_REQUIRE(images && ctx && tokens && top_idx && top_val, "engine_decode_greedy: null pointer");
+        BLT_REQUIRE((images || !regions) && ctx && tokens && top_idx && top_val, "engine_decode_greedy: null pointer");
         BLT_REQUIRE(!p2 || eps, "engine_decode_greedy: eps required when the latent path is on");
         BLT_REQUIRE(c.attention_dropout == 0.f && c.relu_dropout == 0.f, "engine_decode_greedy: create the decode engine with dropout 0");
         if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
@@ -1434,6 +1434,13 @@ int bltvqg_engine_forward(bltvqg_engine* e, const float* images, const int64_t* 
                           const float* eps, int phase2, uint64_t seed, void* stream) {
     BLT_REQUIRE(e, "engine_forward: null engine");
     return e->forward(images, context, posterior, target, eps, phase2, seed, (hipStream_t)stream);
+}
+
+int bltvqg_engine_image_input(bltvqg_engine* e, void** ptr, int* Hp, int* Wp, int* dtype) {
+    BLT_REQUIRE(e && ptr && Hp && Wp && dtype, "engine_image_input: null argument");
+    BLT_REQUIRE(e->bound && !e->regions, "engine_image_input: engine not bound / region mode has no image input");
+    *ptr = e->img; *Hp = e->imgHp; *Wp = e->imgWp; *dtype = e->dt;
+    return BLT_OK;
 }
 
 int bltvqg_engine_decode_greedy(bltvqg_engine* e, const float* images, const int64_t* context, const float* eps, int phase2, int train_bn,

@@ -224,5 +224,8 @@ int blt_dropout_mask(uint64_t seed, uint32_t stream_id, long rows, int cols, int
 int blt_image_store_u8(const float* images, uint8_t* out, long count, hipStream_t s);
 int blt_batch_rows(const int* questions, const int* answers, const int* answer_types, const int* cat_word_ids, int n_cat, long n_rows,
                    const long* index, int B, int q_len, int a_len, long* oq, long* op, long* oa, long* ot, long* oti, hipStream_t s);
+int blt_batch_images_packed(const uint8_t* table, long n_images, int S, const int* image_indices, long n_rows, const long* index,
+                            const int* boxes, const int* coeffs, int KS, int B, int osz, const float* mean_std, int dtype, void* out, int Hp,
+                            int Wp, int pad_top, int pad_left, hipStream_t s);
 int blt_batch_images(const uint8_t* table, long n_images, int S, const int* image_indices, long n_rows, const long* index, const int* boxes,
                      const int* coeffs, int KS, int B, int osz, const float* mean_std, float* out, uint8_t* out_u8, hipStream_t s);

@@ -126,15 +126,25 @@ class StepEngine(object):
     # ------------------------------------------------------------------------------------------------
     def forward(self, images, context, posterior, target, eps=None, phase2=False, seed=0):
         c = self.cfg
-        assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
-        expect = (c.batch, c.num_regions, c.region_dim) if c.num_regions > 0 else (c.batch, 3, c.image_h, c.image_w)
-        assert tuple(images.shape) == expect, (tuple(images.shape), expect)
+        if images is None:      # the caller filled the stem input itself (image_input(), DeviceBatchProducer.batch(engine=...))
+            assert c.num_regions == 0
+        else:
+            assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+            expect = (c.batch, c.num_regions, c.region_dim) if c.num_regions > 0 else (c.batch, 3, c.image_h, c.image_w)
+            assert tuple(images.shape) == expect, (tuple(images.shape), expect)
         for t, n in ((context, c.len_context), (posterior, c.len_posterior), (target, c.len_target)):
             assert t.is_cuda and t.dtype == torch.int64 and t.is_contiguous() and tuple(t.shape) == (c.batch, n), (t.shape, n)
         if eps is not None:
             assert eps.is_cuda and eps.dtype == torch.float32 and eps.is_contiguous() and tuple(eps.shape) == (c.batch, c.latent_dim)
         check(self.lib.bltvqg_engine_forward(self.h, ptr(images), ptr(context), ptr(posterior), ptr(target), ptr(eps),
                                              1 if phase2 else 0, int(seed), stream_ptr()), "engine_forward")
+
+    def image_input(self):
+        """(device pointer, Hp, Wp, dtype) of the engine's zero-bordered NHWC4 stem input (bltvqg_engine_image_input)."""
+        p, hp, wp, dt = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        check(self.lib.bltvqg_engine_image_input(self.h, ctypes.byref(p), ctypes.byref(hp), ctypes.byref(wp), ctypes.byref(dt)),
+              "engine_image_input")
+        return p, hp.value, wp.value, dt.value
 
     def decode_greedy(self, images, context, eps=None, phase2=False, train_bn=False):
         """Greedy decode over len_target steps; returns (tokens [B,T] int32, top_idx [B,T,6] int32, top_val [B,T,6] fp32)."""

@@ -201,6 +201,13 @@ int bltvqg_batch_images(const uint8_t* table, int64_t n_images, int S, const int
                         const int32_t* boxes, const int32_t* coeffs, int KS, int B, int osz, const float* mean_std, float* out,
                         uint8_t* out_u8, void* stream);
 
+/* bltvqg_batch_images written straight into the train-step engine's stem input (bltvqg_engine_image_input gives out / dtype / Hp / Wp;
+ * pad_top = pad_left = 3): zero-bordered NHWC4 [B,Hp,Wp,4], what bltvqg_img_pack makes of the fp32 NCHW tensor — bit-identical to
+ * batch_images + img_pack, without the fp32 tensor and the extra launch.  Follow with bltvqg_engine_forward(images = NULL). */
+int bltvqg_batch_images_packed(const uint8_t* table, int64_t n_images, int S, const int32_t* image_indices, int64_t n_rows,
+                               const int64_t* index, const int32_t* boxes, const int32_t* coeffs, int KS, int B, int osz, const float* mean_std,
+                               int dtype, void* out, int Hp, int Wp, int pad_top, int pad_left, void* stream);
+
 /* ---------------- train-step engine ---------------- */
 
 typedef struct bltvqg_config {
@@ -240,6 +247,11 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
                        void* workspace, int64_t workspace_bytes);
 /* Frozen backbone weights changed (load_state_dict): repack on next forward. */
 void bltvqg_engine_invalidate_frozen(bltvqg_engine* e);
+
+/* The engine's stem input: zero-bordered NHWC4 [batch, *Hp, *Wp, 4] of *dtype inside the bound workspace, image at (3,3).  A caller
+ * that fills it itself (bltvqg_batch_images_packed) passes images = NULL to bltvqg_engine_forward / decode_greedy, which then skip
+ * bltvqg_img_pack.  Image mode only. */
+int bltvqg_engine_image_input(bltvqg_engine* e, void** ptr, int* Hp, int* Wp, int* dtype);
 
 /* IQ.forward (iq.py:82-114).  images fp32 NCHW [B,3,h,w]; token tensors int64 like the reference batch; eps fp32 [B,Z]
  * (may be NULL in phase 1).  train_bn: BatchNorm in train mode (batch statistics + running-stat update), as the reference. */

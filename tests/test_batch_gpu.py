@@ -132,3 +132,30 @@ def test_full_size_batch_feeds_the_train_step():
         t.fused_training_step(p.batch(next(p.epoch(128, drop_last=True))))
     st = t.last_stats()
     assert np.isfinite(st["loss"]) and st["loss"] > 0
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("resize", [False, True])
+def test_packed_engine_input_is_bit_identical(dtype, resize):
+    """DeviceBatchProducer.batch(engine=...) fills the engine's packed stem input directly: same image feature, bit for bit, as the
+    fp32 NCHW batch + the engine's own img_pack; borders stay zero; identity crops and Pillow-resampled crops."""
+    from bltvqg_amd.batch import DeviceBatchProducer, crop_boxes
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import init_reference_style
+    S, out, B = (80, 64, 6) if resize else (64, 64, 6)
+    store = _synthetic_store(40, 7, S, V=97, n_cat=8, seed=11)
+    p = DeviceBatchProducer(store, out_size=out, scale=(0.3, 1.0) if resize else (1.0, 1.2))
+    e = StepEngine(make_config(B, 64, 128, 64, 20, 1, 4, 97, image_hw=(out, out), dtype=dtype, attention_dropout=0.0, relu_dropout=0.0))
+    e.allocate()
+    init_reference_style(e, seed=3)
+    idx = np.arange(B) * 3
+    boxes = crop_boxes(B, S, S, torch.Generator().manual_seed(1), scale=(0.3, 1.0)) if resize else np.tile(np.array([0, 0, 64, 64], np.int32), (B, 1))
+    b = p.batch(idx, boxes=boxes)
+    e.forward(b["images"], b["answers"], b["posteriors"], b["questions"], None, False, 0)
+    feats_ref, out_ref = e.read(2).clone(), e.read(0).clone()
+    b2 = p.batch(idx, boxes=boxes, engine=e)
+    assert b2["images"] is None and torch.equal(b2["questions"], b["questions"])
+    e.forward(None, b2["answers"], b2["posteriors"], b2["questions"], None, False, 0)
+    assert torch.equal(e.read(2), feats_ref) and torch.equal(e.read(0), out_ref)
+    with pytest.raises(ValueError):
+        p.batch(idx[:3], engine=e)

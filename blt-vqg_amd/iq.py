@@ -210,11 +210,21 @@ class IQ(nn.Module):
         if not images.is_cuda:
             raise RuntimeError("IQ.forward runs on MI355X only (libbltvqg_hip.so); there is no CPU fallback. Move the batch to the GPU.")
         h, w = (images.shape[2], images.shape[3]) if images.dim() == 4 else (0, 0)       # region mode: [B, regions, dim]
+        return self.engine_for_shape(images.shape[0], answers.shape[1], response.shape[1], target.shape[1], h, w, images.device)
+
+    def engine_for_shape(self, B, Sa, Sp, T, h, w, device):
+        """The (cached) engine of one static shape; used directly by loops that fill the engine's stem input themselves
+        (DeviceBatchProducer.batch(engine=...))."""
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the HIP engine runs on MI355X only; there is no CPU fallback")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         # train / eval engines differ in dropout (config) and BatchNorm mode; they share the parameter buffers
-        key = (images.shape[0], answers.shape[1], response.shape[1], target.shape[1], h, w, images.device.index, bool(self.training))
+        key = (int(B), int(Sa), int(Sp), int(T), int(h), int(w), device.index, bool(self.training))
         eng = self._engines.get(key)
         if eng is None:
-            eng = self._make_engine(*key[:6], device=images.device, training=self.training)
+            eng = self._make_engine(*key[:6], device=device, training=self.training)
             if self._primary is None:
                 eng.allocate()
                 self._primary = eng

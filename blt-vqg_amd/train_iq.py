@@ -56,7 +56,8 @@ class TrainIQ(_Base):
         # dict order = reference collate_fn (utils/data_loader.py:175); the reference hard-codes .cuda() (train_iq.py:69,114),
         # routed through args.device here
         dev = self._device()
-        images, questions, posteriors = batch["images"].to(dev), batch["questions"].to(dev), batch["posteriors"].to(dev)
+        images = batch["images"].to(dev) if batch["images"] is not None else None      # None: already in the engine's stem input
+        questions, posteriors = batch["questions"].to(dev), batch["posteriors"].to(dev)
         mode = getattr(self.args, "input_mode", "ans")
         context = batch["answers"].to(dev) if mode == "ans" else batch["answer_types_for_input"].to(dev)
         return images, context, posteriors, questions
@@ -146,7 +147,10 @@ class TrainIQ(_Base):
         """One full reference training step inside the HIP engine.  Returns nothing; `last_stats()` syncs and reads the losses."""
         self._phase_switch()
         images, context, posteriors, questions = self._unpack(batch)
-        eng = self.model.engine(images, context, posteriors, questions)
+        if images is None:      # DeviceBatchProducer.batch(engine=...) wrote the images into this engine's packed stem input
+            eng = batch["engine"]
+        else:
+            eng = self.model.engine(images, context, posteriors, questions)
         if self._dp is None or self._dp.e is not eng:
             self._dp = DataParallelStep(eng, dist)
         if getattr(self, "_pending_adam", None) is not None:      # optimiser state of a loaded checkpoint (fused path)
@@ -157,10 +161,12 @@ class TrainIQ(_Base):
         phase2 = self.latent_transformer
         eps = None
         if phase2:
-            eps = batch["eps"].to(images.device) if "eps" in batch else torch.randn(images.shape[0], self.args.latent_dim, device=images.device)
+            eps = batch["eps"].to(questions.device) if "eps" in batch else torch.randn(questions.shape[0], self.args.latent_dim,
+                                                                                       device=questions.device)
         w = kl_weight(self.kliter, self.args.full_kl_step) if phase2 else 0.0
         self.model._step_seed += 1
-        self._dp.run(images.contiguous().float(), context.contiguous(), posteriors.contiguous(), questions.contiguous(), eps, phase2,
+        self._dp.run(None if images is None else images.contiguous().float(), context.contiguous(), posteriors.contiguous(),
+                     questions.contiguous(), eps, phase2,
                      self.model._base_seed + self.model._step_seed, w, noam_lr(self.iter, self.args.hidden_dim), 5.0)
         self._last_engine, self._last_w = eng, w
         if phase2:
@@ -217,6 +223,28 @@ class TrainIQ(_Base):
                     print("step %d %s" % (step, {k: round(v, 4) for k, v in self.last_stats().items()}), flush=True)
                 if step >= max_steps:
                     break
+
+
+def _fit_from_producer(self, producer, batch_size, max_steps, shuffle=True, log_every=100, dist=None):
+    """Training straight from a store that lives in HBM (blt-vqg_amd/batch.py): per step the producer's two gather kernels write the
+    token rows and the transformed images (into the engine's packed stem input), then the fused step runs — no host pixels at all."""
+    sa = (producer.a_len + 1) if getattr(self.args, "input_mode", "ans") == "ans" else 3
+    step = 0
+    while step < max_steps:
+        for idx in producer.epoch(batch_size, shuffle=shuffle, drop_last=True):
+            eng = self.model.engine_for_shape(batch_size, sa, producer.q_len + 1, producer.q_len, producer.out_size, producer.out_size,
+                                              producer.device)
+            b = producer.batch(idx, engine=eng)
+            b["engine"] = eng
+            self.fused_training_step(b, dist)
+            step += 1
+            if log_every and step % log_every == 0:
+                print("step %d %s" % (step, {k: round(v, 4) for k, v in self.last_stats().items()}), flush=True)
+            if step >= max_steps:
+                break
+
+
+TrainIQ.fit_from_producer = _fit_from_producer
 
 
 def build_parser():

@@ -159,3 +159,37 @@ def test_packed_engine_input_is_bit_identical(dtype, resize):
     assert torch.equal(e.read(2), feats_ref) and torch.equal(e.read(0), out_ref)
     with pytest.raises(ValueError):
         p.batch(idx[:3], engine=e)
+
+
+def test_fit_from_producer_matches_dict_batches():
+    """TrainIQ.fit_from_producer (images written into the engine's stem input) follows the same trajectory as fused_training_step on
+    the producer's fp32 batches."""
+    from bltvqg_amd.batch import DeviceBatchProducer
+    from train_iq import SyntheticVocabulary, TrainIQ
+    V, B = 200, 16
+    store = _synthetic_store(64, 10, 64, V=V, seed=5)
+
+    def make():
+        args = SimpleNamespace(emb_dim=32, hidden_dim=64, latent_dim=64, pwffn_dim=128, num_layers=1, num_heads=4, device="cuda", emb_file=None,
+                               root_dir=".", lr=3e-5, num_pretraining_steps=2, full_kl_step=10, kl_ceiling=0.5, aux_ceiling=1.0,
+                               image_recon_lambda=0.1, batch_size=B, input_mode="ans", print_note="", precision="fp32",
+                               attention_dropout=0.0, relu_dropout=0.0, seed=3)
+        return TrainIQ(SyntheticVocabulary(V), args).to("cuda")
+
+    eps = torch.randn(B, 64, generator=torch.Generator().manual_seed(0)).cuda()
+    p = DeviceBatchProducer(store, out_size=64, seed=0)
+    t1 = make()
+    for idx in list(p.epoch(B, shuffle=False, drop_last=True))[:4]:
+        b = p.batch(idx)
+        b["eps"] = eps
+        t1.fused_training_step(b)
+    t2 = make()
+    real_batch = p.batch
+    p.batch = lambda idx, **kw: dict(real_batch(idx, **kw), eps=eps)         # same latent noise in both runs
+    t2.fit_from_producer(p, B, max_steps=4, shuffle=False, log_every=0)
+    assert t1.iter == t2.iter == 4 and t2.latent_transformer
+    s1, s2 = t1.last_stats(), t2.last_stats()
+    assert abs(s1["loss"] - s2["loss"]) < 1e-4 * max(1.0, abs(s1["loss"]))
+    for (k, v1), (_, v2) in zip(t1.model.state_dict().items(), t2.model.state_dict().items()):
+        if v1.dtype.is_floating_point and v1.numel() > 1:
+            assert float((v1 - v2).abs().max()) <= 1e-4 + 2.5 * 4 * 1e-3, k      # Adam turns rounding noise of ~0 gradients into +-lr

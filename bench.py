@@ -116,6 +116,11 @@ def cpu_baseline(cfg, phase2, batch, steps):
 
 def main():
     a = parse()
+    # stdout carries exactly ONE line, the JSON: native libraries that write to file descriptor 1 (RCCL prints a version banner there
+    # when NCCL_DEBUG=VERSION is set, as it is on the GPU boxes) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -280,7 +285,10 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, phase2, a.cpu_batch, a.cpu_steps)
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if dist:
         dist.destroy_process_group()
 

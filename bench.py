@@ -2,17 +2,23 @@
 """Headline benchmark: image-question pairs/s of the BLT-VQG IQ train step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A step = one full reference training step (train_iq.py:105-132 + Lightning's backward / clip 5 / Adam) on one synthetic
 minibatch per GPU, inputs already resident in HBM: frozen ResNet-18 forward (train-mode BatchNorm), both transformer
 encoders, latent, decoder, losses, the whole backward, gradient all-reduce (N > 1), clip + Adam.  Dropout is on at the
-reference's 0.1/0.1.  Workload at N=1 = BASELINE.json configs[1]: the 2-layer d_model=256 model at batch 128, bf16.
-Prints ONE JSON line on rank 0.
+reference's 0.1/0.1.  Workload = BASELINE.json configs[2] (the configuration the metric's targets are quoted on): the 6-layer
+d_model=512 8-head model at per-GPU batch 256, bf16; `--config small|regions` select configs[1] / configs[4].
+
+N > 1: one process per GPU over RCCL.  Started under `torch.distributed.run` (WORLD_SIZE in the environment) this process is one
+rank; started plainly with `--gpus N` it spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD before
+any GPU call (the parent never initialises the GPU) and relays rank 0's JSON line — the equivalent of the reference's one flag
+`pl.Trainer(gpus=N)` (train_iq.py:372-373).  Prints ONE JSON line on stdout.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,8 +29,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 # trainer's communication stream plus RCCL's own: with 8 queues none of them is silently serialised behind another
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-import torch  # noqa: E402
-
 CONFIGS = {
     # BASELINE.json configs[0]/[1]: train_iq.py defaults-shaped model (small)
     "small": dict(hidden_dim=256, pwffn_dim=512, latent_dim=256, emb_dim=300, num_layers=2, num_heads=4, vocab_size=8000, batch=128),
@@ -34,18 +38,12 @@ CONFIGS = {
     "regions": dict(hidden_dim=512, pwffn_dim=2048, latent_dim=512, emb_dim=300, num_layers=6, num_heads=8, vocab_size=8000, batch=64,
                     num_regions=36, region_dim=2048),
 }
+CONFIG_NAMES = {"small": "BASELINE configs[1]", "big": "BASELINE configs[2]", "regions": "BASELINE configs[4], one GPU's shard"}
 # algorithmic FLOP per pair per train step: CNN fwd x1 + everything trainable x3; regions: the projection runs on the
 # region mean (the mean commutes with the Linear), 2.1 MFLOP per pair instead of the survey's 75.5
 FLOP_PER_PAIR = {"small": 4.25e9, "big": 9.95e9, "regions": 6.33e9}
-
-
-def region_features(B, R, D, seed):
-    """Synthetic bottom-up features: non-negative (post-ReLU) with a per-sample component."""
-    g = torch.Generator().manual_seed(int(seed) + 77)
-    x = torch.relu(torch.randn(B, R, D, generator=g) + 0.3 * torch.randn(B, 1, D, generator=g))
-    return (x * (0.5 + torch.rand(B, 1, 1, generator=g))).contiguous()
-PROFILE_EVERY = 10
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HP = dict(kl_weight=0.5, lr=1e-4, max_norm=5.0)
 
 
 def parse():
@@ -53,37 +51,82 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="small", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="big", choices=sorted(CONFIGS))
     ap.add_argument("--h2d", action="store_true",
-                    help="PCIe-inclusive variant (NOT the headline value): the batch lives in pinned host memory and is copied to the GPU "
-                         "every step on a copy stream, one step ahead (the reference's boundary hands over host tensors, train_iq.py:67-79)")
+                    help="make the PCIe-inclusive variant the timed loop (NOT the headline value): the batch lives in pinned host memory and "
+                         "is copied to the GPU every step on a copy stream, one step ahead (the reference's boundary hands over host tensors, "
+                         "train_iq.py:67-79).  Without this flag that variant is still measured, as the extra field `h2d`")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the config's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--phase", type=int, default=2, choices=[1, 2], help="1 = pre-training (latent off), 2 = latent on")
+    ap.add_argument("--phase", type=int, default=2, choices=[1, 2], help="timed loop: 1 = pre-training (latent off), 2 = latent on")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra fields (phase-1 / PCIe-inclusive loops, per-bucket all-reduce timing)")
+    ap.add_argument("--extra-steps", type=int, default=10)
+    ap.add_argument("--bf16-wire", action="store_true", help="N > 1: gradients cross xGMI as bf16 (half the bytes); default fp32 like Lightning DDP")
     ap.add_argument("--autotune", action="store_true", help="time candidate GEMM/conv kernels per launch in the first warm-up step")
     ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=5)
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, phase2, batch, steps):
-    """The CPU oracle (plain PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host cores:
-    full train step (forward, losses, backward, clip, Adam) on the same synthetic workload at a bounded batch."""
+def spawn_ranks(a):
+    """`--gpus N` without a launcher: start N ranks as a child process group and relay rank 0's JSON line.  Nothing here touches the
+    GPU (no torch.cuda call, no HIP library load): exec'ing or forking from a GPU-initialised process is not allowed on these boxes."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] spawning %d ranks: %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout:
+        if ln.startswith('{"metric"'):
+            line = ln.strip()
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line:
+        print(line, flush=True)
+    return rc if rc else (0 if line else 1)
+
+
+def region_features(B, R, D, seed):
+    """Synthetic bottom-up features: non-negative (post-ReLU) with a per-sample component."""
+    import torch
+    g = torch.Generator().manual_seed(int(seed) + 77)
+    x = torch.relu(torch.randn(B, R, D, generator=g) + 0.3 * torch.randn(B, 1, D, generator=g))
+    return (x * (0.5 + torch.rand(B, 1, 1, generator=g))).contiguous()
+
+
+def oracle_namespace(cfg):
     from types import SimpleNamespace
-    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-    from oracle import iq_oracle as O
-    from synth import synth_state
-    import bltvqg_amd.synthetic as synthetic
-    ns = SimpleNamespace(emb_dim=cfg["emb_dim"], hidden_dim=cfg["hidden_dim"], latent_dim=cfg["latent_dim"], pwffn_dim=cfg["pwffn_dim"],
-                         num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], vocab_size=cfg["vocab_size"],
-                         num_regions=cfg.get("num_regions", 0), region_dim=cfg.get("region_dim", 0))
+    return SimpleNamespace(emb_dim=cfg["emb_dim"], hidden_dim=cfg["hidden_dim"], latent_dim=cfg["latent_dim"], pwffn_dim=cfg["pwffn_dim"],
+                           num_layers=cfg["num_layers"], num_heads=cfg["num_heads"], vocab_size=cfg["vocab_size"],
+                           num_regions=cfg.get("num_regions", 0), region_dim=cfg.get("region_dim", 0))
+
+
+def host_threads():
+    import torch
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))         # the GPU box gives a 1-GPU job a 16-core share; more threads only oversubscribe
     torch.set_num_threads(cores)
+    return cores
+
+
+def cpu_baseline(cfg, phase2, batch, steps):
+    """The CPU oracle (plain PyTorch fp32 restatement of the reference, pinned by tests/golden) timed on the host cores:
+    full train step (forward, losses, backward, clip, Adam) on the same synthetic workload at a bounded batch."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from oracle import iq_oracle as O
+    from synth import synth_state
+    import bltvqg_amd.synthetic as synthetic
+    ns = oracle_namespace(cfg)
+    cores = host_threads()
     print("[bench] cpu baseline: %d threads (os.cpu_count() = %s)" % (cores, os.cpu_count()), file=sys.stderr, flush=True)
     state = synth_state(O.iq_spec(ns), seed=1)
     P = O.clone_params(state)
@@ -97,9 +140,8 @@ def cpu_baseline(cfg, phase2, batch, steps):
     times = []
     for i in range(steps + 1):
         t0 = time.perf_counter()
-        masks = None
         out, z_logit, kld, recon, _ = O.iq_forward(P, ns, b["images"], b["answers"], b["posteriors"], b["questions"], phase2,
-                                                   torch.randn(batch, ns.latent_dim, generator=gen), masks, 0.0, True, {})
+                                                   torch.randn(batch, ns.latent_dim, generator=gen), None, 0.0, True, {})
         loss, _ = O.calculate_losses(out, recon, kld, z_logit, b["questions"], phase2, 100, hp)
         opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -110,12 +152,70 @@ def cpu_baseline(cfg, phase2, batch, steps):
         print("[bench] cpu baseline step %d: %.2f s" % (i, time.perf_counter() - t0), file=sys.stderr, flush=True)
     t = sorted(times)[len(times) // 2]
     return dict(value=round(batch / t, 2), unit="pairs/s", cores=cores, kind="port",
-                sample="%d timed train steps (median) of the CPU oracle at batch %d, fp32, dropout off, same model config and synthetic inputs"
-                       % (steps, batch))
+                sample="%d timed train steps (median, 1 untimed warm-up) of the CPU oracle: same model config and synthetic inputs at batch %d, "
+                       "fp32, phase %d (latent %s), dropout OFF (the GPU leg runs the reference's 0.1/0.1: Philox masks cost the CPU leg nothing "
+                       "it would not also skip), forward + losses + backward + clip 5 + Adam" % (steps, batch, 2 if phase2 else 1,
+                                                                                                 "on" if phase2 else "off"))
+
+
+def loss_vs_oracle(eng, cfg, a, B, phase2, batch, rank):
+    """One dropout-off step of the BENCHED dtype / config / batch on the GPU (an engine of the same shape with dropout 0 that shares the
+    timed engine's current parameters) against the CPU oracle's forward + losses on the same inputs and parameters."""
+    import torch
+    from bltvqg_amd.engine import StepEngine, make_config
+    from oracle import iq_oracle as O
+    dev = eng.device
+    c = make_config(B, cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"], cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"],
+                    cfg["vocab_size"], dtype=1 if a.dtype == "bf16" else 0, attention_dropout=0.0, relu_dropout=0.0,
+                    num_regions=cfg.get("num_regions", 0), region_dim=cfg.get("region_dim", 0))
+    e0 = StepEngine(c, dev)
+    e0.allocate(share_from=eng)
+    ns = oracle_namespace(cfg)
+    state = {n: eng.view(n, 0).detach().cpu().clone() for n in eng.train_info}
+    state.update({n: eng.view(n, 1).detach().cpu().clone() for n in eng.frozen_info})
+    for k, shape in O.iq_spec(ns).items():
+        if k not in state:      # num_batches_tracked counters
+            state[k] = torch.zeros(shape, dtype=torch.long)
+    eps = batch["eps"]
+    d = {k: batch[k].to(dev) for k in ("images", "answers", "posteriors", "questions")}
+    e0.forward(d["images"], d["answers"], d["posteriors"], d["questions"], eps.to(dev) if phase2 else None, phase2, 0)
+    e0.loss_backward(HP["kl_weight"])
+    st = e0.stats()
+    gpu = dict(rec=st["rec"], img=st["img"], kld=st["kld"] if phase2 else 0.0, aux=st["aux"] if phase2 else 0.0)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out, z_logit, kld, recon, _ = O.iq_forward(O.clone_params(state, requires_grad=False), ns, batch["images"], batch["answers"],
+                                                   batch["posteriors"], batch["questions"], phase2, eps, None, 0.0, True, {})
+        hp = O.default_hp()
+        _, ost = O.calculate_losses(out, recon, kld, z_logit, batch["questions"], phase2, 100, hp)
+    print("[bench] oracle forward + losses at batch %d: %.1f s" % (B, time.perf_counter() - t0), file=sys.stderr, flush=True)
+    ref = dict(rec=ost["rec"], img=ost["img"], kld=ost["kld"], aux=ost["aux"])
+
+    def total(x):
+        return x["rec"] + hp.image_recon_lambda * x["img"] + (hp.kl_ceiling * HP["kl_weight"] * x["kld"] + hp.aux_ceiling * x["aux"] if phase2 else 0.0)
+    tg, tr = total(gpu), total(ref)
+    return {"gpu_loss": round(tg, 6), "oracle_loss": round(tr, 6), "abs": round(abs(tg - tr), 6), "rel": round(abs(tg - tr) / max(abs(tr), 1e-30), 6),
+            "components_abs": {k: round(abs(gpu[k] - ref[k]), 6) for k in ref},
+            "what": "total loss (rec + 0.1 img%s) of ONE dropout-off step, %s engine at batch %d with the timed engine's current parameters, injected eps, "
+                    "vs the fp32 CPU oracle on the same inputs" % (" + 0.5*%.2f kld + aux" % HP["kl_weight"] if phase2 else "", a.dtype, B)}
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
+    import torch
+    if os.environ.get("BLT_BENCH_REHEARSE_LAUNCH") == "1":
+        # CPU rehearsal of the launch path only (tests/test_bench_launch.py): the ranks meet over gloo, prove that the collective spans
+        # `--gpus` ranks and rank 0 prints a line of the same shape; nothing is measured and no GPU is touched
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.ones(1)
+        dist.all_reduce(t)
+        if dist.get_rank() == 0:
+            print(json.dumps({"metric": "launch rehearsal (no measurement)", "n_gpus": dist.get_world_size(), "ranks_seen": int(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
     # stdout carries exactly ONE line, the JSON: native libraries that write to file descriptor 1 (RCCL prints a version banner there
     # when NCCL_DEBUG=VERSION is set, as it is on the GPU boxes) are sent to stderr for the duration of the run
     sys.stdout.flush()
@@ -124,8 +224,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (a.gpus, world), file=sys.stderr)
+    if a.gpus != world:
+        print("warning: --gpus %d but WORLD_SIZE %d (the launcher's world size is what runs)" % (a.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -135,10 +235,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == world
 
     import bltvqg_amd.synthetic as synthetic
     from bltvqg_amd.engine import StepEngine, make_config
-    from bltvqg_amd.trainer import DataParallelStep, init_reference_style
+    from bltvqg_amd.trainer import DataParallelStep, comm_plan, init_reference_style, shard_seed
 
     # A/B switches of the kernels (bltvqg_debug_set): BLT_DEBUG="key=value,key=value"
     if os.environ.get("BLT_DEBUG"):
@@ -149,142 +250,210 @@ def main():
     cfg = dict(CONFIGS[a.config])
     B = a.batch or cfg.pop("batch")
     cfg.pop("batch", None)
-    phase2 = a.phase == 2
     c = make_config(B, cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"], cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"],
                     cfg["vocab_size"], dtype=1 if a.dtype == "bf16" else 0, num_regions=cfg.get("num_regions", 0),
                     region_dim=cfg.get("region_dim", 0))
     eng = StepEngine(c, dev)
     eng.allocate()
     init_reference_style(eng, seed=0)                      # same weights on every rank
-    step = DataParallelStep(eng, dist, overlap_optimizer=True)
-    from bltvqg_amd.trainer import shard_seed
+    step = DataParallelStep(eng, dist, overlap_optimizer=True, bf16_wire=a.bf16_wire)
     batch = synthetic.make_batch(B, cfg["vocab_size"], cfg["latent_dim"], seed=shard_seed(1234, rank),
                                  image_hw=32 if cfg.get("num_regions") else 224)
     if cfg.get("num_regions"):
         batch["images"] = region_features(B, cfg["num_regions"], cfg["region_dim"], shard_seed(1234, rank))
-    d = {k: v.to(dev) for k, v in batch.items() if k in ("images", "answers", "posteriors", "questions")}
+    keys = ("images", "answers", "posteriors", "questions")
+    d = {k: batch[k].to(dev) for k in keys}
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
 
-    keys = ("images", "answers", "posteriors", "questions")
-    if a.h2d:
-        host = {k: batch[k].contiguous().pin_memory() for k in keys}
-        bufs = [{k: torch.empty_like(d[k]) for k in keys} for _ in range(2)]
-        copy_stream = torch.cuda.Stream(device=dev)
-        ready = [torch.cuda.Event(), torch.cuda.Event()]       # buffer filled
-        free = [torch.cuda.Event(), torch.cuda.Event()]        # buffer consumed by its step
+    # ---- the PCIe-inclusive feed: pinned host batch, copied one step ahead on a copy stream into two device buffers -----------
+    h2d_state = {}
 
-        def upload(slot):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(free[slot])
-                for k in keys:
-                    bufs[slot][k].copy_(host[k], non_blocking=True)
-                ready[slot].record(copy_stream)
-
-        for ev in free:
+    def h2d_setup():
+        if h2d_state:
+            return
+        h2d_state["host"] = {k: batch[k].contiguous().pin_memory() for k in keys}
+        h2d_state["bufs"] = [{k: torch.empty_like(d[k]) for k in keys} for _ in range(2)]
+        h2d_state["stream"] = torch.cuda.Stream(device=dev)
+        h2d_state["ready"] = [torch.cuda.Event(), torch.cuda.Event()]       # buffer filled
+        h2d_state["free"] = [torch.cuda.Event(), torch.cuda.Event()]        # buffer consumed by its step
+        for ev in h2d_state["free"]:
             ev.record()
         upload(0)
 
-    def one_step(i):
+    def upload(slot):
+        hs = h2d_state
+        with torch.cuda.stream(hs["stream"]):
+            hs["stream"].wait_event(hs["free"][slot])
+            for k in keys:
+                hs["bufs"][slot][k].copy_(hs["host"][k], non_blocking=True)
+            hs["ready"][slot].record(hs["stream"])
+
+    def one_step(i, phase2, h2d=False):
         eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
         cur = d
-        if a.h2d:
+        if h2d:
             slot = i % 2
             upload(slot ^ 1)                                   # next step's batch crosses PCIe underneath this step
-            torch.cuda.current_stream().wait_event(ready[slot])
-            cur = bufs[slot]
+            torch.cuda.current_stream().wait_event(h2d_state["ready"][slot])
+            cur = h2d_state["bufs"][slot]
         step.run(cur["images"], cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=1000 + i,
-                 kl_weight=0.5, lr=1e-4, max_norm=5.0)
-        if a.h2d:
-            free[i % 2].record()
+                 kl_weight=HP["kl_weight"], lr=HP["lr"], max_norm=HP["max_norm"])
+        if h2d:
+            h2d_state["free"][i % 2].record()
 
+    def timed_loop(n, first, phase2, h2d=False, profile_step=-1):
+        """n steps bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the wall time."""
+        if h2d:
+            h2d_setup()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            eng.profile_enable(3 if i == profile_step else 0)
+            one_step(first + i, phase2, h2d)
+        step.finish()                                           # the last (overlapped) optimiser update is part of the timed region
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        eng.profile_enable(0)
+        if dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    phase2 = a.phase == 2
     print("[bench] rank %d: engine ready (workspace %.2f GB), warming up" % (rank, eng.workspace_bytes / 1e9), file=sys.stderr, flush=True)
+    if a.h2d:
+        h2d_setup()
     if a.autotune:
         # measure, don't guess: the first warm-up step times every candidate GEMM/conv kernel (tile shape, LDS-DMA ring vs
         # register staging) on the real operands of each distinct launch and caches the fastest (csrc/gemm.hip::autotune)
         eng.lib.bltvqg_debug_set(2, 1)
-        one_step(0)
+        one_step(0, phase2, a.h2d)
         torch.cuda.synchronize()
         eng.lib.bltvqg_debug_set(2, 0)
     for i in range(a.warmup):
-        one_step(i)
+        one_step(i, phase2, a.h2d)
     torch.cuda.synchronize()
     print("[bench] rank %d: warm-up done" % rank, file=sys.stderr, flush=True)
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    # The conv kernels are bracketed by HIP events on their own stream for the roofline figure.  An event record costs the stream
-    # a ~5.7 us bubble (40 of them per step = 5 % of a 4 ms step), so only every PROFILE_EVERY-th timed step carries them.
-    profiled = 0
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        on = (i % PROFILE_EVERY == 0)
-        eng.profile_enable(on)
-        profiled += int(on)
-        one_step(a.warmup + i)
-    step.finish()                                           # the last (overlapped) optimiser update is part of the timed region
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    # ---- the timed region: EXACTLY a.steps steps.  ONE of them (the middle one) carries a HIP event pair around every launch of the
+    # two dominant kernel families, on the stream of the launch — an event record costs its stream a ~5.7 us bubble, ~1100 of them
+    # would add ~50 % to every step, so they are sampled; the profiled step IS inside the timed region and counted in `value`.
+    prof_step = a.steps // 2
+    dt = timed_loop(a.steps, a.warmup, phase2, a.h2d, profile_step=prof_step)
     print("[bench] rank %d: %d timed steps in %.3f s" % (rank, a.steps, dt), file=sys.stderr, flush=True)
-    conv_ms, conv_launches, conv_flops = eng.profile_read()
-    eng.profile_enable(False)
+    conv_ms, conv_n, conv_flops = eng.profile_read(0)
+    gemm_ms, gemm_n, gemm_flops = eng.profile_read(1)
+    stats = eng.stats()
     # What an event bracket measures on top of the kernel it brackets: empty brackets on the same stream (the two markers' own
     # latency, ~4-5 us).  It is subtracted per launch below; the raw figure is reported next to it.
-    null_us = 0.0
-    if conv_launches:
-        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
-        tiny = torch.zeros(64, device=dev)
-        for ea, eb in pairs:
-            tiny.add_(1.0)                       # a kernel in front, as in the step (markers behind an idle stream are cheaper)
-            ea.record()
-            eb.record()
-        torch.cuda.synchronize()
-        null_us = sorted(ea.elapsed_time(eb) * 1e3 for ea, eb in pairs)[len(pairs) // 2]
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]
+    tiny = torch.zeros(64, device=dev)
+    for ea, eb in pairs:
+        tiny.add_(1.0)                       # a kernel in front, as in the step (markers behind an idle stream are cheaper)
+        ea.record()
+        eb.record()
+    torch.cuda.synchronize()
+    null_us = sorted(ea.elapsed_time(eb) * 1e3 for ea, eb in pairs)[len(pairs) // 2]
+
+    extras = {}
+    if not a.no_extras and a.extra_steps > 0:
+        n = a.extra_steps
+        # both training phases (train_iq.py:108-111) and the PCIe-inclusive feed (train_iq.py:67-79), each as a short loop of its own
+        other = not phase2
+        for _ in range(2):
+            one_step(0, other, a.h2d)
+        dt_o = timed_loop(n, 0, other, a.h2d)
+        extras["phase%d" % (2 if other else 1)] = {"ms_per_step": round(dt_o / n * 1e3, 3), "pairs_per_s": round(B * world * n / dt_o, 1), "steps": n}
+        for _ in range(2):
+            one_step(0, phase2, not a.h2d)
+        dt_h = timed_loop(n, 0, phase2, not a.h2d)
+        extras["resident" if a.h2d else "h2d"] = {
+            "ms_per_step": round(dt_h / n * 1e3, 3), "pairs_per_s": round(B * world * n / dt_h, 1), "steps": n,
+            "what": "same step, batch resident in HBM" if a.h2d else
+                    "same step fed from a pinned host batch copied over PCIe every step, one step ahead on a copy stream (never the headline value)"}
+    comm = None
     if dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    stats = eng.stats()
+        # the exchange in isolation: each collective of the step's plan alone on the communication stream, median of 5
+        comm = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "wire": "bf16" if a.bf16_wire else "fp32", "allreduce": []}
+        from bltvqg_amd.trainer import allreduce_bucket
+        for ids, off, n in comm_plan(step.buckets, phase2):
+            ts = []
+            for _ in range(6):
+                torch.cuda.synchronize()
+                dist.barrier()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                with torch.cuda.stream(step.comm):
+                    e0.record()
+                    allreduce_bucket(dist, eng.flat_grad, off, n, step.wire)
+                    e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ms = sorted(ts[1:])[2]
+            nbytes = n * (2 if a.bf16_wire else 4)
+            w = dist.get_world_size()
+            comm["allreduce"].append({"buckets": ids, "bytes": nbytes, "ms": round(ms, 3),
+                                      "bus_GBps": round(2.0 * (w - 1) / w * nbytes / (ms * 1e-3) / 1e9, 1) if w > 1 else None})
+
     if rank == 0:
         ms = dt / a.steps * 1e3
         value = B * world * a.steps / dt
-        raw_us = conv_ms * 1e3 / max(conv_launches, 1)
-        launch_us = max(raw_us - null_us, 1e-3)
-        achieved = conv_flops / (launch_us * 1e-6 * max(conv_launches, 1)) / 1e12 if conv_ms > 0 else 0.0
-        # HBM bytes per conv launch from the committed PMC passes (profiles/summarize_pmc.py); they were collected for this
-        # default workload only, so any other configuration reports null
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_conv_traffic.json")
-        if a.config == "small" and B == 128 and a.dtype == "bf16" and os.path.exists(pmc):
-            traffic = int(json.load(open(pmc))["traffic_MB_per_launch"] * 1e6)
+
+        def family(ms_total, launches, flops, kernel):
+            if not launches:
+                return None
+            raw_us = ms_total * 1e3 / launches
+            us = max(raw_us - null_us, 1e-3)
+            achieved = flops / (us * 1e-6 * launches) / 1e12
+            return {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
+                    "kernel": kernel, "launches_per_step": launches, "gflop_per_step": round(flops / 1e9, 1),
+                    "avg_launch_us": round(us, 2), "avg_bracket_us_raw": round(raw_us, 2), "empty_bracket_us": round(null_us, 2),
+                    "profiled_steps": "1 of the %d timed steps (step %d) carries a HIP event pair around every launch of the family, on the "
+                                      "stream of the launch" % (a.steps, prof_step),
+                    "kernel_time_ms_per_step": round(us * launches * 1e-3, 3)}
+        roof = family(gemm_ms, gemm_n, gemm_flops,
+                      "every Linear-layer GEMM of the step (attention q|k|v / output projections, FFN, embedding, vocabulary projection, latent "
+                      "nets: forward gemm_nt_kernel / gemm_dma_kernel<*,*,plain,*>, input gradients through the transposed weight shadow, weight "
+                      "gradients gemm_kernel<bf16,*,*,T,T> / wgrad_group_kernel); flops = 2*M*N*K per launch")
+        roof_conv = family(conv_ms, conv_n, conv_flops,
+                           "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), conv_stem_direct_kernel (1), "
+                           "gemm_dma_kernel<*,*,conv,*> (6: stride-2 / 1x1); flops over real pixels, unpadded Cin")
+        # HBM bytes per launch from the committed PMC passes (profiles/summarize_pmc.py): collected for the default workload only
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        if a.config == "big" and B == 256 and a.dtype == "bf16" and os.path.exists(pmc):
+            tr = json.load(open(pmc))
+            if roof and "gemm_bytes_per_launch" in tr:
+                roof["traffic"] = int(tr["gemm_bytes_per_launch"])
+            if roof_conv and "conv_bytes_per_launch" in tr:
+                roof_conv["traffic"] = int(tr["conv_bytes_per_launch"])
         out = {
             "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic, pinned host batch copied over PCIe every step (one step ahead)" if a.h2d else "synthetic",
-            "config": {"workload": "IQ train step (fwd+loss+bwd+clip+Adam), %s cfg: %d-layer d_model=%d, per-GPU batch %d, %s, "
+            "config": {"workload": "%s: IQ train step (fwd+loss+bwd+clip+Adam), %s cfg: %d-layer d_model=%d %d-head, per-GPU batch %d, %s, "
                                    "T=20/S_a=5/S_p=21, V=%d, phase %d, dropout 0.1" % (
-                                       a.config, cfg["num_layers"], cfg["hidden_dim"], B,
+                                       CONFIG_NAMES[a.config], a.config, cfg["num_layers"], cfg["hidden_dim"], cfg["num_heads"], B,
                                        "%dx%d region features (no CNN)" % (cfg["num_regions"], cfg["region_dim"]) if cfg.get("num_regions")
                                        else "224x224 images", cfg["vocab_size"], a.phase),
                        "global_batch": B * world, "parallelism": "dp%d" % world, "loss_rec": round(stats["rec"], 4),
                        "model_tflops": round(value * FLOP_PER_PAIR[a.config] / 1e12, 2)},
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
-                         "kernel": "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), "
-                                   "conv_stem_direct_kernel (1), gemm_dma_kernel<*,*,conv,*> (6: stride-2 / 1x1)" if conv_launches else
-                                   "not measured: this configuration has no convolution stack (the bracketed kernels)",
-                         "launches_per_step": conv_launches // max(profiled, 1),
-                         "avg_launch_us": round(launch_us, 2), "avg_bracket_us_raw": round(raw_us, 2),
-                         "empty_bracket_us": round(null_us, 2),
-                         "profiled_steps": "%d of the %d timed steps (every %dth) carry the HIP events" % (profiled, a.steps, PROFILE_EVERY),
-                         "kernel_share_of_step": round(launch_us * 1e-3 * (conv_launches // max(profiled, 1)) / (dt / a.steps * 1e3), 4)},
+            "roofline": roof if roof else roof_conv,
         }
+        if roof and roof_conv:
+            out["roofline_conv"] = roof_conv
+        out.update(extras)
+        if comm:
+            out["dist"] = comm
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, phase2, a.cpu_batch, a.cpu_steps)
+            out["loss_vs_oracle"] = loss_vs_oracle(eng, cfg, a, B, phase2, batch, rank)
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

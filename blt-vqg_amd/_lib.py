@@ -106,10 +106,12 @@ SIGNATURES = {
     "bltvqg_engine_optimizer_wait": (I, [P, P]),
     "bltvqg_engine_adam_steps": (I, [P, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "bltvqg_engine_set_adam_steps": (I, [P, ctypes.c_int32, ctypes.c_int32]),
+    "bltvqg_engine_share_optimizer_state": (I, [P, P]),
     "bltvqg_engine_read": (I, [P, I, P, P]),
     "bltvqg_engine_dropout_stream_id": (U32, [I, I, I]),
     "bltvqg_engine_profile_enable": (I, [P, I]),
     "bltvqg_engine_profile_read": (I, [P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]),
+    "bltvqg_engine_profile_read_class": (I, [P, I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]),
     "bltvqg_engine_num_buckets": (I, [P]),
     "bltvqg_engine_bucket_info": (I, [P, I, ctypes.POINTER(L), ctypes.POINTER(L), ctypes.POINTER(ctypes.c_int32)]),
     "bltvqg_engine_bucket_wait": (I, [P, I, P]),

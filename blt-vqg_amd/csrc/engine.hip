@@ -6,7 +6,9 @@
 // models/encoder_transformer.py:22-37, models/decoder_transformer.py:22-41, models/transformer_layers.py:41-59,138-152,
 // 205-221,260-282,326-364,400-408,486-532, models/mlp.py:49-56, train_iq.py:81-103 (losses), 259-261,372 (Adam, clip).
 #include <map>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 #include <math.h>
 #include <stdio.h>
@@ -85,7 +87,11 @@ struct bltvqg_engine {
     bool bound = false, frozen_dirty = true, fwd_done = false;
     int phase2 = 0;
     uint64_t seed = 0;
-    int step_main = 0, step_late = 0;
+    // Adam bias-correction counters of the always-trained / latent-phase-only regions.  They belong to the OPTIMISER STATE (the
+    // moment buffers), not to an engine: engines of different batch shapes that share one set of parameter / moment buffers (the
+    // ragged last batch of an epoch) share one counter object too (bltvqg_engine_share_optimizer_state).
+    struct AdamSteps { int main = 0, late = 0; };
+    std::shared_ptr<AdamSteps> steps = std::make_shared<AdamSteps>();
     int last_bwd_phase2 = 0;
     // workspace buffers
     void* wshadow = nullptr;    // bf16 mirror of the flat trainable buffer (bf16 mode)
@@ -154,11 +160,36 @@ struct bltvqg_engine {
         if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) { blt_set_error("engine: stream fork/join failed"); return BLT_ERR_HIP; }
         return BLT_OK;
     }
-    // optional in-stream timing of the dominant kernel (implicit-GEMM conv): one event pair per launch
-    bool prof_on = false;
-    std::vector<hipEvent_t> prof_a, prof_b;
+    // optional in-stream timing of the two dominant kernel families: one event pair per launch, on the stream of the launch.
+    // class 0 = the convolution launches of the frozen ResNet-18 stack, class 1 = every Linear-layer GEMM (forward, input gradient,
+    // weight gradient) of the transformer stacks / embedding / vocabulary projection / latent nets.  prof_mask bit c enables class c.
+    int prof_mask = 0;
+    struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; double flops = 0.0; };
+    std::vector<ProfRec> prof;
     size_t prof_n = 0;
-    double prof_flops = 0.0;
+    int prof_begin(int cls, hipStream_t s) {
+        if (!((prof_mask >> cls) & 1)) return -1;
+        if (prof_n == prof.size()) {
+            ProfRec r;
+            if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+            prof.push_back(r);
+        }
+        prof[prof_n].cls = cls;
+        (void)hipEventRecord(prof[prof_n].a, s);
+        return (int)prof_n++;
+    }
+    void prof_end(int idx, hipStream_t s, double flops) {
+        if (idx < 0) return;
+        (void)hipEventRecord(prof[idx].b, s);
+        prof[idx].flops = flops;
+    }
+    // every Linear-layer GEMM of the engine goes through here (class-1 bracket when enabled)
+    int gemm(int dtype, const GemmArgs& g, hipStream_t s) {
+        const int pi = (prof_mask & 2) ? prof_begin(1, s) : -1;
+        const int rc = blt_gemm(dtype, g, s);
+        prof_end(pi, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);
+        return rc;
+    }
     int64_t bucket_off[3], bucket_len[3];
     int bucket_late[3];
 
@@ -324,9 +355,10 @@ struct bltvqg_engine {
     int64_t layout(char* base) {
         int64_t off = 0;
         auto A = [&](int64_t bytes) -> void* {
-            char* p = base + off;
+            // integer arithmetic: the sizing pass runs with base = nullptr (pointer arithmetic on a null pointer is undefined behaviour)
+            void* p = (void*)((uintptr_t)base + (uintptr_t)off);
             off += (bytes + 255) / 256 * 256;
-            return (void*)p;
+            return p;
         };
         auto AT = [&](int64_t elems) -> void* { return A(elems * es); };
         auto AF = [&](int64_t n) -> float* { return (float*)A(n * 4); };
@@ -340,7 +372,7 @@ struct bltvqg_engine {
         timing = AF((int64_t)64 * H);
         ids_all = AI(Mtot); pos_all = AI(Mtot); tgt_shift = AI(Mt); tgt32 = AI(Mt); ctx32 = AI(Ma); post32 = AI(Mp);
         counters = AF(1 + B);
-        stats = AF(8);
+        stats = (float*)((uintptr_t)AF(12) + sizeof(float));         // stats[-1] = number of token ids outside [0, V) seen by prep_tokens (zeroed with the loss statistics)
         eps_dev = AF((int64_t)B * Z);
         // CNN
         img = regions ? nullptr : AT((int64_t)B * imgHp * imgWp * 4);
@@ -353,7 +385,7 @@ struct bltvqg_engine {
             if (cs.pp) {      // guards of zero pixels in front of / behind the positions (the bind-time memset provides the zeros)
                 M = blt_pp_pixels(B, cs.Ho, cs.Wo);
                 char* base_ = (char*)AT((BLT_PP_GUARD_FRONT + M + BLT_PP_GUARD_TAIL) * cs.Cout);
-                cs.out = base_ + (size_t)BLT_PP_GUARD_FRONT * cs.Cout * es;
+                cs.out = (void*)((uintptr_t)base_ + (size_t)BLT_PP_GUARD_FRONT * cs.Cout * es);
             } else {
                 cs.out = AT(M * cs.Cout);
             }
@@ -365,7 +397,7 @@ struct bltvqg_engine {
         if (!regions) {
             const int ph = (convs[0].Ho + 2 - 3) / 2 + 1, pw = (convs[0].Wo + 2 - 3) / 2 + 1;
             char* base_ = (char*)AT((BLT_PP_GUARD_FRONT + blt_pp_pixels(B, ph, pw) + BLT_PP_GUARD_TAIL) * 64);
-            pool0 = base_ + (size_t)BLT_PP_GUARD_FRONT * 64 * es;
+            pool0 = (void*)((uintptr_t)base_ + (size_t)BLT_PP_GUARD_FRONT * 64 * es);
         }
         pooled = AF((int64_t)B * FD);
         featpre = AF((int64_t)B * H); feats32 = AF((int64_t)B * H); dfeats32 = AF((int64_t)B * H); dfeatpre32 = AF((int64_t)B * H);
@@ -498,12 +530,12 @@ struct bltvqg_engine {
         GemmArgs g = mk(dY, ldy, 1, X, ldx, 1, G(wname), p.dims[1], p.dims[0], p.dims[1], M);
         g.out_f32 = 1; g.split_k = 32;
         if (bias) g.a_rowsum = G(bias);       // bias gradient in the same launch
-        return blt_gemm(dt, g, s);
+        return gemm(dt, g, s);
     }
     // same, but deferred to the weight-gradient stream when the caller's operands are stable (stack_bwd)
     int wgrad_later(const GemmArgs& g, hipStream_t s) {
         if (defer_wgrads) { pending_wgrads.push_back(g); return BLT_OK; }
-        return blt_gemm(dt, g, s);
+        return gemm(dt, g, s);
     }
     int wgrad_later(const void* dY, int ldy, const void* X, int ldx, const std::string& wname, const char* bias, int M, hipStream_t s) {
         const PInfo& p = tpi(wname);
@@ -516,7 +548,7 @@ struct bltvqg_engine {
     int flush_wgrads(hipStream_t from, hipStream_t to, hipEvent_t ev) {
         if (pending_wgrads.empty() && pending_ln.empty()) return BLT_OK;
         int rc = fork(from, to, ev);
-        for (size_t i = 0; i < pending_wgrads.size() && !rc; ++i) rc = blt_gemm(dt, pending_wgrads[i], to);
+        for (size_t i = 0; i < pending_wgrads.size() && !rc; ++i) rc = gemm(dt, pending_wgrads[i], to);
         pending_wgrads.clear();
         for (size_t i = 0; i < pending_ln.size() && !rc; i += BLT_LN_RED_MAX) {
             LnRedArgs a;
@@ -548,10 +580,10 @@ struct bltvqg_engine {
     // workgroups into an fp32 scratch (atomics) and cast back; falls through to the plain kernel in fp32 mode / small V
     int dgrad_bigk(const void* dY, int ldy, const std::string& wname, void* dX, int ldx, int M, hipStream_t s, float* acc_buf = nullptr,
                    size_t acc_floats = 0) {
-        if (dt != BLT_BF16 || tpi(wname).dims[0] < 2048) return blt_gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
+        if (dt != BLT_BF16 || tpi(wname).dims[0] < 2048) return gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
         // enough rows to fill the chip with 64x64 tiles (the decoder's output projection: 40 x 4 tiles, 125 K-tiles each on a deep ring):
         // the k-contiguous form through the transposed shadow needs no fp32 scratch, memset or cast
-        if (M >= 1024 && WT(wname, tpi(wname).dims[0]) != nullptr) return blt_gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
+        if (M >= 1024 && WT(wname, tpi(wname).dims[0]) != nullptr) return gemm(dt, dgrad(dY, ldy, wname, dX, ldx, M), s);
         GemmArgs g;
         {   // n-contiguous B (the plain shadow): the split-K path lives in the register-staged kernel
             int ldw;
@@ -560,10 +592,10 @@ struct bltvqg_engine {
             g = mk(dY, ldy, 0, w, ldw, 1, dX, ldx, M, p.dims[1], p.dims[0]);
         }
         float* acc = acc_buf ? acc_buf : acc_big;
-        if ((size_t)M * g.N > (acc_buf ? acc_floats : (size_t)(Mp > Mt ? Mp : Mt) * H)) return blt_gemm(dt, g, s);
+        if ((size_t)M * g.N > (acc_buf ? acc_floats : (size_t)(Mp > Mt ? Mp : Mt) * H)) return gemm(dt, g, s);
         if (hipMemsetAsync(acc, 0, (size_t)M * g.N * 4, s) != hipSuccess) { blt_set_error("dgrad_bigk: memset failed"); return BLT_ERR_HIP; }
         g.C = acc; g.ldc = g.N; g.out_f32 = 1; g.split_k = 16;
-        { const int rc_ = blt_gemm(dt, g, s); if (rc_) return rc_; }
+        { const int rc_ = gemm(dt, g, s); if (rc_) return rc_; }
         return blt_cast_rows(BLT_F32, acc, g.N, dt, dX, ldx, M, g.N, s);
     }
 
@@ -621,12 +653,12 @@ struct bltvqg_engine {
         GemmArgs g = lin(xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, F, M);
         if (lnA_on()) set_lnA(g, xres, ln, xn, m, r);
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 1);
-        RC(blt_gemm(dt, g, s));
+        RC(gemm(dt, g, s));
         g = lin(y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), y.x2, H, M);
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 2);
         g.C2 = y.y2; g.ldc2 = H; g.R = xres; g.ldr = H;
         if (ln_fused()) set_ln(g, next.name, next.out, next.m, next.r);
-        RC(blt_gemm(dt, g, s));
+        RC(gemm(dt, g, s));
         if (!ln_fused() && (next_is_final || !lnA_on()))
             RC(blt_layernorm_fwd(dt, y.x2, P(next.name + ".weight"), P(next.name + ".bias"), next.out, next.m, next.r, M, H, 1e-5f, s));
         return BLT_OK;
@@ -639,7 +671,7 @@ struct bltvqg_engine {
             const std::string a2 = dec.prefix + ".dec." + std::to_string(l) + ".multi_head_attention_enc_dec.";
             int ldw;
             const void* w = W(a2 + "key_linear.weight", &ldw);
-            RC(blt_gemm(dt, mk(enc.out, H, 0, w, ldw, 0, dec.layers[l].kv2, 2 * H, Ma, 2 * H, H), sb));
+            RC(gemm(dt, mk(enc.out, H, 0, w, ldw, 0, dec.layers[l].kv2, 2 * H, Ma, 2 * H, H), sb));
         }
         if (hipEventRecord(fj[13], sb) != hipSuccess) { blt_set_error("engine_forward: event record failed"); return BLT_ERR_HIP; }
         kv_hoisted = true;
@@ -673,7 +705,7 @@ struct bltvqg_engine {
                 const void* w = W(a1 + "query_linear.weight", &ldw);
                 GemmArgs g = mk(y.xn1, H, 0, w, ldw, 0, y.qkv, 3 * H, M, 3 * H, H);
                 if (lnA_on()) set_lnA(g, x, lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha"), y.xn1, y.m1, y.r1);
-                RC(blt_gemm(dt, g, s));
+                RC(gemm(dt, g, s));
             }
             RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
                         st.dec ? causal_mode : 0, sid(st.id, l, 0), s));
@@ -682,7 +714,7 @@ struct bltvqg_engine {
                 GemmArgs g = lin(y.ctx, H, a1 + "output_linear.weight", nullptr, y.x1, H, M);
                 g.R = x; g.ldr = H;
                 if (ln_fused()) set_ln(g, ln2, y.xn2, y.m2, y.r2);
-                RC(blt_gemm(dt, g, s));
+                RC(gemm(dt, g, s));
                 if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
             }
             if (st.dec) {
@@ -690,12 +722,12 @@ struct bltvqg_engine {
                 {
                     GemmArgs g = lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M);
                     if (lnA_on()) set_lnA(g, y.x1, ln2, y.xn2, y.m2, y.r2);
-                    RC(blt_gemm(dt, g, s));
+                    RC(gemm(dt, g, s));
                 }
                 if (!kv_hoisted) {
                     int ldw;
                     const void* w = W(a2 + "key_linear.weight", &ldw);
-                    RC(blt_gemm(dt, mk(enc_out, H, 0, w, ldw, 0, y.kv2, 2 * H, Ma, 2 * H, H), s));
+                    RC(gemm(dt, mk(enc_out, H, 0, w, ldw, 0, y.kv2, 2 * H, Ma, 2 * H, H), s));
                 } else if (l == 0 && hipStreamWaitEvent(s, fj[13], 0) != hipSuccess) {
                     blt_set_error("engine_forward: stream wait failed");
                     return BLT_ERR_HIP;
@@ -705,7 +737,7 @@ struct bltvqg_engine {
                 GemmArgs g = lin(y.ctx2, H, a2 + "output_linear.weight", nullptr, y.x1b, H, M);
                 g.R = y.x1; g.ldr = H;
                 if (ln_fused()) set_ln(g, ln3, y.xn3, y.m3, y.r3);
-                RC(blt_gemm(dt, g, s));
+                RC(gemm(dt, g, s));
                 if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s));
                 RC(ffn_fwd(lp + "positionwise_feed_forward.", ln3, y.xn3, y.m3, y.r3, y.x1b, y, M, st.id, l, next, l + 1 == L, s));
             } else {
@@ -736,23 +768,12 @@ struct bltvqg_engine {
             g.M = B * g.cg.Ho * g.cg.Wo;
         }
         if (bn_train) { g.stat_sum = stat_sum; g.stat_sq = stat_sq; }
-        if (prof_on) {
-            if (prof_n == prof_a.size()) {
-                hipEvent_t a, b;
-                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { blt_set_error("profile: event creation failed"); return BLT_ERR_HIP; }
-                prof_a.push_back(a); prof_b.push_back(b);
-            }
-            (void)hipEventRecord(prof_a[prof_n], s);
-        }
+        const int pi = prof_begin(0, s);
         const bool direct_stem = stem && blt_conv_stem_direct_ok(dt, c.image_h, c.image_w, imgHp, imgWp, cs.Cout);
         if (direct) RC(blt_conv3x3_pp(x, cs.wpacked, cs.out, B, cs.Ho, cs.Wo, cs.Cin, cs.Cout, g.stat_sum, g.stat_sq, s));
         else if (direct_stem) RC(blt_conv_stem_direct(x, cs.wpacked, cs.out, B, c.image_h, c.image_w, imgHp, imgWp, g.stat_sum, g.stat_sq, s));
         else RC(blt_gemm(dt, g, s));
-        if (prof_on) {
-            (void)hipEventRecord(prof_b[prof_n], s);
-            ++prof_n;
-            prof_flops += 2.0 * (double)B * cs.Ho * cs.Wo * (double)cs.Cout * (double)(cs.K * cs.K * cs.Cin);   // algorithmic: real pixels, unpadded Cin
-        }
+        prof_end(pi, s, 2.0 * (double)B * cs.Ho * cs.Wo * (double)cs.Cout * (double)(cs.K * cs.K * cs.Cin));   // algorithmic: real pixels, unpadded Cin
         if (!bn_train)
             return blt_bn_eval_scale(FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"),
                                      1e-5f, cs.scale, cs.shift, cs.Cout, s);
@@ -823,7 +844,7 @@ struct bltvqg_engine {
             const PInfo& pw = tpi(fcw);
             GemmArgs g = mk(pooled, FD, 0, train + pw.off, FD, 0, featpre, H, B, H, FD);
             g.bias = P(fcb);
-            RC(blt_gemm(BLT_F32, g, s));
+            RC(gemm(BLT_F32, g, s));
         }
         if (bn_train) {
             RC(blt_bn1d_fwd(BLT_F32, featpre, P("encoder_cnn.bn.weight"), P("encoder_cnn.bn.bias"), feats32, bn1_mean, bn1_rstd,
@@ -839,11 +860,11 @@ struct bltvqg_engine {
     int mlp3_fwd(const std::string& net, const void* x, int din, void* h1, void* h2, void* out, hipStream_t s) {
         GemmArgs g = lin(x, din, net + ".0.weight", (net + ".0.bias").c_str(), h1, 2 * Z, B);
         g.relu = 1;   // the ReLU that opens the next Sequential stage is applied to the stored activation
-        RC(blt_gemm(dt, g, s));
+        RC(gemm(dt, g, s));
         g = lin(h1, 2 * Z, net + ".3.weight", (net + ".3.bias").c_str(), h2, 2 * Z, B);
         g.relu = 1;
-        RC(blt_gemm(dt, g, s));
-        return blt_gemm(dt, lin(h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), out, 2 * Z, B), s);
+        RC(gemm(dt, g, s));
+        return gemm(dt, lin(h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), out, 2 * Z, B), s);
     }
     // backward of mlp3: dout [B,2Z] -> parameter grads, dx [B,din] (written, or accumulated into dx if acc)
     int mlp3_bwd(const std::string& net, int which, const void* x, int din, const void* h1, const void* h2, const void* dout, void* dx, int lddx,
@@ -852,15 +873,15 @@ struct bltvqg_engine {
         RC(wgrad_later(dout, 2 * Z, h2, 2 * Z, net + ".6.weight", (net + ".6.bias").c_str(), B, s));
         GemmArgs g = dgrad(dout, 2 * Z, net + ".6.weight", gh2, 2 * Z, B);
         g.maskY = h2; g.ldm = 2 * Z; g.mask_scale = 1.f;
-        RC(blt_gemm(dt, g, s));
+        RC(gemm(dt, g, s));
         RC(wgrad_later(gh2, 2 * Z, h1, 2 * Z, net + ".3.weight", (net + ".3.bias").c_str(), B, s));
         g = dgrad(gh2, 2 * Z, net + ".3.weight", gh1, 2 * Z, B);
         g.maskY = h1; g.ldm = 2 * Z; g.mask_scale = 1.f;
-        RC(blt_gemm(dt, g, s));
+        RC(gemm(dt, g, s));
         RC(wgrad_later(gh1, 2 * Z, x, din, net + ".0.weight", (net + ".0.bias").c_str(), B, s));
         g = dgrad(gh1, 2 * Z, net + ".0.weight", dx, lddx, B);
         g.accumulate = acc;
-        return blt_gemm(dt, g, s);
+        return gemm(dt, g, s);
     }
 
     int forward(const float* images, const int64_t* ctx, const int64_t* post, const int64_t* tgt, const float* eps, int p2,
@@ -873,7 +894,7 @@ struct bltvqg_engine {
         const bool overlap_opt = opt_pending && use_streams;
         if (opt_pending && !overlap_opt) { RC(sync_opt(s)); opt_pending = false; }
         // loss statistics [0..3]; [4] (gradient norm) belongs to the optimiser, which may still be reading it
-        if (hipMemsetAsync(stats, 0, 4 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
+        if (hipMemsetAsync(stats - 1, 0, 5 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
         if (overlap_opt) {
             // the frozen CNN does not depend on the update: it is enqueued first, everything else goes behind the optimiser
             hipStream_t s0 = side[0];
@@ -913,7 +934,7 @@ struct bltvqg_engine {
         if (dt == BLT_BF16 && !tlist.empty()) RC(blt_shadow_transpose(train, wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
-                           tgt32, ctx32, post32, counters, s));
+                           tgt32, ctx32, post32, counters, V, stats - 1, s));
         if (se != s) RC(fork(s, se, fj[0]));
         // shared embedding over the three token streams at once (iq.py:72-78): gather -> Linear(E,H) + bias + timing signal
         RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Mtot, E, Epad, se));
@@ -923,7 +944,7 @@ struct bltvqg_engine {
             GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Mtot, H, E);
             g.bias = P("embedding.1.bias");
             g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
-            RC(blt_gemm(dt, g, se));
+            RC(gemm(dt, g, se));
         }
         enc.x_in = X_all; enc.key_ids = ctx32;
         dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = tgt_shift;
@@ -950,12 +971,12 @@ struct bltvqg_engine {
             RC(mlp3_fwd("latent_layer.mean_logvar_prior", (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, mlvp, s));
             RC(mlp3_fwd("latent_layer.mean_logvar_posterior", cat_in, 2 * H, mlvq_h1, mlvq_h2, mlvq, s));
             RC(blt_latent_fwd(dt, mlvp, mlvq, eps_dev, zlat, stats + 2, B, Z, 2 * Z, s));
-            RC(blt_gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
+            RC(gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
             // target_embedding[:,0] += image_features + z ; z_logit = z_classifier(z + image_features)
             RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, zproj, H, B, H, 1, s));
             if (sb != s) RC(fork(s, sb, fj[12]));            // the branch continues behind z
             RC(blt_rows_add(dt, zc_in, H, feats, H, zproj, H, B, H, 0, sb));
-            RC(blt_gemm(dt, lin(zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", zlogit, ldV, B), sb));
+            RC(gemm(dt, lin(zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", zlogit, ldV, B), sb));
             RC(blt_rows_add(dt, r_in, H, enc.out, (long)Sa * H, zproj, H, B, H, 0, sb));
         } else {
             RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, nullptr, 0, B, H, 1, s));
@@ -966,12 +987,12 @@ struct bltvqg_engine {
         {
             GemmArgs g = lin(r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", hrec, F, B);
             g.relu = 1;
-            RC(blt_gemm(dt, g, sb));
-            RC(blt_gemm(dt, lin(hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", recon, H, B), sb));
+            RC(gemm(dt, g, sb));
+            RC(gemm(dt, lin(hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", recon, H, B), sb));
         }
         RC(stack_fwd(dec, enc.out, ctx32, s));
         kv_hoisted = false;
-        RC(blt_gemm(dt, lin(dec.out, H, "decoder.output.weight", "decoder.output.bias", logits, ldV, Mt), s));
+        RC(gemm(dt, lin(dec.out, H, "decoder.output.weight", "decoder.output.bias", logits, ldV, Mt), s));
         if (sb != s) RC(fork(sb, s, fj[14]));
         fwd_done = true;
         return BLT_OK;
@@ -999,7 +1020,8 @@ struct bltvqg_engine {
     int decode_body(const float* images, const int64_t* ctx, const float* eps, int* tokens, int* top_idx, float* top_val, hipStream_t s) {
         if (dt == BLT_BF16) RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
-        RC(blt_prep_decode((const long long*)ctx, B, Sa, T, ids_all, pos_all, ctx32, s));
+        if (hipMemsetAsync(stats - 1, 0, sizeof(float), s) != hipSuccess) { blt_set_error("engine_decode_greedy: memset failed"); return BLT_ERR_HIP; }
+        RC(blt_prep_decode((const long long*)ctx, B, Sa, T, ids_all, pos_all, ctx32, V, stats - 1, s));
         int* ys = ids_all + Ma;
         RC(cnn_fwd(images, s));
         int ldw;
@@ -1009,7 +1031,7 @@ struct bltvqg_engine {
             GemmArgs g = mk((char*)emb_rows + (size_t)row0 * Epad * es, Epad, 0, we, ldw, 0, (char*)X_all + (size_t)row0 * H * es, H, rows, H, E);
             g.bias = P("embedding.1.bias");
             g.rowtab = timing; g.rowidx = pos_all + row0; g.ldt = H;
-            return blt_gemm(dt, g, s);
+            return gemm(dt, g, s);
         };
         RC(embed(0, Ma));
         enc.x_in = X_all; enc.key_ids = ctx32;
@@ -1022,14 +1044,14 @@ struct bltvqg_engine {
             RC(blt_copy2d(dt, enc.out, Sa * H, (char*)cat_in + (size_t)H * es, 2 * H, B, H, s));
             RC(mlp3_fwd("latent_layer.mean_logvar_prior", (char*)cat_in + (size_t)H * es, 2 * H, mlvp_h1, mlvp_h2, mlvp, s));
             RC(blt_latent_fwd(dt, mlvp, mlvp, eps_dev, zlat, stats + 6, B, Z, 2 * Z, s));      // reparameterise with the PRIOR; KL slot unused
-            RC(blt_gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
+            RC(gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
         }
         for (int t = 0; t < T; ++t) {
             RC(embed(Ma, Mt));
             RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, phase2 ? zproj : nullptr, H, B, H, 1, s));     // [:,0] += z + image_features
             RC(stack_fwd(dec, enc.out, ctx32, s));
             GemmArgs g = lin((char*)dec.out + (size_t)t * H * es, T * H, "decoder.output.weight", "decoder.output.bias", zlogit, ldV, B);
-            RC(blt_gemm(dt, g, s));
+            RC(gemm(dt, g, s));
             RC(blt_argmax_top6(dt, zlogit, ldV, B, V, t, T, ys, tokens, top_idx, top_val, s));
         }
         return BLT_OK;
@@ -1047,9 +1069,9 @@ struct bltvqg_engine {
         RC(wgrad_later(y.gY, H, y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), M, s));
         GemmArgs g = dgrad(y.gY, H, fp_ + "layers.1.weight", y.gF, F, M);
         g.maskY = y.h; g.ldm = F; g.mask_scale = ks;
-        RC(blt_gemm(dt, g, s));
+        RC(gemm(dt, g, s));
         RC(wgrad_later(y.gF, F, xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), M, s));
-        RC(blt_gemm(dt, dgrad(y.gF, F, fp_ + "layers.0.weight", gB, H, M), s));
+        RC(gemm(dt, dgrad(y.gF, F, fp_ + "layers.0.weight", gB, H, M), s));
         return ln_bwd(gB, xres, ln, m, r, dx_in, dx_out, M, s);
     }
 
@@ -1072,11 +1094,11 @@ struct bltvqg_engine {
                 // encoder-decoder attention
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
                 RC(wgrad_later(cur, H, y.ctx2, H, a2 + "output_linear.weight", nullptr, M, s));
-                RC(blt_gemm(dt, dgrad(cur, H, a2 + "output_linear.weight", gA, H, M), s));
+                RC(gemm(dt, dgrad(cur, H, a2 + "output_linear.weight", gA, H, M), s));
                 RC(attn_bwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, gA, y.gQ, H, y.gKV, (char*)y.gKV + (size_t)H * es, 2 * H, src_ids,
                             S, Sa, 0, sid(st.id, l, 3), s));
                 RC(wgrad_later(y.gQ, H, y.xn2, H, a2 + "query_linear.weight", nullptr, M, s));
-                RC(blt_gemm(dt, dgrad(y.gQ, H, a2 + "query_linear.weight", gC, H, M), s));
+                RC(gemm(dt, dgrad(y.gQ, H, a2 + "query_linear.weight", gC, H, M), s));
                 {   // key/value projections of encoder_outputs: [2H,H] fused
                     const PInfo& pk = tpi(a2 + "key_linear.weight");
                     GemmArgs g = mk(y.gKV, 2 * H, 1, enc_out, H, 1, grad + pk.off, H, 2 * H, H, Ma);
@@ -1084,7 +1106,7 @@ struct bltvqg_engine {
                     RC(wgrad_later(g, s));
                     g = dgrad_rows(y.gKV, 2 * H, a2 + "key_linear.weight", 2 * H, d_enc, H, Ma);
                     g.accumulate = (l == L - 1) ? 0 : 1;
-                    RC(blt_gemm(dt, g, s));
+                    RC(gemm(dt, g, s));
                 }
                 const std::string ln2 = lp + "layer_norm_mha_enc";
                 RC(ln_bwd(gC, y.x1, ln2, y.m2, y.r2, cur, y.dx2, M, s));
@@ -1095,7 +1117,7 @@ struct bltvqg_engine {
             }
             // self attention
             RC(wgrad_later(cur, H, y.ctx, H, a1 + "output_linear.weight", nullptr, M, s));
-            RC(blt_gemm(dt, dgrad(cur, H, a1 + "output_linear.weight", gA, H, M), s));
+            RC(gemm(dt, dgrad(cur, H, a1 + "output_linear.weight", gA, H, M), s));
             RC(attn_bwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, gA, y.gQKV, 3 * H,
                         (char*)y.gQKV + (size_t)H * es, (char*)y.gQKV + (size_t)2 * H * es, 3 * H, st.key_ids, S, S, st.dec ? 1 : 0, sid(st.id, l, 0), s));
             {
@@ -1103,7 +1125,7 @@ struct bltvqg_engine {
                 GemmArgs g = mk(y.gQKV, 3 * H, 1, y.xn1, H, 1, grad + pq.off, H, 3 * H, H, M);
                 g.out_f32 = 1; g.split_k = 32;
                 RC(wgrad_later(g, s));
-                RC(blt_gemm(dt, dgrad_rows(y.gQKV, 3 * H, a1 + "query_linear.weight", 3 * H, gB, H, M), s));
+                RC(gemm(dt, dgrad_rows(y.gQKV, 3 * H, a1 + "query_linear.weight", 3 * H, gB, H, M), s));
             }
             // the last sub-layer of the stack writes d(stack input) back into the caller's buffer (its old content is dead by now:
             // only the top layer's FFN branch read it, on this same stream)
@@ -1126,7 +1148,7 @@ struct bltvqg_engine {
         const PInfo& pw = tpi(fcw);
         GemmArgs g = mk(dfeatpre32, H, 1, pooled, FD, 1, grad + pw.off, FD, H, FD, B);
         g.accumulate = 1; g.a_rowsum = G(fcb);
-        return blt_gemm(BLT_F32, g, s);
+        return gemm(BLT_F32, g, s);
     }
 
     // Everything downstream of the loss-gradient seeds: `logits` holds d(output), dzl holds d(z_logit) (phase 2),
@@ -1147,10 +1169,10 @@ struct bltvqg_engine {
         {
             GemmArgs g = dgrad(d_recon, H, "image_reconstructor.layers.fc1.weight", g_rec1, F, B);
             g.maskY = hrec; g.ldm = F; g.mask_scale = 1.f;
-            RC(blt_gemm(dt, g, sbr));
+            RC(gemm(dt, g, sbr));
         }
         RC(wgrad_later(g_rec1, F, r_in, H, "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias", B, s));
-        RC(blt_gemm(dt, dgrad(g_rec1, F, "image_reconstructor.layers.fc0.weight", g_rin, H, B), sbr));   // d r_in
+        RC(gemm(dt, dgrad(g_rec1, F, "image_reconstructor.layers.fc0.weight", g_rin, H, B), sbr));   // d r_in
         if (phase2) {
             RC(wgrad_later(dzl, ldV, zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", B, s));
             RC(dgrad_bigk(dzl, ldV, "decoder.z_classifier.weight", g_zc, H, B, sbr, acc_big2, (size_t)B * H));
@@ -1177,7 +1199,7 @@ struct bltvqg_engine {
         if (phase2) {
             // ---- latent projection, reparameterisation + KL, prior / posterior nets ----
             RC(wgrad_later(d_zproj, H, zlat, Z, "latent_projection.weight", "latent_projection.bias", B, s));
-            RC(blt_gemm(dt, dgrad(d_zproj, H, "latent_projection.weight", g_b3, Z, B), s));   // dz
+            RC(gemm(dt, dgrad(d_zproj, H, "latent_projection.weight", g_b3, Z, B), s));   // dz
             RC(blt_latent_bwd(dt, mlvp, mlvq, eps_dev, g_b3, kld_g, g_b4, g_mq, B, Z, 2 * Z, s));
             // posterior net: d cat(x_p, x)
             RC(mlp3_bwd("latent_layer.mean_logvar_posterior", 0, cat_in, 2 * H, mlvq_h1, mlvq_h2, g_mq, g_cat, 2 * H, 0, s));
@@ -1231,7 +1253,7 @@ struct bltvqg_engine {
             defer_wgrads = false;
             int ldw;
             const void* w = W("embedding.1.weight", &ldw);
-            RC(blt_gemm(dt, mk(dX_all, H, 0, w, ldw, 1, dE, Epad, Memb, E, H), s));
+            RC(gemm(dt, mk(dX_all, H, 0, w, ldw, 1, dE, Epad, Memb, E, H), s));
             RC(blt_embed_scatter(dt, dE, Epad, ids_all, G("embedding.0.weight"), Memb, E, 0, s));
         }
         if (!use_streams) RC(cnn_head_bwd(s));
@@ -1307,8 +1329,9 @@ struct bltvqg_engine {
         if (hipMemsetAsync(stats + 4, 0, sizeof(float), s) != hipSuccess) return BLT_ERR_HIP;
         // the latent-phase parameters sit right behind the others in the flat buffers: one launch covers both regions when both are live
         RC(blt_sumsq(grad, last_bwd_phase2 ? tsize : n_main, stats + 4, s));
-        ++step_main;
-        if (last_bwd_phase2) ++step_late;
+        const int step_main = ++steps->main;
+        if (last_bwd_phase2) ++steps->late;
+        const int step_late = steps->late;
         if (last_bwd_phase2 && step_late == step_main)      // same bias correction: one launch (only when training began in phase 2)
             return blt_adam_step(train, grad, adam_m, adam_v, tsize, stats + 4, max_norm, lr, b1, b2, eps, step_main, s);
         RC(blt_adam_step(train, grad, adam_m, adam_v, n_main, stats + 4, max_norm, lr, b1, b2, eps, step_main, s));
@@ -1348,7 +1371,7 @@ void bltvqg_engine_destroy(bltvqg_engine* e) {
     for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
     if (e->opt_fork) (void)hipEventDestroy(e->opt_fork);
     if (e->opt_done) (void)hipEventDestroy(e->opt_done);
-    for (size_t i = 0; i < e->prof_a.size(); ++i) { (void)hipEventDestroy(e->prof_a[i]); (void)hipEventDestroy(e->prof_b[i]); }
+    for (size_t i = 0; i < e->prof.size(); ++i) { (void)hipEventDestroy(e->prof[i].a); (void)hipEventDestroy(e->prof[i].b); }
     delete e;
 }
 
@@ -1476,14 +1499,19 @@ int bltvqg_engine_optimizer_step_async(bltvqg_engine* e, float lr, float max_nor
 }
 int bltvqg_engine_adam_steps(const bltvqg_engine* e, int32_t* steps_main_host, int32_t* steps_late_host) {
     BLT_REQUIRE(e && steps_main_host && steps_late_host, "engine_adam_steps: bad args");
-    *steps_main_host = e->step_main;
-    *steps_late_host = e->step_late;
+    *steps_main_host = e->steps->main;
+    *steps_late_host = e->steps->late;
     return BLT_OK;
 }
 int bltvqg_engine_set_adam_steps(bltvqg_engine* e, int32_t steps_main, int32_t steps_late) {
     BLT_REQUIRE(e && steps_main >= 0 && steps_late >= 0, "engine_set_adam_steps: bad args");
-    e->step_main = steps_main;
-    e->step_late = steps_late;
+    e->steps->main = steps_main;
+    e->steps->late = steps_late;
+    return BLT_OK;
+}
+int bltvqg_engine_share_optimizer_state(bltvqg_engine* e, bltvqg_engine* primary) {
+    BLT_REQUIRE(e && primary && e->tsize == primary->tsize, "engine_share_optimizer_state: engines of different models");
+    e->steps = primary->steps;
     return BLT_OK;
 }
 int bltvqg_engine_optimizer_wait(bltvqg_engine* e, void* stream) {
@@ -1505,7 +1533,8 @@ int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
         case 3: return blt_cast_rows(e->dt, e->recon, e->H, BLT_F32, dst, e->H, e->B, e->H, s);
         case 4:
             if (hipMemcpyAsync(dst, e->stats, 8 * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return BLT_ERR_HIP;
-            return hipMemcpyAsync(dst + 5, e->counters, sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? BLT_OK : BLT_ERR_HIP;
+            if (hipMemcpyAsync(dst + 5, e->counters, sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) return BLT_ERR_HIP;
+            return hipMemcpyAsync(dst + 6, e->stats - 1, sizeof(float), hipMemcpyDeviceToDevice, s) == hipSuccess ? BLT_OK : BLT_ERR_HIP;
         case 5: return blt_cast_rows(e->dt, e->enc.out, e->H, BLT_F32, dst, e->H, e->Ma, e->H, s);
         case 6: return blt_cast_rows(e->dt, e->dec.out, e->H, BLT_F32, dst, e->H, e->Mt, e->H, s);
         default:
@@ -1519,27 +1548,33 @@ int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
 
 uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site) { return (uint32_t)(stack * 1000 + layer * 10 + site); }
 
-int bltvqg_engine_profile_enable(bltvqg_engine* e, int on) {
-    BLT_REQUIRE(e, "engine_profile_enable: null engine");
-    e->prof_on = on != 0;       // pause / resume: the recorded launches accumulate until bltvqg_engine_profile_read drains them
+int bltvqg_engine_profile_enable(bltvqg_engine* e, int mask) {
+    BLT_REQUIRE(e && mask >= 0 && mask <= 3, "engine_profile_enable: bad args");
+    e->prof_mask = mask;        // pause / resume: the recorded launches accumulate until bltvqg_engine_profile_read* drains them
     return BLT_OK;
 }
 
-int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host) {
-    BLT_REQUIRE(e && total_ms_host && launches_host && flops_host, "engine_profile_read: bad args");
-    double total = 0.0;
+int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host) {
+    BLT_REQUIRE(e && (cls == 0 || cls == 1) && total_ms_host && launches_host && flops_host, "engine_profile_read: bad args");
+    double total = 0.0, flops = 0.0;
+    int32_t n = 0;
+    size_t keep = 0;
     for (size_t i = 0; i < e->prof_n; ++i) {
-        if (hipEventSynchronize(e->prof_b[i]) != hipSuccess) { blt_set_error("engine_profile_read: event sync failed"); return BLT_ERR_HIP; }
+        bltvqg_engine::ProfRec& r = e->prof[i];
+        if (r.cls != cls) { std::swap(e->prof[keep], e->prof[i]); ++keep; continue; }
+        if (hipEventSynchronize(r.b) != hipSuccess) { blt_set_error("engine_profile_read: event sync failed"); return BLT_ERR_HIP; }
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e->prof_a[i], e->prof_b[i]) != hipSuccess) { blt_set_error("engine_profile_read: elapsed failed"); return BLT_ERR_HIP; }
-        total += ms;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { blt_set_error("engine_profile_read: elapsed failed"); return BLT_ERR_HIP; }
+        total += ms; flops += r.flops; ++n;
     }
+    e->prof_n = keep;      // records of the other class stay queued (the swaps keep every event pair alive in the vector)
     *total_ms_host = total;
-    *launches_host = (int32_t)e->prof_n;
-    *flops_host = e->prof_flops;
-    e->prof_n = 0;
-    e->prof_flops = 0.0;
+    *launches_host = n;
+    *flops_host = flops;
     return BLT_OK;
+}
+int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host) {
+    return bltvqg_engine_profile_read_class(e, 0, total_ms_host, launches_host, flops_host);
 }
 
 int bltvqg_engine_num_buckets(const bltvqg_engine* e) { return e ? 3 : 0; }

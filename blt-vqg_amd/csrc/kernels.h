@@ -162,8 +162,8 @@ int blt_embed_scatter(int dtype, const void* d, int ld, const int* ids, float* d
                       hipStream_t s);
 // builds int32 token streams from the int64 batch tensors (see engine.hip)
 int blt_prep_tokens(const long long* ctx, const long long* post, const long long* tgt, int B, int Sa, int Sp, int T,
-                    int* ids_all, int* pos_all, int* tgt_shift, int* tgt32, int* ctx32, int* post32, float* counters,
-                    hipStream_t s);
+                    int* ids_all, int* pos_all, int* tgt_shift, int* tgt32, int* ctx32, int* post32, float* counters, int V,
+                    float* bad_ids /* += number of ids outside [0, V); they are replaced by <pad> */, hipStream_t s);
 
 // ---- elementwise ---------------------------------------------------------------------------
 // y[b*ystride + j] (+)= a[b*astride + j] (+ c[b*cstride + j]) for j < n  (row-0 injections and their gradients)
@@ -206,7 +206,7 @@ int blt_latent_bwd(int dtype, const void* mlv_p, const void* mlv_q, const float*
                    void* dmlv_p, void* dmlv_q, int B, int Z, int ld, hipStream_t s);
 
 // ---- greedy decoding ----------------------------------------------------------------------------------
-int blt_prep_decode(const long long* ctx, int B, int Sa, int T, int* ids_all, int* pos_all, int* ctx32, hipStream_t s);
+int blt_prep_decode(const long long* ctx, int B, int Sa, int T, int* ids_all, int* pos_all, int* ctx32, int V, float* bad_ids, hipStream_t s);
 int blt_argmax_top6(int dtype, const void* logits, int ld, int B, int V, int t, int T, int* ys, int* tokens, int* top_idx, float* top_val,
                     hipStream_t s);
 int blt_bn_eval_scale(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps, float* scale, float* shift, int C,

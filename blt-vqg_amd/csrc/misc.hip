@@ -25,32 +25,42 @@ inline int ew_grid(long n, int per_block = 256) {
 __global__ void prep_tokens_kernel(const long long* __restrict__ ctx, const long long* __restrict__ post,
                                    const long long* __restrict__ tgt, int B, int Sa, int Sp, int T, int* __restrict__ ids_all,
                                    int* __restrict__ pos_all, int* __restrict__ tgt_shift, int* __restrict__ tgt32,
-                                   int* __restrict__ ctx32, int* __restrict__ post32, float* __restrict__ counters) {
+                                   int* __restrict__ ctx32, int* __restrict__ post32, float* __restrict__ counters, int V,
+                                   float* __restrict__ bad_ids) {
     const int na = B * Sa, np = B * Sp, nt = B * T;
     const int total = na + np + nt;
+    // Every id that reaches the embedding gather / scatter, the attention masks and the cross-entropy kernels passes through here: an
+    // id outside [0, V) (vocabulary / dataset mismatch; the reference raises a device-side index error) is counted in *bad_ids, which
+    // the host surfaces as an error (engine_read item 4), and replaced by <pad> so that nothing indexes out of bounds meanwhile.
+    int nbad = 0;
+    auto chk = [&](long long v) -> int {
+        if (v < 0 || v >= (long long)V) { ++nbad; return 0; }
+        return (int)v;
+    };
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         if (i < na) {
-            const int v = (int)ctx[i];
+            const int v = chk(ctx[i]);
             ids_all[i] = v; ctx32[i] = v; pos_all[i] = i % Sa;
         } else if (i < na + nt) {
             const int j = i - na;
             const int t = j % T;
-            const int v = (t == 0) ? 1 : (int)tgt[j - 1];
+            const int v = (t == 0) ? 1 : chk(tgt[j - 1]);
             ids_all[i] = v; tgt_shift[j] = v; pos_all[i] = t;
-            tgt32[j] = (int)tgt[j];
+            tgt32[j] = chk(tgt[j]);
         } else {
             const int j = i - na - nt;
-            const int v = (int)post[j];
+            const int v = chk(post[j]);
             ids_all[i] = v; post32[j] = v; pos_all[i] = j % Sp;
         }
     }
+    if (nbad && bad_ids) atomicAdd(bad_ids, (float)nbad);
     if (blockIdx.x == 0) {
         // per-sample and total non-pad target counts (exact small integers in fp32; block reduction, deterministic)
         __shared__ float red[16];
         float mine = 0.f;
         for (int b = threadIdx.x; b < B; b += blockDim.x) {
             int c = 0;
-            for (int t = 0; t < T; ++t) c += (tgt[b * T + t] != 0);
+            for (int t = 0; t < T; ++t) { const long long v = tgt[b * T + t]; c += (v > 0 && v < (long long)V); }
             counters[1 + b] = (float)c;
             mine += (float)c;
         }
@@ -488,11 +498,12 @@ __global__ void latent_bwd_kernel(const T* __restrict__ mlvp, const T* __restric
 // greedy decoding helpers (reference models/iq.py:117-152)
 // ---------------------------------------------------------------------------------------------------------------
 __global__ void prep_decode_kernel(const long long* __restrict__ ctx, int B, int Sa, int T, int* __restrict__ ids_all, int* __restrict__ pos_all,
-                                   int* __restrict__ ctx32) {
+                                   int* __restrict__ ctx32, int V, float* __restrict__ bad_ids) {
     const int na = B * Sa, nt = B * T;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < na + nt; i += gridDim.x * blockDim.x) {
         if (i < na) {
-            const int v = (int)ctx[i];
+            int v = (int)ctx[i];
+            if (ctx[i] < 0 || ctx[i] >= (long long)V) { v = 0; if (bad_ids) atomicAdd(bad_ids, 1.f); }      // see prep_tokens_kernel
             ids_all[i] = v; ctx32[i] = v; pos_all[i] = i % Sa;
         } else {
             ids_all[i] = 0;                 // ys starts as <pad> everywhere (iq.py:129)
@@ -618,12 +629,12 @@ __global__ void dropout_mask_kernel(uint64_t seed, uint32_t stream_id, long rows
 #define CHECK_DTYPE(dtype, what) BLT_REQUIRE((dtype) == BLT_F32 || (dtype) == BLT_BF16, what ": bad dtype %d", (int)(dtype))
 
 int blt_prep_tokens(const long long* ctx, const long long* post, const long long* tgt, int B, int Sa, int Sp, int T,
-                    int* ids_all, int* pos_all, int* tgt_shift, int* tgt32, int* ctx32, int* post32, float* counters,
-                    hipStream_t s) {
+                    int* ids_all, int* pos_all, int* tgt_shift, int* tgt32, int* ctx32, int* post32, float* counters, int V,
+                    float* bad_ids, hipStream_t s) {
     BLT_REQUIRE(ctx && post && tgt && ids_all && pos_all && tgt_shift && tgt32 && ctx32 && post32 && counters, "prep_tokens: null pointer");
-    BLT_REQUIRE(B > 0 && Sa > 0 && Sp > 0 && T > 0 && T <= 64, "prep_tokens: bad sizes");
+    BLT_REQUIRE(B > 0 && Sa > 0 && Sp > 0 && T > 0 && T <= 64 && V > 0, "prep_tokens: bad sizes");
     hipLaunchKernelGGL(prep_tokens_kernel, dim3(ew_grid((long)B * (Sa + Sp + T))), dim3(256), 0, s, ctx, post, tgt, B, Sa, Sp, T,
-                       ids_all, pos_all, tgt_shift, tgt32, ctx32, post32, counters);
+                       ids_all, pos_all, tgt_shift, tgt32, ctx32, post32, counters, V, bad_ids);
     return blt_check_launch("prep_tokens");
 }
 
@@ -802,9 +813,9 @@ int blt_latent_bwd(int dtype, const void* mlv_p, const void* mlv_q, const float*
     return blt_check_launch("latent_bwd");
 }
 
-int blt_prep_decode(const long long* ctx, int B, int Sa, int T, int* ids_all, int* pos_all, int* ctx32, hipStream_t s) {
-    BLT_REQUIRE(ctx && ids_all && pos_all && ctx32 && B > 0 && Sa > 0 && T > 0, "prep_decode: bad args");
-    hipLaunchKernelGGL(prep_decode_kernel, dim3(ew_grid((long)B * (Sa + T))), dim3(256), 0, s, ctx, B, Sa, T, ids_all, pos_all, ctx32);
+int blt_prep_decode(const long long* ctx, int B, int Sa, int T, int* ids_all, int* pos_all, int* ctx32, int V, float* bad_ids, hipStream_t s) {
+    BLT_REQUIRE(ctx && ids_all && pos_all && ctx32 && B > 0 && Sa > 0 && T > 0 && V > 0, "prep_decode: bad args");
+    hipLaunchKernelGGL(prep_decode_kernel, dim3(ew_grid((long)B * (Sa + T))), dim3(256), 0, s, ctx, B, Sa, T, ids_all, pos_all, ctx32, V, bad_ids);
     return blt_check_launch("prep_decode");
 }
 

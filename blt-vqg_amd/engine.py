@@ -85,6 +85,9 @@ class StepEngine(object):
             assert share_from.train_size == self.train_size and share_from.frozen_size == self.frozen_size
             self.flat_train, self.flat_grad = share_from.flat_train, share_from.flat_grad
             self.adam_m, self.adam_v, self.flat_frozen = share_from.adam_m, share_from.adam_v, share_from.flat_frozen
+            # ... and the Adam bias-correction counters that belong to those moments (a fresh engine starting at t = 1 against warm
+            # moments would scale its first update by ~0.3)
+            check(self.lib.bltvqg_engine_share_optimizer_state(self.h, share_from.h), "engine_share_optimizer_state")
         else:
             self.flat_train = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
             self.flat_grad = torch.zeros(self.train_size, dtype=torch.float32, device=dev)
@@ -195,18 +198,26 @@ class StepEngine(object):
         check(self.lib.bltvqg_engine_read(self.h, what, ptr(out), stream_ptr()), "engine_read")
         return out
 
-    def stats(self):
-        """dict of python floats (one host sync): rec, img, kld, aux, grad_norm, n_targets."""
+    def stats(self, check_ids=True):
+        """dict of python floats (one host sync): rec, img, kld, aux, grad_norm, n_targets, bad_ids.  Raises when the last forward saw
+        token ids outside [0, vocab_size) (the reference's nn.Embedding raises a device-side index error there)."""
         s = self.read(4).tolist()
-        return dict(rec=s[0], img=s[1], kld=s[2], aux=s[3], grad_norm=s[4] ** 0.5, n_targets=s[5])
+        if check_ids and s[6] > 0:
+            raise _lib.HipError("%d token id(s) outside [0, %d) in the last batch (vocabulary / dataset mismatch?); they were treated as <pad>"
+                                % (int(s[6]), self.cfg.vocab_size))
+        return dict(rec=s[0], img=s[1], kld=s[2], aux=s[3], grad_norm=s[4] ** 0.5, n_targets=s[5], bad_ids=s[6])
 
-    def profile_enable(self, on=True):
-        check(self.lib.bltvqg_engine_profile_enable(self.h, 1 if on else 0), "profile_enable")
+    PROFILE_CONV, PROFILE_GEMM = 1, 2
 
-    def profile_read(self):
-        """(total conv-kernel ms, launches, algorithmic flops) since the last read; synchronises on the recorded events."""
+    def profile_enable(self, mask=1):
+        """mask: PROFILE_CONV | PROFILE_GEMM (True = convolutions only, False / 0 = pause)."""
+        check(self.lib.bltvqg_engine_profile_enable(self.h, int(mask)), "profile_enable")
+
+    def profile_read(self, cls=0):
+        """(total kernel ms, launches, algorithmic flops) of class `cls` (0 = convolutions, 1 = Linear GEMMs) since the last read;
+        synchronises on the recorded events."""
         ms, n, fl = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
-        check(self.lib.bltvqg_engine_profile_read(self.h, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "profile_read")
+        check(self.lib.bltvqg_engine_profile_read_class(self.h, int(cls), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "profile_read")
         return ms.value, n.value, fl.value
 
     def buckets(self):

@@ -56,12 +56,20 @@ class _IQFunction(torch.autograd.Function):
         model._step_seed += 1
         eng.forward(images.contiguous().float(), answers.contiguous(), response.contiguous(), target.contiguous(),
                     None if eps is None else eps.contiguous().float(), phase2, model._base_seed + model._step_seed)
+        # The engine keeps ONE set of saved activations per shape: stamp this forward so that backward can tell whether they are
+        # still its own (a second forward of the same shape, or a second backward, would otherwise silently use the wrong ones)
+        eng.generation = getattr(eng, "generation", 0) + 1
         ctx.eng, ctx.phase2, ctx.names, ctx.was_training = eng, phase2, model._train_names, bool(model.training)
+        ctx.generation = eng.generation
         output = eng.read(0)
         feats, recon = eng.read(2), eng.read(3)
+        stats = eng.read(4)
+        if float(stats[6]) > 0:      # one host sync; the reference's loss code syncs five times per step (train_iq.py:98,103)
+            raise _lib.HipError("%d token id(s) outside [0, %d) in the batch (vocabulary / dataset mismatch?)"
+                                % (int(stats[6]), eng.cfg.vocab_size))
         if phase2:
             z_logit = eng.read(1)
-            kld = eng.read(4)[2].clone()
+            kld = stats[2].clone()
         else:
             z_logit = torch.zeros(0, device=images.device)
             kld = torch.zeros((), device=images.device)
@@ -73,6 +81,11 @@ class _IQFunction(torch.autograd.Function):
         if not ctx.was_training:
             raise RuntimeError("backward through a model.eval() forward is not implemented (BatchNorm backward is the train-mode one); "
                                "call model.train() for training steps")
+        if getattr(eng, "generation", 0) != ctx.generation:
+            raise RuntimeError("IQ backward: the engine's saved activations belong to a later forward of the same batch shape (or were "
+                               "already consumed by a backward); run backward before the next forward, once (retain_graph / double "
+                               "backward are not supported)")
+        eng.generation += 1          # consumed: backward_external overwrites the logits with their gradient
         f = lambda t: None if t is None else t.contiguous().float()   # noqa: E731
         eng.backward_external(f(d_out), f(d_zl) if ctx.phase2 else None, float(d_kld) if (ctx.phase2 and d_kld is not None) else 0.0,
                               f(d_feats), f(d_recon))
@@ -98,6 +111,15 @@ class IQ(nn.Module):
         self.args = args
         if num_att_layers != 2:
             raise ValueError("image_reconstructor is the reference's 2-layer MLP (iq.py:46-48)")
+        # The HIP kernels move activations in 16-byte vectors: every feature width must be a multiple of 8 elements.  The reference
+        # CLI defaults (train_iq.py:315-325: hidden_dim = latent_dim = 300, pwffn_dim = 600) are NOT; say so here instead of failing
+        # inside engine creation (the nearest supported widths are 304 / 304 / 608, or the BASELINE configurations 256 / 512).
+        bad = [(k, getattr(args, k)) for k in ("hidden_dim", "latent_dim", "pwffn_dim") if int(getattr(args, k)) % 8 != 0]
+        if bad or int(args.emb_dim) % 4 != 0 or int(args.hidden_dim) % int(args.num_heads) != 0:
+            raise ValueError("unsupported model widths for the MI355X engine: %s must be multiples of 8, emb_dim (%s) a multiple of 4 and "
+                             "hidden_dim divisible by num_heads (%s); e.g. --hidden_dim 304 --latent_dim 304 --pwffn_dim 608 in place of "
+                             "the reference defaults 300/300/600"
+                             % (", ".join("%s=%s" % kv for kv in bad) or "hidden_dim/latent_dim/pwffn_dim", args.emb_dim, args.num_heads))
         self._dtype = _lib.F32 if getattr(args, "precision", "bf16") in ("fp32", "f32", 32) else _lib.BF16
         self._engines = {}
         self._primary = None

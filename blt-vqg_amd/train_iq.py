@@ -152,7 +152,13 @@ class TrainIQ(_Base):
         else:
             eng = self.model.engine(images, context, posteriors, questions)
         if self._dp is None or self._dp.e is not eng:
-            self._dp = DataParallelStep(eng, dist)
+            # one driver per engine (= per batch shape: the ragged last batch of an epoch has its own); they share the parameter,
+            # gradient and optimiser buffers, so only the first one broadcasts them
+            if not hasattr(self, "_dps"):
+                self._dps = {}
+            if id(eng) not in self._dps:
+                self._dps[id(eng)] = DataParallelStep(eng, dist, broadcast=not self._dps)
+            self._dp = self._dps[id(eng)]
         if getattr(self, "_pending_adam", None) is not None:      # optimiser state of a loaded checkpoint (fused path)
             ad, self._pending_adam = self._pending_adam, None
             eng.adam_m.copy_(ad["m"].to(eng.adam_m.device))
@@ -251,6 +257,8 @@ def build_parser():
     """CLI flags and defaults of the reference (train_iq.py:313-351) + precision."""
     p = argparse.ArgumentParser()
     p.add_argument("--emb_dim", type=int, default=300)
+    # hidden_dim / latent_dim / pwffn_dim: reference defaults; the MI355X engine needs multiples of 8 (IQ.__init__ says so): pass
+    # e.g. 304 / 304 / 608 or the BASELINE widths 256 / 512
     p.add_argument("--hidden_dim", type=int, default=300)
     p.add_argument("--latent_dim", type=int, default=300)
     p.add_argument("--pwffn_dim", type=int, default=600)

@@ -89,9 +89,23 @@ def comm_plan(buckets, phase2):
     return plan
 
 
-def allreduce_bucket(dist, flat_grad, off, n):
-    """Mean of one contiguous gradient bucket across ranks, in place (RCCL has AVG; gloo — used by the CPU tests — only SUM)."""
+def allreduce_bucket(dist, flat_grad, off, n, wire=None):
+    """Mean of one contiguous gradient bucket across ranks, in place (RCCL has AVG; gloo — used by the CPU tests — only SUM).
+    `wire`: optional bf16 staging buffer of at least n elements — the gradients then cross xGMI as bf16 (half the bytes: 164 instead
+    of 329 MB per step on the big configuration), are summed in bf16 by the collective and widened back into the fp32 buffer; the
+    default (None) keeps the exchange in fp32 like Lightning DDP."""
     view = flat_grad[off:off + n]
+    if wire is not None:
+        w = wire[:n]
+        w.copy_(view)
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(w, op=dist.ReduceOp.AVG)
+            view.copy_(w)
+        else:
+            dist.all_reduce(w, op=dist.ReduceOp.SUM)
+            view.copy_(w)
+            view.div_(dist.get_world_size())
+        return
     if dist.get_backend() == "nccl":
         dist.all_reduce(view, op=dist.ReduceOp.AVG)
     else:
@@ -104,43 +118,63 @@ def shard_seed(base_seed, rank):
     return int(base_seed) + int(rank)
 
 
-class DataParallelStep(object):
-    """forward -> fused losses + backward -> (overlapped gradient all-reduce) -> clip + Adam."""
+def rank_dropout_seed(seed, rank):
+    """Dropout seed of one rank: DDP replicas draw independent dropout masks (each process has its own RNG stream), so the rank is
+    mixed into the step seed — rank 0 keeps the caller's seed, which keeps single-GPU runs and their tests unchanged."""
+    return (int(seed) + 0x9E3779B97F4A7C15 * int(rank)) & 0xFFFFFFFFFFFFFFFF
 
-    def __init__(self, engine, dist=None, overlap_optimizer=False):
+
+class DataParallelStep(object):
+    """forward -> fused losses + backward -> (overlapped gradient all-reduce) -> clip + Adam.
+
+    `engine` is a StepEngine (or anything with its surface: device, flat_train / flat_grad / flat_frozen, buckets(), bucket_wait(),
+    forward(), loss_backward(), optimizer_step(), optimizer_wait() — tests/test_dp_gloo.py drives this class with a CPU stand-in over
+    gloo).  On a CPU device there are no streams: the collectives run inline."""
+
+    def __init__(self, engine, dist=None, overlap_optimizer=False, broadcast=True, bf16_wire=False):
         self.e = engine
         self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.cuda = torch.device(engine.device).type == "cuda"
         # clip + Adam (and, behind it, the tail of the gradient all-reduce) overlapped with the next step's frozen CNN
         # (StepEngine.optimizer_step(overlap=True)); call finish() before reading parameters
         self.overlap_optimizer = overlap_optimizer
-        self.comm = torch.cuda.Stream(device=engine.device) if dist is not None else None
+        self.comm = torch.cuda.Stream(device=engine.device) if (dist is not None and self.cuda) else None
         self.buckets = engine.buckets()
-        if dist is not None:
-            # one-time parameter broadcast from rank 0 (DDP does the same at construction)
+        # optional bf16 wire format of the gradient exchange (allreduce_bucket): one staging buffer as large as the largest collective
+        self.wire = None
+        if dist is not None and bf16_wire:
+            self.wire = torch.empty(max(n for _, _, n in comm_plan(self.buckets, True)), dtype=torch.bfloat16, device=engine.flat_grad.device)
+        if dist is not None and broadcast:
+            # one-time parameter broadcast from rank 0 (DDP does the same at construction); engines of other batch shapes share these
+            # buffers and must not repeat it
             dist.broadcast(engine.flat_train, 0)
             dist.broadcast(engine.flat_frozen, 0)
 
+    def _on_comm(self):
+        import contextlib
+        return torch.cuda.stream(self.comm) if self.comm is not None else contextlib.nullcontext()
+
     def reduce_gradients(self, phase2):
         e, dist = self.e, self.dist
-        main = torch.cuda.current_stream(e.device)
         for ids, off, n in comm_plan(self.buckets, phase2):
             for i in ids:
                 e.bucket_wait(i, self.comm)      # the side stream waits for the engine's "bucket i is final" event(s)
-            with torch.cuda.stream(self.comm):
-                allreduce_bucket(dist, e.flat_grad, off, n)
-        if not self.overlap_optimizer:
-            main.wait_stream(self.comm)
+            with self._on_comm():
+                allreduce_bucket(dist, e.flat_grad, off, n, self.wire)
+        if not self.overlap_optimizer and self.comm is not None:
+            torch.cuda.current_stream(e.device).wait_stream(self.comm)
 
     def run(self, images, context, posterior, target, eps, phase2, seed, kl_weight, lr, max_norm=5.0):
         e = self.e
-        e.forward(images, context, posterior, target, eps, phase2, seed)
+        e.forward(images, context, posterior, target, eps, phase2, rank_dropout_seed(seed, self.rank))
         e.loss_backward(kl_weight)
         if self.dist is not None:
             self.reduce_gradients(phase2)
         if self.dist is not None and self.overlap_optimizer:
             # the update is forked from the COMMUNICATION stream (behind the all-reduces); the main stream never waits for them, the
             # next forward's parameter consumers wait for the update
-            with torch.cuda.stream(self.comm):
+            with self._on_comm():
                 e.optimizer_step(lr, max_norm, overlap=True)
         else:
             e.optimizer_step(lr, max_norm, overlap=self.overlap_optimizer)

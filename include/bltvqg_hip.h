@@ -286,18 +286,27 @@ int bltvqg_engine_optimizer_wait(bltvqg_engine* e, void* stream);
 /* Adam step counters (bias correction) of the always-trained and the latent-phase-only parameter regions: checkpoint / resume */
 int bltvqg_engine_adam_steps(const bltvqg_engine* e, int32_t* steps_main_host, int32_t* steps_late_host);
 int bltvqg_engine_set_adam_steps(bltvqg_engine* e, int32_t steps_main, int32_t steps_late);
+/* Engines of ONE model with different batch shapes share the parameter / gradient / Adam-moment buffers (bind the same pointers);
+ * this call makes `e` share `primary`'s Adam step counters as well, so that a step taken by either engine (the ragged last batch
+ * of an epoch, utils/data_loader.py: no drop_last) advances the one bias correction that belongs to those moments. */
+int bltvqg_engine_share_optimizer_state(bltvqg_engine* e, bltvqg_engine* primary);
 /* outputs, converted to contiguous fp32: what = 0 output [B,T,V], 1 z_logit [B,V], 2 image_features [B,H],
- * 3 reconstructed [B,H], 4 stats float[8] = {loss_rec, loss_img, kld, loss_aux, grad_norm_sq, n_targets, 0, 0},
+ * 3 reconstructed [B,H], 4 stats float[8] = {loss_rec, loss_img, kld, loss_aux, grad_norm_sq, n_targets, bad_token_ids, 0}
+ * (bad_token_ids = number of input token ids outside [0, vocab_size) in the last forward: they were replaced by <pad>; the host
+ * mirror raises on a non-zero count, as the reference's embedding lookup raises a device-side index error),
  * 5 encoder_outputs [B,S_a,H], 6 decoder_outputs [B,T,H] */
 int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream);
 uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site);
-/* In-stream timing of the dominant kernel (the implicit-GEMM convolution launches of the frozen ResNet-18 stack): while enabled,
- * every conv launch is bracketed by a hipEvent pair on the caller's stream.  profile_read synchronises on those events and
- * returns the summed kernel time, the number of launches and their ALGORITHMIC flops (2*M*Cout*KH*KW*Cin, unpadded) since
- * the last read.  enable(0) only pauses recording (an event record costs the stream a ~6 us bubble, so callers sample a
- * subset of their steps); the recorded launches accumulate until profile_read drains them. */
-int bltvqg_engine_profile_enable(bltvqg_engine* e, int on);
+/* In-stream timing of the two dominant kernel families: while enabled, every launch of the family is bracketed by a hipEvent pair
+ * on the stream it is launched on.  mask bit 0: the convolution launches of the frozen ResNet-18 stack (class 0, ALGORITHMIC flops
+ * 2*M*Cout*KH*KW*Cin, unpadded); bit 1: every Linear-layer GEMM of the transformer stacks, embedding, vocabulary projection and
+ * latent nets - forward, input gradient and weight gradient (class 1, flops 2*M*N*K).  profile_read_class synchronises on the
+ * class's events and returns the summed kernel time, the number of launches and their flops since the last read.  enable(0) only
+ * pauses recording (an event record costs the stream a ~6 us bubble, so callers sample a subset of their steps); the recorded
+ * launches accumulate until they are read.  profile_read = profile_read_class(0). */
+int bltvqg_engine_profile_enable(bltvqg_engine* e, int mask);
 int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host);
+int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host);
 /* gradient buckets for data-parallel overlap: contiguous float ranges of the flat gradient buffer in the order backward
  * completes them; bltvqg_engine_bucket_wait makes `stream` wait until bucket i of the last backward is complete. */
 int bltvqg_engine_num_buckets(const bltvqg_engine* e);

@@ -57,3 +57,54 @@ def test_argument_validation_without_gpu():
                       len_context=5, len_posterior=21, len_target=20, image_h=64, image_w=64, dtype=0)
     import ctypes
     assert not lib.bltvqg_engine_create(ctypes.byref(cfg))     # hidden_dim % 8 != 0 is rejected
+
+
+def test_host_paths_under_address_sanitizer():
+    """`make asan` (csrc/Makefile): the C-ABI shim, the error path and the engine's host logic (parameter layout, workspace carve, bucket
+    table) built with AddressSanitizer + UBSan, exercised WITHOUT a GPU: argument validation of the operator entry points, engine
+    descriptors of every BASELINE configuration created / queried / destroyed.  (GPU ASan is not available on this pool.)"""
+    import subprocess
+    import sys
+    csrc = os.path.join(ROOT, "blt-vqg_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "asan", "-j8"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    lib = os.path.join(ROOT, "blt-vqg_amd", "libbltvqg_hip_asan.so")
+    assert os.path.exists(lib)
+    rt = subprocess.check_output(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"], text=True).strip()
+    assert os.path.exists(rt), rt
+    code = r'''
+import ctypes, sys
+sys.path.insert(0, %r)
+import bltvqg_amd
+from bltvqg_amd import _lib
+from bltvqg_amd.engine import StepEngine, make_config
+lib = _lib.load()
+assert lib.bltvqg_version() >= 100
+assert lib.bltvqg_layernorm_fwd(0, None, None, None, None, None, None, 4, 12, 1e-5, None) < 0
+assert lib.bltvqg_gemm(7, None, 0, 0, None, 0, 0, None, 0, 1, 1, 1, None, 0, 0.0, 0, 0, None, 0, 1.0, None, 0, 0, 0, 0, 0, None) < 0
+assert lib.bltvqg_engine_forward(None, None, None, None, None, None, 0, 0, None) < 0
+assert b"null engine" in lib.bltvqg_last_error_string()
+assert lib.bltvqg_engine_profile_enable(None, 1) < 0 and lib.bltvqg_engine_share_optimizer_state(None, None) < 0
+bad = _lib.Config(batch=4, hidden_dim=60, pwffn_dim=128, latent_dim=64, emb_dim=20, num_layers=1, num_heads=4, vocab_size=97,
+                  len_context=5, len_posterior=21, len_target=20, image_h=64, image_w=64, dtype=0)
+assert not lib.bltvqg_engine_create(ctypes.byref(bad))
+for kw in (dict(batch=128, hidden_dim=256, pwffn_dim=512, latent_dim=256, num_layers=2, num_heads=4),
+           dict(batch=256, hidden_dim=512, pwffn_dim=2048, latent_dim=512, num_layers=6, num_heads=8),
+           dict(batch=64, hidden_dim=512, pwffn_dim=2048, latent_dim=512, num_layers=6, num_heads=8, num_regions=36, region_dim=2048)):
+    for dtype in (0, 1):
+        e = StepEngine(make_config(emb_dim=300, vocab_size=8000, dtype=dtype, **kw), "cpu")
+        assert e.train_size > 0 and e.workspace_bytes > 0 and len(e.buckets()) == 3
+        assert sum(n for _, n, _ in e.buckets()) == e.train_size
+        assert e.adam_steps() == (0, 0)
+        e2 = StepEngine(make_config(emb_dim=300, vocab_size=8000, dtype=dtype, **dict(kw, batch=kw["batch"] - 1)), "cpu")
+        _lib.check(lib.bltvqg_engine_share_optimizer_state(e2.h, e.h), "share")
+        e.set_adam_steps(3, 1)
+        assert e2.adam_steps() == (3, 1)
+        del e                                   # the shared counters outlive the primary engine
+        assert e2.adam_steps() == (3, 1)
+        del e2
+print("asan-host-ok")
+''' % ROOT
+    env = dict(os.environ, LD_PRELOAD=rt, BLTVQG_LIB=lib, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0 and "asan-host-ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+    assert "AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]

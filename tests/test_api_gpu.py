@@ -252,3 +252,35 @@ def test_eval_mode_forward_and_validation_step(phase2):
     t.train()
     t(b)[0].sum().backward()                                       # and train mode still works on the same model
     assert t.model.get_parameter("decoder.output.weight").grad is not None
+
+
+def test_backward_refuses_stale_activations():
+    """the engine keeps one set of saved activations per batch shape; a second forward of the same shape before backward (or a
+    second backward) must raise instead of silently differentiating the wrong forward."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    z, cfg, state, batch = load_golden("tiny")
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")
+    b = {k: v.cuda() for k, v in batch.items()}
+    out1, _, _, _ = t(b)
+    out2, _, _, _ = t(b)                       # same shape: the engine now holds the activations of THIS forward
+    with pytest.raises(RuntimeError, match="later forward"):
+        out1.sum().backward()
+    out2.sum().backward()                      # the latest forward differentiates fine ...
+    out3, _, _, _ = t(b)
+    out3.sum().backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="already consumed|later forward"):
+        out3.sum().backward()                  # ... once
+
+
+def test_iq_forward_reports_out_of_range_ids():
+    from bltvqg_amd import _lib
+    from train_iq import SyntheticVocabulary, TrainIQ
+    z, cfg, state, batch = load_golden("tiny")
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg)).to("cuda")
+    b = {k: v.cuda() for k, v in batch.items()}
+    b["questions"] = b["questions"].clone()
+    b["questions"][0, 2] = cfg.vocab_size + 3
+    with pytest.raises(_lib.HipError, match="token id"):
+        t(b)

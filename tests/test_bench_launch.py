@@ -1,0 +1,32 @@
+"""bench.py --gpus N started WITHOUT a launcher must start N ranks itself (the reference gets data parallelism from one flag,
+pl.Trainer(gpus=N), train_iq.py:372-373).  CPU rehearsal of that launch path: parent -> torch.distributed.run -> N ranks over gloo
+-> rank 0's JSON line relayed on the parent's stdout."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gpus_flag_spawns_that_many_ranks():
+    env = dict(os.environ, BLT_BENCH_REHEARSE_LAUNCH="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, out.stdout          # stdout carries exactly one line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2
+
+
+def test_parent_of_a_spawn_never_imports_the_hip_library():
+    """The parent process must not initialise the GPU before it starts the ranks: the spawn branch runs before torch / the HIP
+    library are imported."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    head = src[:src.index("def main():")]
+    assert "import torch" not in head.replace("    import torch", "")      # only function-local imports above main()
+    body = src[src.index("def main():"):]
+    assert body.index("spawn_ranks(a)") < body.index("import torch")

@@ -1,0 +1,99 @@
+"""Two RCCL ranks driving the REAL engine (skipped on boxes with fewer than 2 GPUs; tests/test_dp_gloo.py covers the same
+DataParallelStep logic on CPU with a stand-in engine): different shards per rank -> the all-reduced flat gradient equals the mean of the
+two single-rank gradients, the phase-1 step leaves the phase-2-only bucket untouched, and the overlapped optimiser schedule (clip +
+Adam forked from the communication stream) gives the synchronous result.  Reference: pl.Trainer(gpus=N) = Lightning DDP,
+train_iq.py:372-373."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    sys.path.insert(0, os.path.join(root, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    import bltvqg_amd.synthetic as synthetic
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import DataParallelStep, init_reference_style, shard_seed
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        B, V, Z = 8, 97, 64
+        cfg = make_config(B, 64, 128, Z, 20, 2, 4, V, image_hw=(64, 64), dtype=0, attention_dropout=0.0, relu_dropout=0.0)
+        finals = {}
+        for overlap in (False, True):
+            e = StepEngine(cfg, dev)
+            e.allocate()
+            init_reference_style(e, seed=5 + rank)              # ranks start apart: the broadcast must equalise them
+            dp = DataParallelStep(e, dist, overlap_optimizer=overlap)
+            for stepi, phase2 in enumerate((False, True, True)):
+                b = synthetic.make_batch(B, V, Z, seed=shard_seed(100 + stepi, rank), image_hw=64)
+                d = {k: v.to(dev) for k, v in b.items()}
+                # single-rank gradient of this shard (same engine, no exchange)
+                e.optimizer_wait()
+                e.forward(d["images"], d["answers"], d["posteriors"], d["questions"], d["eps"] if phase2 else None, phase2, 7)
+                e.loss_backward(0.25)
+                torch.cuda.synchronize()
+                mine = e.flat_grad.clone()
+                both = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(both, mine)
+                want = sum(both) / world
+                # BatchNorm running statistics were advanced by the probe forward: the step below repeats the forward, which is fine for
+                # the gradient (train-mode statistics come from the batch)
+                e.forward(d["images"], d["answers"], d["posteriors"], d["questions"], d["eps"] if phase2 else None, phase2, 7)
+                e.loss_backward(0.25)
+                dp.reduce_gradients(phase2)
+                torch.cuda.current_stream().wait_stream(dp.comm)
+                torch.cuda.synchronize()
+                got = e.flat_grad
+                lo = e.late_offset
+                hi = e.train_size if phase2 else lo
+                err = float((got[:hi] - want[:hi]).abs().max()) / max(float(want[:hi].abs().max()), 1e-12)
+                assert err < 1e-5, (stepi, err)
+                if not phase2:
+                    assert float(got[lo:].abs().max()) == 0.0
+                if overlap:
+                    with torch.cuda.stream(dp.comm):
+                        e.optimizer_step(1e-3, 5.0, overlap=True)
+                else:
+                    e.optimizer_step(1e-3, 5.0)
+            dp.finish()
+            torch.cuda.synchronize()
+            chk = [torch.zeros_like(e.flat_train) for _ in range(world)]
+            dist.all_gather(chk, e.flat_train)
+            assert torch.equal(chk[0], chk[1])                   # replicas stay identical
+            finals[overlap] = e.flat_train.clone()
+        d = float((finals[False] - finals[True]).abs().max())
+        assert d <= 2.5 * 3e-3, d                                 # Adam turns rounding-level gradient noise into +-lr moves
+        out[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (the 1-GPU test boxes skip it; tests/test_dp_gloo.py covers the logic on CPU)")
+def test_two_rank_engine_gradients_are_the_mean_of_the_single_rank_gradients():
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: "ok", 1: "ok"}

@@ -84,3 +84,126 @@ def test_bucketed_gradient_mean_world_size_2():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: "ok", 1: "ok"}
+
+
+class _StubEngine(object):
+    """CPU stand-in with the StepEngine surface DataParallelStep uses: the 'gradient' is a deterministic function of the rank's batch,
+    the 'optimiser' is plain SGD with norm clipping, and every call is logged so that the ORDER of the step can be checked."""
+
+    def __init__(self, buckets, n, late_offset):
+        self.device = torch.device("cpu")
+        self._buckets, self.late_offset = buckets, late_offset
+        self.flat_train = torch.zeros(n)
+        self.flat_frozen = torch.zeros(8)
+        self.flat_grad = torch.zeros(n)
+        self.log = []
+        self.seeds = []
+
+    def buckets(self):
+        return self._buckets
+
+    def bucket_wait(self, i, stream):
+        assert stream is None                      # CPU: no communication stream
+        self.log.append(("wait", i))
+
+    def forward(self, images, context, posterior, target, eps, phase2, seed):
+        self.log.append(("forward", bool(phase2)))
+        self.seeds.append(seed)
+        self._x, self._phase2 = float(images.sum()), bool(phase2)
+
+    def loss_backward(self, kl_weight):
+        self.log.append(("backward",))
+        n = self.flat_grad.numel()
+        self.flat_grad.zero_()
+        hi = n if self._phase2 else self.late_offset          # phase 1: the latent-phase parameters receive no gradient (SURVEY 3.4)
+        self.flat_grad[:hi] = self._x * (1.0 + torch.arange(hi, dtype=torch.float32) / n) + self.flat_train[:hi]
+
+    def optimizer_step(self, lr, max_norm, overlap=False):
+        self.log.append(("opt", bool(overlap), self.flat_grad.clone()))
+        g = self.flat_grad
+        scale = min(1.0, max_norm / (float(g.norm()) + 1e-6))
+        self.flat_train -= lr * scale * g
+
+    def optimizer_wait(self):
+        self.log.append(("opt_wait",))
+
+
+def _dp_worker(rank, world, port, out):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bltvqg_amd  # noqa: F401
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import DataParallelStep, rank_dropout_seed
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg = make_config(4, 64, 128, 64, 20, 1, 4, 97, image_hw=(64, 64), dtype=0)
+        real = StepEngine(cfg, "cpu")                        # the real engine's bucket layout (host-side descriptor only)
+        buckets, n, lo = real.buckets(), real.train_size, real.late_offset
+        finals = {}
+        for overlap in (False, True):
+            e = _StubEngine(buckets, n, lo)
+            e.flat_train += float(rank)                       # ranks start apart: the constructor's broadcast must make them equal
+            dp = DataParallelStep(e, dist, overlap_optimizer=overlap)
+            assert float(e.flat_train.abs().max()) == 0.0     # rank 0's parameters everywhere
+            singles = []                                      # what each rank's gradient would be on its own
+            for stepi, phase2 in enumerate((False, True, True)):
+                x = torch.full((2, 2), float(10 * rank + stepi + 1))
+                before = e.flat_train.clone()
+                dp.run(x, None, None, None, None, phase2, seed=500 + stepi, kl_weight=0.5, lr=0.1, max_norm=1e9)
+                # the gradient the optimiser saw = mean over ranks of the single-rank gradients (DDP semantics)
+                hi = n if phase2 else lo
+                mine = torch.zeros(n)
+                mine[:hi] = float(x.sum()) * (1.0 + torch.arange(hi, dtype=torch.float32) / n) + before[:hi]
+                both = [torch.zeros(n) for _ in range(world)]
+                dist.all_gather(both, mine)
+                want = sum(both) / world
+                seen = [r for r in e.log if r[0] == "opt"][-1][2]
+                assert torch.allclose(seen, want, rtol=1e-6, atol=1e-6), (stepi, float((seen - want).abs().max()))
+                if not phase2:
+                    assert float(seen[lo:].abs().max()) == 0.0          # the phase-2-only bucket is neither produced nor exchanged
+                singles.append(want)
+                # order inside one step: forward, backward, [wait bucket 0], [wait the rest], optimiser
+                names = [r[0] if r[0] != "wait" else "wait%d" % r[1] for r in e.log[-(5 + (1 if phase2 else 0)):]]
+                assert names == ["forward", "backward", "wait0", "wait1"] + (["wait2"] if phase2 else []) + ["opt"], names
+                assert [r for r in e.log if r[0] == "opt"][-1][1] == overlap
+            dp.finish()
+            assert e.log[-1] == ("opt_wait",)
+            # replicas draw different dropout masks (the rank is mixed into the seed), rank 0 keeps the caller's seed
+            assert e.seeds == [rank_dropout_seed(500 + i, rank) for i in range(3)]
+            if rank == 0:
+                assert e.seeds == [500, 501, 502]
+            # parameters stay identical across ranks after the steps
+            chk = [torch.zeros(n) for _ in range(world)]
+            dist.all_gather(chk, e.flat_train)
+            assert torch.equal(chk[0], chk[1])
+            finals[overlap] = e.flat_train.clone()
+        assert torch.equal(finals[False], finals[True])       # the overlapped optimiser schedule gives the synchronous result
+        # bf16 wire format: same mean up to bf16 rounding of the exchanged values
+        e = _StubEngine(buckets, n, lo)
+        dp = DataParallelStep(e, dist, bf16_wire=True)
+        dp.run(torch.full((2, 2), float(rank + 1)), None, None, None, None, True, seed=1, kl_weight=0.5, lr=0.0, max_norm=1e9)
+        seen = [r for r in e.log if r[0] == "opt"][-1][2]
+        want = (4.0 * 1.5) * (1.0 + torch.arange(n, dtype=torch.float32) / n)
+        assert torch.allclose(seen, want, rtol=2e-2), float((seen - want).abs().max())
+        # a second engine of the same model (ragged last batch) must not broadcast again
+        e2 = _StubEngine(buckets, n, lo)
+        e2.flat_train += float(rank + 1)
+        DataParallelStep(e2, dist, broadcast=False)
+        assert float(e2.flat_train[0]) == float(rank + 1)
+        out[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks_gloo():
+    """DataParallelStep itself (the class bench.py and TrainIQ.fused_training_step drive) over two gloo ranks with a CPU stand-in
+    engine: averaged gradient = mean of the single-rank gradients, bucket waits precede their collectives in plan order, phase 1 skips
+    the late bucket, overlapped = synchronous optimiser, per-rank dropout seeds, optional bf16 wire format."""
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
+    assert dict(out) == {0: "ok", 1: "ok"}

@@ -332,3 +332,65 @@ def test_full_size_properties_batch_permutation_and_gradient_linearity():
     torch.cuda.synchronize()
     assert float(g1.abs().max()) > 0
     assert rel_err(g2.cpu(), 2.0 * g1.cpu()) < 1e-4
+
+
+def test_ragged_last_batch_shares_the_adam_step_counters():
+    """engines of different batch shapes share parameters AND Adam moments (allocate(share_from=...)); the bias-correction
+    counters belong to those moments.  3 full steps on a B-sized engine + 1 step on a smaller one (the ragged last batch of an epoch:
+    the reference DataLoader has no drop_last, utils/data_loader.py:178-206) must follow the oracle's single torch.optim.Adam."""
+    from oracle import iq_oracle as O
+    import bltvqg_amd.synthetic as synthetic
+    z, cfg, state, batch0 = load_golden("tiny")
+    B, hw = int(z["meta_cfg"][7]), int(z["meta_cfg"][8])
+    sizes = [B, B, B, B - 1]
+    batches = [synthetic.make_batch(n, cfg.vocab_size, cfg.latent_dim, seed=900 + i, image_hw=hw) for i, n in enumerate(sizes)]
+    hp = O.default_hp(num_pretraining_steps=0)
+    final, logs = O.train_steps(state, cfg, batches, hp, start_iter=50)
+    full = _engine(cfg, B, hw, 0)
+    full.load_state(state)
+    from bltvqg_amd.engine import StepEngine, make_config
+    c = make_config(B - 1, cfg.hidden_dim, cfg.pwffn_dim, cfg.latent_dim, cfg.emb_dim, cfg.num_layers, cfg.num_heads, cfg.vocab_size,
+                    image_hw=(hw, hw), dtype=0, attention_dropout=0.0, relu_dropout=0.0)
+    ragged = StepEngine(c)
+    ragged.allocate(share_from=full)
+    lr_sum = 0.0
+    for i, b in enumerate(batches):
+        e = full if sizes[i] == B else ragged
+        _run(e, b, True, O.kl_weight(i, hp.full_kl_step))
+        lr = O.noam_lr(50 + i, cfg.hidden_dim)
+        lr_sum += lr
+        e.optimizer_step(lr, 5.0)
+        assert full.adam_steps() == ragged.adam_steps() == (i + 1, i + 1)
+    for n in full.train_info:
+        got, want, init = full.view(n, 0).cpu(), final[n], state[n]
+        assert (got - want).abs().max() <= 2.5 * lr_sum + 1e-7, n
+        if want.ndim == 2 and want.numel() > 1000 and float((want - init).abs().max()) > 0:
+            # a fresh counter on the ragged engine would scale its update by ~0.3 at t = 1: far outside this bound
+            assert rel_err(got - init, want - init) < 0.2, (n, rel_err(got - init, want - init))
+
+
+def test_out_of_range_token_ids_are_reported_not_dereferenced():
+    """an id outside [0, V) must not index the embedding table / logits / gradient buffers; it is counted, treated as <pad>
+    and surfaced as an error on the host (the reference raises a device-side index error)."""
+    from bltvqg_amd import _lib
+    z, cfg, state, batch = load_golden("tiny")
+    B, hw = int(z["meta_cfg"][7]), int(z["meta_cfg"][8])
+    e = _engine(cfg, B, hw, 0)
+    e.load_state(state)
+    bad = {k: v.clone() for k, v in batch.items()}
+    bad["questions"][1, 3] = cfg.vocab_size            # one past the end
+    bad["answers"][0, 2] = -7
+    bad["posteriors"][2, 5] = 10 ** 9
+    d = {k: v.cuda() for k, v in bad.items()}
+    e.forward(d["images"], d["answers"], d["posteriors"], d["questions"], d["eps"], True, 0)
+    e.loss_backward(0.5)
+    torch.cuda.synchronize()
+    with pytest.raises(_lib.HipError, match="token id"):
+        e.stats()
+    st = e.stats(check_ids=False)
+    assert st["bad_ids"] == 4.0                         # questions[1,3] is seen twice: as the shifted decoder input and as a target
+    assert all(torch.isfinite(torch.tensor(st[k])) for k in ("rec", "img", "kld", "aux"))
+    assert torch.isfinite(e.flat_grad).all()
+    # the next clean batch clears the flag
+    _run(e, batch, True, 0.5)
+    assert e.stats()["bad_ids"] == 0.0

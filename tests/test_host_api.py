@@ -122,3 +122,17 @@ def test_phase_switch_and_counters():
     t._phase_switch()
     assert t.latent_transformer is True and t.model.latent_transformer is True
     assert t.custom_optimizer(4000) == pytest.approx(O.noam_lr(4000, 64))
+
+
+def test_reference_default_widths_fail_with_a_clear_message():
+    """the reference CLI defaults (hidden_dim = latent_dim = 300, pwffn_dim = 600, train_iq.py:315-325) are not multiples of
+    8; the drop-in says so at construction (with the nearest supported widths) instead of failing inside engine creation."""
+    from train_iq import SyntheticVocabulary, TrainIQ, build_parser
+    args = build_parser().parse_args(["--synthetic"])
+    args.device, args.root_dir, args.emb_file = "cpu", ".", None
+    with pytest.raises(ValueError, match="multiples of 8.*304"):
+        TrainIQ(SyntheticVocabulary(97), args)
+    ok = build_parser().parse_args(["--synthetic", "--hidden_dim", "304", "--latent_dim", "304", "--pwffn_dim", "608", "--num_layers", "1"])
+    ok.device, ok.root_dir, ok.emb_file = "cpu", ".", None
+    t = TrainIQ(SyntheticVocabulary(97), ok)
+    assert t.model.get_parameter("latent_projection.weight").shape == (304, 304)

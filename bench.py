@@ -292,6 +292,7 @@ def main():
         eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
         cur = d
         if h2d:
+            h2d_setup()
             slot = i % 2
             upload(slot ^ 1)                                   # next step's batch crosses PCIe underneath this step
             torch.cuda.current_stream().wait_event(h2d_state["ready"][slot])

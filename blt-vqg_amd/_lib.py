@@ -39,6 +39,9 @@ SIGNATURES = {
     "bltvqg_last_error_string": (S, []),
     "bltvqg_debug_set": (None, [I, I]),
     "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
+    "bltvqg_gemm_ex": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, F, U64, U32, P, I, F, P, I, P, I, I, I, I, P]),
+    "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
+    "bltvqg_gemm_repeat": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P]),
     "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "bltvqg_layernorm_linear": (I, [P, I, P, P, F, P, P, P, P, I, P, I, F, U64, U32, P, I, P, I, I, I, I, P]),
     "bltvqg_linear_layernorm": (I, [P, I, P, I, P, I, F, U64, U32, P, I, P, I, P, I, P, P, F, P, P, P, I, I, I, P]),
@@ -96,6 +99,7 @@ SIGNATURES = {
     "bltvqg_engine_workspace_bytes": (L, [P]),
     "bltvqg_engine_bind": (I, [P, P, P, P, P, P, P, L]),
     "bltvqg_engine_invalidate_frozen": (None, [P]),
+    "bltvqg_engine_trust_shadows": (I, [P, I]),
     "bltvqg_engine_forward": (I, [P, P, P, P, P, P, I, U64, P]),
     "bltvqg_engine_decode_greedy": (I, [P, P, P, P, I, I, P, P, P, P]),
     "bltvqg_engine_set_bn_train": (I, [P, I]),

@@ -1,4 +1,5 @@
 // extern "C" operator-level entry points (see include/bltvqg_hip.h): thin argument marshalling over kernels.h.
+#include <vector>
 #include "kernels.h"
 #include "../../include/bltvqg_hip.h"
 
@@ -16,6 +17,57 @@ int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, in
     g.bias = bias; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id; g.maskY = maskY; g.ldm = ldm;
     g.mask_scale = mask_scale; g.R = R; g.ldr = ldr; g.accumulate = accumulate; g.out_f32 = out_f32; g.force_tile = force_tile; g.split_k = split_k;
     return blt_gemm(dtype, g, (hipStream_t)stream);
+}
+
+int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const float* rowtab,
+                   const int32_t* rowidx, int ldt, int relu, float drop_p, uint64_t seed, uint32_t stream_id, const void* maskY, int ldm, float mask_scale,
+                   void* C2, int ldc2, const void* R, int ldr, int accumulate, int tile_m, int tile_n, void* stream) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.rowtab = rowtab; g.rowidx = rowidx; g.ldt = ldt; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id;
+    g.maskY = maskY; g.ldm = ldm; g.mask_scale = mask_scale; g.C2 = C2; g.ldc2 = ldc2; g.R = R; g.ldr = ldr; g.accumulate = accumulate;
+    if (tile_m < 0) { g.no_dma = 0; g.force_tile = 64; return blt_gemm(BLT_BF16, g, (hipStream_t)stream); }      // round-1 kernel (64x64 ring)
+    BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g), "gemm_ex: operands do not fit the planned-tile kernel (bf16 NT, lda/ldb %% 8 == 0, M >= 256)");
+    BLT_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
+                "gemm_ex: bad operands");
+    return blt_gemm_nt2(g, (hipStream_t)stream, tile_m, tile_n);
+}
+
+int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, const void* const* X, const int32_t* ldx, float* const* dW,
+                              const int32_t* ldw, float* const* dbias, const int32_t* rows, const int32_t* N, const int32_t* K, void* table_dev,
+                              int64_t table_bytes, void* stream) {
+    BLT_REQUIRE(n > 0 && n < 250 && dY && ldy && X && ldx && dW && ldw && dbias && rows && N && K && table_dev, "linear_wgrad_group: bad args");
+    std::vector<GemmArgs> gs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        GemmArgs& g = gs[i];
+        g.A = dY[i]; g.lda = ldy[i]; g.transA = 1; g.B = X[i]; g.ldb = ldx[i]; g.transB = 1; g.C = dW[i]; g.ldc = ldw[i];
+        g.M = N[i]; g.N = K[i]; g.K = rows[i]; g.out_f32 = 1; g.a_rowsum = dbias[i];
+        BLT_REQUIRE(g.A && g.B && g.C && g.M > 0 && g.N > 0 && g.K > 0 && g.ldc >= g.N, "linear_wgrad_group: bad problem %d", i);
+        BLT_REQUIRE(blt_wgrad_group_ok(BLT_BF16, g), "linear_wgrad_group: problem %d does not fit the grouped kernel (bf16, ld %% 8 == 0, 16-byte aligned)", i);
+    }
+    std::vector<blt_wg_problem> probs;
+    std::vector<int> wg0;
+    const int nwg = blt_wgrad_group_plan(gs, probs, wg0);
+    const size_t pb = probs.size() * sizeof(blt_wg_problem), pb_al = (pb + 63) / 64 * 64;
+    BLT_REQUIRE((int64_t)(pb_al + wg0.size() * 4) <= table_bytes, "linear_wgrad_group: table_dev too small (%lld bytes needed)", (long long)(pb_al + wg0.size() * 4));
+    // synchronous copies: the host vectors die at return
+    if (hipMemcpy(table_dev, probs.data(), pb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy((char*)table_dev + pb_al, wg0.data(), wg0.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        blt_set_error("linear_wgrad_group: table upload failed");
+        return BLT_ERR_HIP;
+    }
+    return blt_wgrad_group_launch((const blt_wg_problem*)table_dev, (const int*)((char*)table_dev + pb_al), n, nwg, (hipStream_t)stream);
+}
+
+int bltvqg_gemm_repeat(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu,
+                       const void* R, int ldr, int reps, void* stream) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.bias = bias; g.relu = relu; g.R = R; g.ldr = ldr;
+    for (int i = 0; i < reps; ++i) {
+        const int rc = blt_gemm(dtype, g, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return BLT_OK;
 }
 
 int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* dbias, int rows, int N, int K,

@@ -85,12 +85,19 @@ struct bltvqg_engine {
     float *train = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr, *frozen = nullptr;
     char* ws = nullptr;
     bool bound = false, frozen_dirty = true, fwd_done = false;
+    // The optimiser pass writes the plain bf16 weight shadow itself (misc.hip::adam_kernel); the next forward then only derives the
+    // transposed copy from it.  That shortcut is valid only if nobody else wrote the fp32 parameters in between: the CALLER says so
+    // (bltvqg_engine_trust_shadows: the fused step driver does, the autograd module whose parameters a torch optimiser updates does
+    // not), and `shadow_gen` must equal the shared params_gen, which every optimiser step of ANY engine sharing these parameters and
+    // every bltvqg_engine_invalidate_frozen (load_state) bumps.
+    bool trust_shadows = false;
+    long shadow_gen = -1;
     int phase2 = 0;
     uint64_t seed = 0;
     // Adam bias-correction counters of the always-trained / latent-phase-only regions.  They belong to the OPTIMISER STATE (the
     // moment buffers), not to an engine: engines of different batch shapes that share one set of parameter / moment buffers (the
     // ragged last batch of an epoch) share one counter object too (bltvqg_engine_share_optimizer_state).
-    struct AdamSteps { int main = 0, late = 0; };
+    struct AdamSteps { int main = 0, late = 0; long params_gen = 0; };      // params_gen: bumped by every write to the shared parameters
     std::shared_ptr<AdamSteps> steps = std::make_shared<AdamSteps>();
     int last_bwd_phase2 = 0;
     // workspace buffers
@@ -127,6 +134,19 @@ struct bltvqg_engine {
     void *g_rin, *g_zc;                              // d(reconstructor input), d(z_classifier input): produced on the branch stream
     float* acc_big2;                                 // split-K accumulator of the z_classifier dgrad (branch stream)
     hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+    // the 330 MB gradient memset leaves the critical path: forward() issues it on a side stream (behind the previous optimiser update,
+    // the last reader of the gradients) and backward only waits for its event
+    hipEvent_t grad_zero_ev = nullptr;
+    bool grads_zeroed = false;
+    int zero_grads_early(hipStream_t side_s) {
+        if (!grad_zero_ev) return BLT_OK;
+        if (hipMemsetAsync(grad, 0, sizeof(float) * (size_t)tsize, side_s) != hipSuccess || hipEventRecord(grad_zero_ev, side_s) != hipSuccess) {
+            blt_set_error("engine_forward: early gradient memset failed");
+            return BLT_ERR_HIP;
+        }
+        grads_zeroed = true;
+        return BLT_OK;
+    }
     // side streams: independent sub-graphs (CNN | posterior encoder | context encoder) run concurrently so that their small
     // launches (40-160 workgroups each) fill the 256 CUs together; fork/join with events (capturable into a hipGraph)
     // Only TWO side streams: HIP multiplexes streams onto 4 hardware queues by default, and a stream that shares a queue with the main
@@ -450,6 +470,7 @@ struct bltvqg_engine {
         ln_pool_floats = ((size_t)(2 * L + 1) * (blt_layernorm_bwd_grid(Ma, H) + blt_layernorm_bwd_grid(Mp, H)) +
                           (size_t)(3 * L + 1) * blt_layernorm_bwd_grid(Mt, H)) * 2 * H;
         ln_pool = AF((int64_t)ln_pool_floats);
+        wg_pool = (char*)A((int64_t)WG_SLOTS * WG_SLOT_BYTES);
         return off;
     }
 
@@ -544,11 +565,45 @@ struct bltvqg_engine {
         if (bias) g.a_rowsum = G(bias);
         return wgrad_later(g, s);
     }
-    // issue the collected weight-gradient GEMMs on `to`, ordered after everything enqueued on `from` so far
+    // issue the collected weight-gradient GEMMs on `to`, ordered after everything enqueued on `from` so far.  bf16: ONE grouped launch
+    // (gemm2.hip::wgrad_group_kernel) over a device-side problem table; the table of a flush point is the same every step (static
+    // workspace pointers), so it is uploaded once and only re-uploaded when its content changes (phase switch).
+    struct WgTable { std::vector<blt_wg_problem> probs; std::vector<int> wg0; int nwg = 0; bool valid = false; };
+    std::vector<WgTable> wg_tables;
+    int flush_idx = 0;
+    char* wg_pool = nullptr;
+    static constexpr int WG_SLOTS = 24, WG_SLOT_BYTES = 16384;
     int flush_wgrads(hipStream_t from, hipStream_t to, hipEvent_t ev) {
         if (pending_wgrads.empty() && pending_ln.empty()) return BLT_OK;
         int rc = fork(from, to, ev);
-        for (size_t i = 0; i < pending_wgrads.size() && !rc; ++i) rc = gemm(dt, pending_wgrads[i], to);
+        bool grouped = dt == BLT_BF16 && !pending_wgrads.empty() && blt_debug_get(11) != 1 && flush_idx < WG_SLOTS && wg_pool != nullptr &&
+                       pending_wgrads.size() * sizeof(blt_wg_problem) + (pending_wgrads.size() + 1) * 4 + 64 <= (size_t)WG_SLOT_BYTES;
+        for (size_t i = 0; i < pending_wgrads.size() && grouped; ++i) grouped = blt_wgrad_group_ok(dt, pending_wgrads[i]);
+        if (grouped && !rc) {
+            if ((int)wg_tables.size() <= flush_idx) wg_tables.resize(flush_idx + 1);
+            WgTable& t = wg_tables[flush_idx];
+            std::vector<blt_wg_problem> probs;
+            std::vector<int> wg0;
+            const int nwg = blt_wgrad_group_plan(pending_wgrads, probs, wg0);
+            char* dev = wg_pool + (size_t)flush_idx * WG_SLOT_BYTES;
+            const size_t pb = probs.size() * sizeof(blt_wg_problem), pb_al = (pb + 63) / 64 * 64;
+            if (!t.valid || t.nwg != nwg || t.probs.size() != probs.size() || memcmp(t.probs.data(), probs.data(), pb) != 0) {
+                t.probs = probs; t.wg0 = wg0; t.nwg = nwg; t.valid = true;
+                if (hipMemcpyAsync(dev, t.probs.data(), pb, hipMemcpyHostToDevice, to) != hipSuccess ||
+                    hipMemcpyAsync(dev + pb_al, t.wg0.data(), t.wg0.size() * 4, hipMemcpyHostToDevice, to) != hipSuccess) {
+                    blt_set_error("flush_wgrads: table upload failed");
+                    return BLT_ERR_HIP;
+                }
+            }
+            double fl = 0.0;
+            for (const GemmArgs& g : pending_wgrads) fl += 2.0 * (double)g.M * (double)g.N * (double)g.K;
+            const int pi = (prof_mask & 2) ? prof_begin(1, to) : -1;
+            rc = blt_wgrad_group_launch((const blt_wg_problem*)dev, (const int*)(dev + pb_al), (int)t.probs.size(), nwg, to);
+            prof_end(pi, to, fl);
+            ++flush_idx;
+        } else {
+            for (size_t i = 0; i < pending_wgrads.size() && !rc; ++i) rc = gemm(dt, pending_wgrads[i], to);
+        }
         pending_wgrads.clear();
         for (size_t i = 0; i < pending_ln.size() && !rc; i += BLT_LN_RED_MAX) {
             LnRedArgs a;
@@ -901,6 +956,7 @@ struct bltvqg_engine {
             RC(fork(s, s0, fj[0]));
             RC(cnn_fwd(images, s));
             RC(sync_opt(s0));
+            if (bn_train) RC(zero_grads_early(s0));
             RC(forward_tokens(ctx, post, tgt, s0, s0));
             RC(fork(s0, side[1], fj[1]));
             RC(stack_fwd(enc, nullptr, nullptr, side[1]));
@@ -913,6 +969,7 @@ struct bltvqg_engine {
         // weight shadows
         hipStream_t s0 = use_streams ? side[0] : s, s1 = use_streams ? side[1] : s;
         RC(forward_tokens(ctx, post, tgt, s, s0));
+        if (use_streams && bn_train) RC(zero_grads_early(s0));      // s0 was forked from s (behind any earlier optimiser update) in forward_tokens
         // three independent sub-graphs until the image feature is injected: CNN (main) | embedding + posterior encoder (side 0) |
         // context encoder (side 1)
         if (use_streams) RC(fork(s0, s1, fj[1]));
@@ -931,7 +988,13 @@ struct bltvqg_engine {
     // unless they are the same stream)
     int forward_tokens(const int64_t* ctx, const int64_t* post, const int64_t* tgt, hipStream_t s, hipStream_t se) {
         // bf16 shadows of every GEMM weight (plain + transposed) in one launch; biases / LayerNorm / embedding rows are read in fp32
-        if (dt == BLT_BF16 && !tlist.empty()) RC(blt_shadow_transpose(train, wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
+        if (dt == BLT_BF16 && !tlist.empty()) {
+            if (trust_shadows && shadow_gen == steps->params_gen) RC(blt_shadow_transpose_bf16(wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
+            else {
+                RC(blt_shadow_transpose(train, wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
+                shadow_gen = steps->params_gen;        // the plain shadow mirrors the parameters as of now
+            }
+        }
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
                            tgt32, ctx32, post32, counters, V, stats - 1, s));
@@ -1157,6 +1220,7 @@ struct bltvqg_engine {
         pending_wgrads.clear();
         pending_ln.clear();
         ln_pool_used = 0;
+        flush_idx = 0;
         defer_wgrads = false;
         // every weight gradient from here on is collected and issued on a side stream at the next flush point (their operands live
         // in buffers that nothing overwrites during this backward pass); only the input-gradient chain stays on `s`
@@ -1267,6 +1331,11 @@ struct bltvqg_engine {
         return BLT_OK;
     }
     int zero_grads(hipStream_t s) {
+        if (grads_zeroed) {          // done by forward() on a side stream: every gradient writer of this backward is forked from `s` later
+            grads_zeroed = false;
+            if (hipStreamWaitEvent(s, grad_zero_ev, 0) != hipSuccess) { blt_set_error("backward: grad memset wait failed"); return BLT_ERR_HIP; }
+            return BLT_OK;
+        }
         if (hipMemsetAsync(grad, 0, sizeof(float) * (size_t)tsize, s) != hipSuccess) { blt_set_error("backward: grad memset failed"); return BLT_ERR_HIP; }
         return BLT_OK;
     }
@@ -1332,12 +1401,18 @@ struct bltvqg_engine {
         const int step_main = ++steps->main;
         if (last_bwd_phase2) ++steps->late;
         const int step_late = steps->late;
+        // bf16 mode: the update also writes the plain weight shadow (same offsets as the flat buffer)
+        char* sh = (dt == BLT_BF16) ? (char*)wshadow : nullptr;
+        // a phase-1 step does not touch the latent-phase region: its shadow stays as valid as it was before this step
+        const bool was_valid = shadow_gen == steps->params_gen;
+        ++steps->params_gen;
+        shadow_gen = (sh && (last_bwd_phase2 || was_valid)) ? steps->params_gen : -1;
         if (last_bwd_phase2 && step_late == step_main)      // same bias correction: one launch (only when training began in phase 2)
-            return blt_adam_step(train, grad, adam_m, adam_v, tsize, stats + 4, max_norm, lr, b1, b2, eps, step_main, s);
-        RC(blt_adam_step(train, grad, adam_m, adam_v, n_main, stats + 4, max_norm, lr, b1, b2, eps, step_main, s));
+            return blt_adam_step(train, grad, adam_m, adam_v, tsize, stats + 4, max_norm, lr, b1, b2, eps, step_main, s, sh);
+        RC(blt_adam_step(train, grad, adam_m, adam_v, n_main, stats + 4, max_norm, lr, b1, b2, eps, step_main, s, sh));
         if (last_bwd_phase2)
             RC(blt_adam_step(train + late_off, grad + late_off, adam_m + late_off, adam_v + late_off, n_late, stats + 4, max_norm, lr, b1, b2,
-                             eps, step_late, s));
+                             eps, step_late, s, sh ? sh + (size_t)late_off * 2 : nullptr));
         return BLT_OK;
     }
 #undef RC
@@ -1367,6 +1442,7 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
 void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (!e) return;
     for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
+    if (e->grad_zero_ev) (void)hipEventDestroy(e->grad_zero_ev);
     for (int i = 0; i < 16; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
     for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
     if (e->opt_fork) (void)hipEventDestroy(e->opt_fork);
@@ -1426,6 +1502,10 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
             return BLT_ERR_HIP;
         }
     }
+    if (!e->grad_zero_ev && hipEventCreateWithFlags(&e->grad_zero_ev, hipEventDisableTiming) != hipSuccess) {
+        blt_set_error("engine_bind: event creation failed");
+        return BLT_ERR_HIP;
+    }
     for (int i = 0; i < 3; ++i)
         if (!e->bucket_ev[i] && hipEventCreateWithFlags(&e->bucket_ev[i], hipEventDisableTiming) != hipSuccess) {
             blt_set_error("engine_bind: event creation failed");
@@ -1451,7 +1531,16 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
     return BLT_OK;
 }
 
-void bltvqg_engine_invalidate_frozen(bltvqg_engine* e) { if (e) e->frozen_dirty = true; }
+void bltvqg_engine_invalidate_frozen(bltvqg_engine* e) {
+    if (!e) return;
+    e->frozen_dirty = true;
+    ++e->steps->params_gen;        // parameters were (re)written from outside: every engine sharing them rebuilds its weight shadows
+}
+int bltvqg_engine_trust_shadows(bltvqg_engine* e, int on) {
+    BLT_REQUIRE(e, "engine_trust_shadows: null engine");
+    e->trust_shadows = on != 0;
+    return BLT_OK;
+}
 
 int bltvqg_engine_forward(bltvqg_engine* e, const float* images, const int64_t* context, const int64_t* posterior, const int64_t* target,
                           const float* eps, int phase2, uint64_t seed, void* stream) {

@@ -1125,9 +1125,10 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 
 // process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode,
 // [3] = ring depth of the DMA kernels (0 = by grid size; 128x128: 1 = always 4 stages, 2 = always 2; 64x64: 3 = always 5, 4 = always 3)
-static int g_debug[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-void blt_debug_set(int key, int value) { if (key >= 0 && key < 8) g_debug[key] = value; }
-int blt_debug_get(int key) { return (key >= 0 && key < 8) ? g_debug[key] : 0; }
+// [8] = 1: round-1 kernels for the Linear GEMMs instead of gemm2.hip's planned-tile kernel (A/B); [9] / [10] = force its BM / BN
+static int g_debug[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+void blt_debug_set(int key, int value) { if (key >= 0 && key < 16) g_debug[key] = value; }
+int blt_debug_get(int key) { return (key >= 0 && key < 16) ? g_debug[key] : 0; }
 
 struct Choice { int bm, bn, no_dma; };
 static std::unordered_map<uint64_t, Choice> g_tuned;     // filled by autotune mode: measured best kernel per GEMM descriptor
@@ -1284,6 +1285,8 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
                     ((uintptr_t)a.ln_gamma % 16) == 0 && ((uintptr_t)a.ln_beta % 16) == 0 && ((uintptr_t)a.ln_out % 16) == 0, "gemm: fused LayerNorm operands must be 16-byte aligned");
         return launch_dma_ln(a, stream);
     }
+    if (!g_debug[8] && !a.force_tile && !a.no_dma && blt_gemm_nt2_ok(dtype, a))
+        return blt_gemm_nt2(a, stream, g_debug[9], g_debug[10]);
     const int splits = blt_gemm_splits(a, dtype);
     if (g_debug[2] && splits == 1 && !a.accumulate && !a.force_tile && g_tuned.find(tune_key(a, dtype)) == g_tuned.end()) {
         int rc = autotune(dtype, a, stream);

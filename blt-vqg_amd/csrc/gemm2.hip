@@ -1,0 +1,598 @@
+// Second-generation bf16 GEMMs for the transformer half of the step, built around what bounds these shapes on MI355X.
+//
+// The Linear layers of the stacks are [5120 | 5376 | 1280 rows] x [512 .. 2048] x [K = 512 .. 2048] problems: 2.7 - 10.7 GFLOP, i.e.
+// 1 - 4 us at the MFMA peak.  What bounds them is not the matrix pipe but what one CU can take in from L2 into LDS (~70 GB/s per CU
+// through the LDS-DMA path, MI355X_MICROARCH "ring-gemm"): a 128x128 tile needs 32 KB per 64-deep K-step for 2.1 MFLOP, so its CU is
+// intake-bound at <= 45 % of its MFMA rate, and a grid of 640 such tiles is 1.25 rounds of 512 resident workgroups.  Round 1's
+// kernels (gemm.hip) lost another 2-3x to that quantisation, to one K-tile in flight per workgroup and to a serial epilogue.  Here:
+//
+//   * gemm_nt2_kernel<BM, BN, ...>: C = epilogue(A[M,K] B[N,K]^T), both operands k-contiguous (Linear forward; input gradients through
+//     the transposed weight shadow).  ONE workgroup of 8 waves per CU, and the tile shape is chosen PER PROBLEM so that the grid is
+//     one round of <= 256 workgroups with the smallest (BM + BN) per flop (5120 x 2048 -> 160 x 256 tiles, 5120 x 512 -> 160 x 64,
+//     5376 x 1536 -> 192 x 192, ...: blt_gemm_nt2_plan).  LDS-DMA ring of 3-4 stages with two or three K-steps (>= 80 KB) in flight,
+//     counted vmcnt + one raw barrier per K-step; the epilogue's residual / mask rows are fetched BEFORE the K loop ends, the result
+//     goes through LDS in 16-row slabs and leaves as 16-byte stores.
+//   * wgrad_group_kernel: dW[N,K] = dY[M,N]^T X[M,K] for MANY Linear layers in one launch (a device-side problem table): the
+//     weight gradients of a whole stack are ~1500 tiles of 128x128 with an M = 5120-deep contraction each — six full rounds of the
+//     chip — where round 1 launched them one by one as 32-64 workgroups with split-K float atomics (16 MB of atomics per 512x512
+//     gradient).  Token-major operands are DMA'd as they are and read with ds_read_b64_tr_b16; no split-K unless a launch is short
+//     of tiles, results are stored (not added), bias gradients come from one extra MFMA against a ones fragment.
+//
+// Replaces torch.nn.Linear forward / backward call sites of the reference hot path (models/transformer_layers.py:453-456,489-491,530,
+// 400-408; models/iq.py:39,72-78; models/decoder_transformer.py:19-20,40).
+#include <vector>
+#include "kernels.h"
+
+namespace {
+
+__device__ __attribute__((aligned(16))) uint4 g2_zero_page[1];
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt2() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void dma16b(const void* gsrc, char* lds_dst_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ s16x4 lds_tr16b(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+typedef __attribute__((ext_vector_type(8))) short s16x8b;
+
+// ---------------------------------------------------------------------------------------------------------------
+// NT GEMM
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int cmin(int a, int b) { return a < b ? a : b; }
+template <int BM_, int BN_, int NWM_, int NWN_>
+struct Nt2 {
+    static constexpr int BM = BM_, BN = BN_, NWM = NWM_, NWN = NWN_;
+    static constexpr int NW = NWM * NWN, NT = NW * 64, BK = 64;
+    static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
+    static_assert(BM % (16 * NWM) == 0 && BN % (16 * NWN) == 0 && BM % 8 == 0 && BN % 8 == 0, "tile / wave layout mismatch");
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    // DMA wave-instructions per wave per stage: instruction j of wave w covers the 64 chunks (j * NW + w) * 64 ..; a wave whose 64
+    // chunks lie beyond the tile still issues (vmcnt stays uniform) — from the zero page into its 1 KB slot of the dump area
+    static constexpr int CH_A = (BM * 8 + NT - 1) / NT, CH_B = (BN * 8 + NT - 1) / NT, PER_STAGE = CH_A + CH_B;
+    static constexpr int DUMP = 1024;          // ONE slot for every wave's beyond-the-tile DMA (zeros over zeros)
+    // ring depth: as many stages as LDS holds (<= 8), so that NST - 1 K-steps (>= ~96 KB for the big tiles) are in flight per CU;
+    // (AHEAD - 1) * PER_STAGE must fit the 6-bit vmcnt
+    static constexpr int NST = cmin(cmin(8, (160 * 1024 - DUMP) / STAGE), 63 / PER_STAGE + 2);
+    static constexpr int RING = NST * STAGE;
+    static constexpr int AHEAD = NST - 1;
+    static_assert(NST >= 2 && (AHEAD - 1) * PER_STAGE <= 63, "vmcnt is a 6-bit counter");
+    // epilogue: the result leaves in TM passes of one 16-row block per wave row: slab = NWM*16 rows x BN fp32, double-buffered
+    static constexpr int SLAB_ROWS = NWM * 16, CS = BN + 4, SLAB_BYTES = SLAB_ROWS * CS * 4;
+    // a thread owns ONE group of 8 columns (tid % GPR; bias is loaded once) and every RPS-th slab row from tid / GPR on: IPP rows per pass
+    static constexpr int GPR = BN / 8, RPS = NT / GPR, IPP = (SLAB_ROWS + RPS - 1) / RPS;
+    static constexpr int LDS = (RING + DUMP > 2 * SLAB_BYTES) ? RING + DUMP : 2 * SLAB_BYTES;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+};
+
+template <typename C>
+__global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NW = C::NW, NT = C::NT, TM = C::TM, TN = C::TN, CS = C::CS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::NWN, wn = wave % C::NWN;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    // consecutive workgroups walk down a column of tiles: they share the B (weight) panel, and A panels are re-read tiles_n times from L2
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tile_n = blockIdx.x / tiles_m, tile_m = blockIdx.x % tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bf16* __restrict__ Ag = (const bf16*)p.A;
+    const bf16* __restrict__ Bg = (const bf16*)p.B;
+    const void* zero = (const void*)g2_zero_page;
+    char* dump = smem + C::RING;
+
+    long a_off[C::CH_A], b_off[C::CH_B];
+    int a_gk[C::CH_A], b_gk[C::CH_B];
+    bool a_in[C::CH_A], b_in[C::CH_B];
+#pragma unroll
+    for (int j = 0; j < C::CH_A; ++j) {
+        const int c = (j * NW + wave) * 64 + lane;
+        const int row = c >> 3, gc = (c & 7) ^ (row & 7);
+        a_in[j] = (j * NW + wave) * 64 < BM * 8;                  // wave-uniform
+        a_gk[j] = gc * 8;
+        a_off[j] = (a_in[j] && m0 + row < p.M) ? (long)(m0 + row) * p.lda + gc * 8 : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < C::CH_B; ++j) {
+        const int c = (j * NW + wave) * 64 + lane;
+        const int row = c >> 3, gc = (c & 7) ^ (row & 7);
+        b_in[j] = (j * NW + wave) * 64 < BN * 8;
+        b_gk[j] = gc * 8;
+        b_off[j] = (b_in[j] && n0 + row < p.N) ? (long)(n0 + row) * p.ldb + gc * 8 : -1;
+    }
+    // DMA wave-instruction d (0 .. PER_STAGE-1: the A ones first) of K-step kt into ring stage `stage`; K-steps beyond the last one
+    // are still "issued" — every lane from the zero page — so that the vmcnt arithmetic of the loop is the same in every iteration
+    auto issue_one = [&](int d, int kt, int stage) {
+        char* a_st = smem + stage * C::STAGE;
+        char* b_st = a_st + C::A_BYTES;
+        const int k0 = kt * BK;
+        if (d < C::CH_A) {
+            const int j = d;
+            const bool ok = (a_off[j] >= 0) && (k0 + a_gk[j] < p.K);
+            dma16b(ok ? (const void*)(Ag + a_off[j] + k0) : zero, a_in[j] ? a_st + (j * NW + wave) * 1024 : dump);
+        } else {
+            const int j = d - C::CH_A;
+            const bool ok = (b_off[j] >= 0) && (k0 + b_gk[j] < p.K);
+            dma16b(ok ? (const void*)(Bg + b_off[j] + k0) : zero, b_in[j] ? b_st + (j * NW + wave) * 1024 : dump);
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int l15 = lane & 15, lg = lane >> 4;
+    const int nk = (p.K + BK - 1) / BK;
+    constexpr int AHEAD = C::AHEAD, PS = C::PER_STAGE;
+
+    // ---- epilogue operands that do not depend on the result (bias, residual rows, ReLU/dropout-backward mask rows) are fetched
+    // before the K loop: item (pass pp, q) of this thread is slab row sr = tid / GPR + q * RPS (wave row sr / 16, row sr % 16 of its
+    // pass-pp block) of its column group cg = tid % GPR ----
+    constexpr int GPR = C::GPR, IPP = C::IPP, RPS = C::RPS;
+    const int cg = tid % GPR, sr0 = tid / GPR;
+    const int n = n0 + cg * 8;
+    const bool t_on = sr0 < RPS && n < p.N;              // threads beyond RPS * GPR (BN = 192) and beyond the N tail sit the epilogue out
+    const int nv = (p.N - n < 8) ? (p.N - n) : 8;
+    uint4 rP[TM][IPP];                                   // residual rows, or (no residual) the mask rows; if both, the mask rows are read late
+    const bool pre_ok = (p.ldr % 8 == 0) && (p.ldm % 8 == 0);
+    const bool fast = t_on && (nv == 8) && pre_ok && (p.ldc % 8 == 0) && (!p.C2 || p.ldc2 % 8 == 0) && (!p.rowtab || p.ldt % 4 == 0) &&
+                      (!p.bias || (((uintptr_t)(p.bias + n)) & 15) == 0);
+    float bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bias[e] = 0.f;
+    if (p.bias && t_on) {
+        if (fast) Vec8<float>::load(p.bias + n, bias);
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (e < nv) bias[e] = p.bias[n + e];
+        }
+    }
+    if (fast) {
+#pragma unroll
+        for (int pp = 0; pp < TM; ++pp)
+#pragma unroll
+            for (int q = 0; q < IPP; ++q) {
+                const int sr = sr0 + q * RPS;
+                const int m = m0 + (sr >> 4) * C::WM + pp * 16 + (sr & 15);
+                const bool ok = sr < C::SLAB_ROWS && m < p.M;
+                if (p.R && ok) rP[pp][q] = *reinterpret_cast<const uint4*>((const bf16*)p.R + (size_t)m * p.ldr + n);
+                else if (p.maskY && ok) rP[pp][q] = *reinterpret_cast<const uint4*>((const bf16*)p.maskY + (size_t)m * p.ldm + n);
+            }
+    }
+
+    // (the operand fetches above are the OLDEST entries of the in-order vmcnt queue: the counted waits below cover them)
+#pragma unroll
+    for (int t = 0; t < AHEAD; ++t)
+#pragma unroll
+        for (int d = 0; d < PS; ++d) issue_one(d, t, t);
+
+    int st_cur = 0, st_nxt = AHEAD % C::NST;
+    for (int kt = 0; kt < nk; ++kt) {
+        // AHEAD - 1 K-steps are issued beyond kt (null ones past the end): this wave's part of K-step kt has landed
+        wait_vmcnt2<(AHEAD - 1) * PS>();
+        __builtin_amdgcn_s_barrier();                          // every wave's part of K-step kt landed; stage (kt + AHEAD) % NST is free
+        const char* a_st = smem + st_cur * C::STAGE;
+        const char* b_st = a_st + C::A_BYTES;
+        // K-step kt + AHEAD is issued BETWEEN the MFMA groups of K-step kt (one DMA wave-instruction costs its wave ~100 issue cycles;
+        // in front of the MFMAs they would be 0.3 us of every K-step during which the matrix pipe idles): 2 * TM slots per K-step
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int r = wn * C::WN + j * 16 + l15;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(b_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+            bf16x8 a_cur, a_nxt;
+            {
+                const int r = wm * C::WM + l15;
+                a_cur = *reinterpret_cast<const bf16x8*>(a_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (i + 1 < TM) {      // the next A fragment is in flight while this one's MFMAs run
+                    const int r = wm * C::WM + (i + 1) * 16 + l15;
+                    a_nxt = *reinterpret_cast<const bf16x8*>(a_st + r * 128 + (((ks * 4 + lg) ^ (r & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, bfr[j], acc[i][j], 0, 0, 0);
+                constexpr int SLOTS = 2 * TM;
+                const int slot = ks * TM + i;
+#pragma unroll
+                for (int d = 0; d < PS; ++d)
+                    if (d * SLOTS / PS == slot) issue_one(d, kt + AHEAD, st_nxt);
+                a_cur = a_nxt;
+            }
+        }
+        st_cur = (st_cur + 1 == C::NST) ? 0 : st_cur + 1;
+        st_nxt = (st_nxt + 1 == C::NST) ? 0 : st_nxt + 1;
+    }
+    __syncthreads();          // all MFMA reads of the ring are done (and every DMA has landed) before the slabs overwrite it
+
+    // ---- epilogue: same term order as gemm.hip::gemm_epilogue ----
+    const uint32_t thresh = dropout_threshold(p.drop_p);
+    const float keep_scale = (p.drop_p > 0.f) ? 1.f / (1.f - p.drop_p) : 1.f;
+    const int drop_ld = (p.N + 7) & ~7;
+#pragma unroll
+    for (int pp = 0; pp < TM; ++pp) {
+        float* Cs = reinterpret_cast<float*>(smem + (pp & 1) * C::SLAB_BYTES);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[(wm * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[pp][j][r];
+        __syncthreads();      // slab pp complete; slab pp-1's readers are behind this barrier too, so pp+1 may overwrite it next pass
+        if (!t_on) continue;
+#pragma unroll
+        for (int q = 0; q < IPP; ++q) {
+            const int sr = sr0 + q * RPS;
+            const int m = m0 + (sr >> 4) * C::WM + pp * 16 + (sr & 15);
+            if (sr >= C::SLAB_ROWS || m >= p.M) continue;
+            float v[8], t[8];
+            {
+                const float4 x0 = *reinterpret_cast<const float4*>(&Cs[sr * CS + cg * 8]);
+                const float4 x1 = *reinterpret_cast<const float4*>(&Cs[sr * CS + cg * 8 + 4]);
+                v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+            if (p.rowtab) {
+                const float* tr = p.rowtab + (size_t)p.rowidx[m] * p.ldt + n;
+                if (fast) {
+                    Vec8<float>::load(tr, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += t[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (e < nv) v[e] += tr[e];
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.drop_p > 0.f) {
+                uint32_t w[4];
+                dropout_words(p.seed, p.stream_id, ((uint64_t)m * (uint64_t)drop_ld + (uint64_t)n) >> 3, w);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (dropout_lane(w, e) >= thresh) ? v[e] * keep_scale : 0.f;
+            }
+            if (p.maskY) {
+                if (fast) {
+                    uint4 mraw = rP[pp][q];
+                    if (p.R) mraw = *reinterpret_cast<const uint4*>((const bf16*)p.maskY + (size_t)m * p.ldm + n);
+                    const bf16x8 mv = __builtin_bit_cast(bf16x8, mraw);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((float)mv[e] != 0.f) ? v[e] * p.mask_scale : 0.f;
+                } else {
+                    const bf16* mp = (const bf16*)p.maskY + (size_t)m * p.ldm + n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (e < nv) v[e] = ((float)mp[e] != 0.f) ? v[e] * p.mask_scale : 0.f;
+                }
+            }
+            if (p.C2) {
+                if (fast) Vec8<bf16>::store((bf16*)p.C2 + (size_t)m * p.ldc2 + n, v);
+                else {
+                    bf16* cp = (bf16*)p.C2 + (size_t)m * p.ldc2 + n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = (bf16)v[e];
+                }
+            }
+            if (p.R) {
+                if (fast) {
+                    const bf16x8 rv = __builtin_bit_cast(bf16x8, rP[pp][q]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)rv[e];
+                } else {
+                    const bf16* rp = (const bf16*)p.R + (size_t)m * p.ldr + n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (e < nv) v[e] += (float)rp[e];
+                }
+            }
+            bf16* cp = (bf16*)p.C + (size_t)m * p.ldc + n;
+            if (fast) {
+                if (p.accumulate) {
+                    Vec8<bf16>::load(cp, t);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += t[e];
+                }
+                Vec8<bf16>::store(cp, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = (bf16)(p.accumulate ? (float)cp[e] + v[e] : v[e]);
+            }
+        }
+    }
+}
+
+template <typename C>
+int launch_nt2(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    auto kern = gemm_nt2_kernel<C>;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
+            blt_set_error("gemm_nt2: hipFuncSetAttribute(%d) failed", C::LDS);
+            return BLT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    const long tiles = (long)cdiv(a.M, C::BM) * cdiv(a.N, C::BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(C::NT), C::LDS, s, a);
+    return blt_check_launch("gemm_nt2");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Grouped weight gradients: dW_p[Nw, Kw] = dY_p[Mtok, Nw]^T X_p[Mtok, Kw] (+ db_p[Nw] = column sums of dY_p) for a table of problems.
+// 128 x 128 output tiles, 64 tokens per K-step, 8 waves as 2 x 4 (wave tile 64 x 32).  Both operands are token-major, i.e. the
+// contraction index is the ROW index in memory: the tiles are DMA'd as they are ([64 tokens][128 columns] bf16 = 256-byte rows, the
+// 16-byte chunks of a row XOR-swizzled by f(row) on the SOURCE side) and the MFMA operands come out of LDS through
+// ds_read_b64_tr_b16 (cdna_hip_programming.md T10, image (b): conflict-free for the 16x16x32 operand).
+// ---------------------------------------------------------------------------------------------------------------
+struct WgCfg {
+    static constexpr int BM = 128, BN = 128, BK = 64, NW = 8, NT = 512, NWN = 4;
+    static constexpr int WM = 64, WN = 32, TM = 4, TN = 2;
+    static constexpr int A_BYTES = BK * 256, B_BYTES = BK * 256, STAGE = A_BYTES + B_BYTES;      // 32 KB
+    static constexpr int CH = 2, PER_STAGE = 4;          // DMA wave-instructions per wave per stage: 2 for A, 2 for B
+    static constexpr int NST = 4, AHEAD = 3;
+    static constexpr int LDS = NST * STAGE + 1024;       // + the table's workgroup offsets
+};
+
+__device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+__global__ __launch_bounds__(WgCfg::NT) void wgrad_group_kernel(const blt_wg_problem* __restrict__ probs, const int* __restrict__ wg0, int nprob) {
+    typedef WgCfg C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::NWN, wn = wave % C::NWN;
+    // ---- which problem / tile / K-slice is this workgroup?  wg0[p] = first workgroup of problem p (wg0[nprob] = grid size) ----
+    int* s_wg0 = reinterpret_cast<int*>(smem + C::NST * C::STAGE);
+    if (tid <= nprob) s_wg0[tid] = wg0[tid];
+    __syncthreads();
+    int pi = 0;
+    {
+        int lo = 0, hi = nprob;            // largest p with wg0[p] <= blockIdx.x
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wg0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+        pi = __builtin_amdgcn_readfirstlane(lo);
+    }
+    const blt_wg_problem P = probs[pi];
+    const int local = (int)blockIdx.x - s_wg0[pi];
+    const int split = local % P.splits, tile = local / P.splits;
+    const int tile_m = tile / P.tiles_n, tile_n = tile % P.tiles_n;
+    const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
+    const int nk_all = (P.Mtok + C::BK - 1) / C::BK;
+    const int per = (nk_all + P.splits - 1) / P.splits;
+    const int kt0 = split * per;
+    const int nk = (kt0 + per < nk_all ? kt0 + per : nk_all) - kt0;
+    if (nk <= 0) return;                   // (uniform) an empty K-slice: nothing to add
+    const bf16* __restrict__ Ag = (const bf16*)P.A;
+    const bf16* __restrict__ Bg = (const bf16*)P.B;
+    const void* zero = (const void*)g2_zero_page;
+    const int a_cols = (P.Nw + 7) & ~7, b_cols = (P.Kw + 7) & ~7;      // loadable columns (lda / ldb cover the rounded width)
+
+    // DMA instruction j of this wave covers chunks c = (j*8 + wave)*64 + lane of a [64][16-chunk] tile: token row c >> 4, LDS slot
+    // c & 15 <- source chunk (c & 15) ^ f(row)
+    int a_row[C::CH], b_row[C::CH];
+    long a_off[C::CH], b_off[C::CH];
+#pragma unroll
+    for (int j = 0; j < C::CH; ++j) {
+        const int c = (j * C::NW + wave) * 64 + lane;
+        const int row = c >> 4, gc = (c & 15) ^ wg_swz(row);
+        a_row[j] = row; b_row[j] = row;
+        a_off[j] = (m0 + gc * 8 < a_cols) ? (long)row * P.lda + m0 + gc * 8 : -1;
+        b_off[j] = (n0 + gc * 8 < b_cols) ? (long)row * P.ldb + n0 + gc * 8 : -1;
+    }
+    auto issue_one = [&](int d, int kt, int stage) {      // kt relative to kt0; K-steps beyond the slice come from the zero page
+        char* a_st = smem + stage * C::STAGE;
+        char* b_st = a_st + C::A_BYTES;
+        const long t0 = (long)(kt0 + kt) * C::BK;
+        if (d < C::CH) {
+            const int j = d;
+            const bool ok = kt < nk && a_off[j] >= 0 && t0 + a_row[j] < P.Mtok;
+            dma16b(ok ? (const void*)(Ag + t0 * P.lda + a_off[j]) : zero, a_st + (j * C::NW + wave) * 1024);
+        } else {
+            const int j = d - C::CH;
+            const bool ok = kt < nk && b_off[j] >= 0 && t0 + b_row[j] < P.Mtok;
+            dma16b(ok ? (const void*)(Bg + t0 * P.ldb + b_off[j]) : zero, b_st + (j * C::NW + wave) * 1024);
+        }
+    };
+
+    f32x4 acc[C::TM][C::TN], accb[C::TM];
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i) {
+        accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = P.bias != nullptr && tile_n == 0 && wn == 0;          // wave-uniform
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
+    const int l15 = lane & 15, lg = lane >> 4;
+    // transposed-read addressing: lane 4q+p of a 16-lane group reads token row (8*lg + q [+4]) and the 4 columns 4p.. of its block
+    const int tq = l15 >> 2, tp = l15 & 3;
+
+#pragma unroll
+    for (int t = 0; t < C::AHEAD; ++t)
+#pragma unroll
+        for (int d = 0; d < C::PER_STAGE; ++d) issue_one(d, t, t);
+
+    int st_cur = 0, st_nxt = C::AHEAD % C::NST;
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_vmcnt2<(C::AHEAD - 1) * C::PER_STAGE>();
+        __builtin_amdgcn_s_barrier();
+        const char* a_st = smem + st_cur * C::STAGE;
+        const char* b_st = a_st + C::A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = ks * 32 + lg * 8 + tq;            // token row of the first transposed read (the second: + 4)
+            const int f0 = wg_swz(r0), f1 = wg_swz(r0 + 4);
+            bf16x8 bfr[C::TN], af[C::TM];
+#pragma unroll
+            for (int j = 0; j < C::TN; ++j) {
+                const int cb = wn * C::WN + j * 16 + tp * 4;           // first of the lane's 4 columns
+                const s16x4 lo = lds_tr16b(b_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
+                const s16x4 hi = lds_tr16b(b_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
+                bfr[j] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) {
+                const int cb = wm * C::WM + i * 16 + tp * 4;
+                const s16x4 lo = lds_tr16b(a_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
+                const s16x4 hi = lds_tr16b(a_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
+                af[i] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+                // K-step kt + AHEAD goes out between the MFMA groups: 4 DMA wave-instructions over the 8 slots of a K-step
+                const int slot = ks * C::TM + i;
+                if ((slot & 1) == 0) issue_one(slot >> 1, kt + C::AHEAD, st_nxt);
+            }
+        }
+        st_cur = (st_cur + 1 == C::NST) ? 0 : st_cur + 1;
+        st_nxt = (st_nxt + 1 == C::NST) ? 0 : st_nxt + 1;
+    }
+    wait_vmcnt2<0>();          // the null K-steps issued past the end must have landed before the workgroup retires its LDS
+
+    // ---- results: fp32, stored (one K-slice) or added (split-K: atomics into the zeroed gradient buffer) ----
+    float* Cg = P.C;
+#pragma unroll
+    for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * C::WM + i * 16 + lg * 4 + r, n = n0 + wn * C::WN + j * 16 + l15;
+                if (m < P.Nw && n < P.Kw) {
+                    float* dst = Cg + (size_t)m * P.ldc + n;
+                    if (P.splits > 1 || P.accumulate) atomicAdd(dst, acc[i][j][r]);
+                    else *dst = acc[i][j][r];
+                }
+            }
+    if (do_bias && l15 == 0) {
+#pragma unroll
+        for (int i = 0; i < C::TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * C::WM + i * 16 + lg * 4 + r;
+                if (m < P.Nw) {
+                    if (P.splits > 1 || P.accumulate) atomicAdd(P.bias + m, accb[i][r]);
+                    else P.bias[m] = accb[i][r];
+                }
+            }
+    }
+}
+
+// tile shapes compiled in: BM x BN, 8 waves as NWM x NWN, ring depth
+struct TileOpt { int bm, bn; int (*launch)(const GemmArgs&, hipStream_t); };
+#define NT2(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN>>}
+const TileOpt kTiles[] = {
+    NT2(64, 64, 2, 4),   NT2(64, 128, 2, 4),  NT2(128, 64, 4, 2),  NT2(128, 128, 2, 4),
+    NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(160, 192, 2, 4), NT2(160, 256, 2, 4),
+    NT2(192, 64, 4, 2),  NT2(192, 128, 2, 4), NT2(192, 192, 2, 4), NT2(192, 256, 2, 4),
+    NT2(128, 256, 2, 4), NT2(256, 128, 4, 2), NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
+};
+#undef NT2
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+}  // namespace
+
+// Cost model of one launch (microseconds, relative): rounds of <= 256 one-per-CU workgroups x (K-steps x max(intake, MFMA) + a fixed
+// prologue / epilogue); intake = (BM + BN) * 128 B per K-step at ~70 GB/s per CU, MFMA = BM * BN * 64 * 2 flop at 9.8 TFLOP/s per CU.
+int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn) {
+    int best = -1;
+    double best_cost = 1e30;
+    const int nk = cdiv(K, 64);
+    for (int i = 0; i < kNumTiles; ++i) {
+        const TileOpt& t = kTiles[i];
+        if (force_bm && (t.bm != force_bm || t.bn != force_bn)) continue;
+        const long tiles = (long)cdiv(M, t.bm) * cdiv(N, t.bn);
+        const long rounds = (tiles + 255) / 256;
+        const double intake = (t.bm + t.bn) * 128.0 / 70e3;                   // us per K-step
+        const double mfma = (double)t.bm * t.bn * 128.0 / 9.8e6;               // us per K-step
+        const double epi = 1.0 + (double)t.bm * t.bn / 40960.0 * 1.0;         // slab passes
+        // a partly filled last round still costs a full round; waste in padded tiles is priced through the tile count
+        const double cost = rounds * (nk * (intake > mfma ? intake : mfma) + 2.0 + epi);
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    // measured corrections of the model (scratch/mb_rep.py, un-profiled back-to-back launches on MI355X): at N ~ 1536 the 128 x 256
+    // tile (240-252 workgroups, 64 x 64 per wave) beats the 160/192-row tiles the model prefers by 10-15 %
+    if (!force_bm && M >= 4096 && N > 1024 && N < 2048)
+        for (int i = 0; i < kNumTiles; ++i)
+            if (kTiles[i].bm == 128 && kTiles[i].bn == 256) return i;
+    return best;
+}
+
+bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a) {
+    return dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv && !a.out_f32 && a.split_k == 0 && !a.stat_sum && !a.ln_out && !a.lnA_out &&
+           !a.a_rowsum && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.M >= 256;
+}
+
+int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm, int force_bn) {
+    const int i = blt_gemm_nt2_plan(a.M, a.N, a.K, force_bm, force_bn);
+    BLT_REQUIRE(i >= 0, "gemm_nt2: no tile %dx%d compiled in", force_bm, force_bn);
+    return kTiles[i].launch(a, s);
+}
+void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn) {
+    const int i = blt_gemm_nt2_plan(M, N, K, 0, 0);
+    *bm = kTiles[i].bm; *bn = kTiles[i].bn;
+}
+
+// ---- grouped weight gradients ----------------------------------------------------------------------------------------------
+bool blt_wgrad_group_ok(int dtype, const GemmArgs& a) {
+    return dtype == BLT_BF16 && a.transA && a.transB && a.out_f32 && !a.is_conv && !a.bias && !a.relu && a.drop_p == 0.f && !a.maskY && !a.C2 &&
+           !a.R && !a.rowtab && !a.stat_sum && a.alpha == 1.f && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.lda >= ((a.M + 7) & ~7) &&
+           a.ldb >= ((a.N + 7) & ~7) && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0;
+}
+// host table -> (problems, wg0); returns the number of workgroups.  Split-K only when the whole launch is short of tiles.
+int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_problem>& probs, std::vector<int>& wg0) {
+    long tiles = 0;
+    for (const GemmArgs& a : g) tiles += (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    probs.clear(); wg0.clear();
+    int wg = 0;
+    for (const GemmArgs& a : g) {
+        blt_wg_problem p;
+        p.A = a.A; p.B = a.B; p.C = (float*)a.C; p.bias = a.a_rowsum;
+        p.Nw = a.M; p.Kw = a.N; p.Mtok = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
+        p.tiles_n = cdiv(a.N, 128);
+        const int t = cdiv(a.M, 128) * p.tiles_n;
+        const int nk = cdiv(a.K, 64);
+        int s = 1;
+        if (tiles < 192) {                 // fewer tiles than CUs in the whole launch: slice K (>= 4 K-steps per slice)
+            s = (int)(256 / (tiles > 0 ? tiles : 1));
+            if (s > nk / 4) s = nk / 4;
+            if (s < 1) s = 1;
+            if (s > 32) s = 32;
+        }
+        p.splits = s;
+        p.accumulate = a.accumulate ? 1 : 0;
+        p.pad = 0;
+        probs.push_back(p);
+        wg0.push_back(wg);
+        wg += t * s;
+    }
+    wg0.push_back(wg);
+    return wg;
+}
+int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, hipStream_t s) {
+    BLT_REQUIRE(probs_dev && wg0_dev && nprob > 0 && nprob < 250 && nwg > 0, "wgrad_group: bad table");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg::LDS) != hipSuccess) {
+            blt_set_error("wgrad_group: hipFuncSetAttribute(%d) failed", WgCfg::LDS);
+            return BLT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)nwg), dim3(WgCfg::NT), WgCfg::LDS, s, probs_dev, wg0_dev, nprob);
+    return blt_check_launch("wgrad_group");
+}

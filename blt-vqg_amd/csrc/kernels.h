@@ -2,6 +2,7 @@
 // allocates nothing and returns BLT_OK or a negative error (message via bltvqg_last_error_string()).
 // `dtype` is BLT_F32 or BLT_BF16 and names the storage type T of activations / (shadow) weights.
 #pragma once
+#include <vector>
 #include "common.h"
 
 // "Padded-pitch" (PP) activation layout [N][H+1][W+1][C]: every image row is followed by ONE zero pixel and every image by ONE
@@ -83,6 +84,19 @@ int blt_gemm_tile(const GemmArgs& a, int dtype);
 void blt_debug_set(int key, int value);
 int blt_debug_get(int key);      // keys 4..6: A/B switches of conv_pp.hip (4 = force BN 64/128, 5 = XCD mapping 1 chunked / 2 round-robin, 6 = ring 1 deep / 2 shallow)
 int blt_gemm_splits(const GemmArgs& a, int dtype);
+// gemm2.hip: one-round-per-chip NT GEMM (bf16, k-contiguous operands, bf16 output): tile shape planned per problem
+bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a);
+int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm = 0, int force_bn = 0);
+void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn);
+// gemm2.hip: grouped weight gradients (one launch for a table of dW = dY^T X problems; GemmArgs in the transA/transB weight-gradient
+// form: A = dY [rows, lda], B = X [rows, ldb], C = dW fp32 [M = out features, ldc], K = rows, a_rowsum = bias gradient or null)
+struct blt_wg_problem {
+    const void* A; const void* B; float* C; float* bias;
+    int Nw, Kw, Mtok, lda, ldb, ldc, tiles_n, splits, accumulate, pad;
+};
+bool blt_wgrad_group_ok(int dtype, const GemmArgs& a);
+int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_problem>& probs, std::vector<int>& wg0);
+int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, hipStream_t s);
 
 // ---- padded-pitch 3x3 stride-1 convolution (conv_pp.hip), bf16 only ----------------
 long blt_pp_pixels(int N, int H, int W);                 // N*(H+1)*(W+1) positions (without the guards)
@@ -187,6 +201,8 @@ int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int
 int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long rows, int cols, hipStream_t s);
 // table_dev: int4 {element offset, rows, cols, first 64x64 tile} per matrix; dst_bf16 may be null (transposed copy only)
 int blt_shadow_transpose(const float* src, void* dst_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s);
+// transposed shadows only, from the plain bf16 shadow (kept current by blt_adam_step's shadow output)
+int blt_shadow_transpose_bf16(const void* src_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s);
 
 // ---- losses ------------------------------------------------------------------------------------
 // token CE with ignore_index=0, mean over non-pad targets (count from counters[0]); writes d(logits) IN PLACE scaled by
@@ -216,7 +232,7 @@ int blt_bn_eval_scale(const float* gamma, const float* beta, const float* rmean,
 int blt_sumsq(const float* x, long n, float* out /* += */, hipStream_t s);
 // clip_grad_norm_(max_norm) + Adam (torch defaults) over a flat fp32 buffer; gnorm_sq is a device scalar
 int blt_adam_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float max_norm, float lr,
-                  float beta1, float beta2, float eps, int step, hipStream_t s);
+                  float beta1, float beta2, float eps, int step, hipStream_t s, void* shadow_bf16 = nullptr /* bf16 mirror of p, written in the same pass */);
 int blt_dropout_mask(uint64_t seed, uint32_t stream_id, long rows, int cols, int ld_index, float p, unsigned char* out,
                      hipStream_t s);
 

@@ -587,15 +587,49 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, s);
 }
 
-// torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam.step (defaults: amsgrad off, wd 0)
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                  float* __restrict__ v, long n, const float* __restrict__ gnorm_sq, float max_norm,
-                                                  float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt) {
+// torch.nn.utils.clip_grad_norm_(max_norm) followed by torch.optim.Adam.step (defaults: amsgrad off, wd 0).  HBM-bound: 28 bytes per
+// parameter (p, g, m, v read; p, m, v written) + 2 when `shadow` (the bf16 mirror the next forward's GEMMs read) is written in the same
+// pass; 16-byte accesses (n4 = number of float4 groups, the flat buffers are 16-byte aligned and padded to a multiple of 8 floats).
+__global__ __launch_bounds__(256) void adam_kernel(float4* __restrict__ p, const float4* __restrict__ g, float4* __restrict__ m,
+                                                  float4* __restrict__ v, long n4, const float* __restrict__ gnorm_sq, float max_norm,
+                                                  float lr, float beta1, float beta2, float eps, float bc1, float bc2_sqrt, s16x4* __restrict__ shadow) {
     float clip = 1.f;
     if (max_norm > 0.f) {
         const float norm = sqrtf(gnorm_sq[0]);
         clip = fminf(max_norm / (norm + 1e-6f), 1.f);
     }
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 g4 = g[i], m4 = m[i], v4 = v[i];
+        float4 p4 = p[i];
+        float gg[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = gg[e] * clip;
+            mm[e] = beta1 * mm[e] + (1.f - beta1) * gi;
+            vv[e] = beta2 * vv[e] + (1.f - beta2) * gi * gi;
+            const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+            pp[e] -= step_size * (mm[e] / denom);
+        }
+        m[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+        v[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        p[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+        if (shadow) {
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+            bf16x4 b;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) b[e] = (bf16)pp[e];
+            shadow[i] = __builtin_bit_cast(s16x4, b);
+        }
+    }
+}
+
+// scalar form for ragged / unaligned callers of the operator (the engine's flat buffers always take the vector form)
+__global__ __launch_bounds__(256) void adam_scalar_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                                         const float* __restrict__ gnorm_sq, float max_norm, float lr, float beta1, float beta2, float eps,
+                                                         float bc1, float bc2_sqrt, bf16* __restrict__ shadow) {
+    float clip = 1.f;
+    if (max_norm > 0.f) clip = fminf(max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f), 1.f);
     const float step_size = lr / bc1;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * clip;
@@ -603,8 +637,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         const float vi = beta2 * v[i] + (1.f - beta2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        p[i] -= step_size * (mi / denom);
+        const float pn = p[i] - step_size * (mi / (sqrtf(vi) / bc2_sqrt + eps));
+        p[i] = pn;
+        if (shadow) shadow[i] = (bf16)pn;
+    }
+}
+
+// transposed bf16 shadows from the PLAIN bf16 shadow (which the optimiser pass above keeps current): same table as
+// shadow_transpose_kernel, half the bytes (no fp32 read, no plain write)
+__global__ __launch_bounds__(256) void shadow_transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dstT, const int4* __restrict__ table,
+                                                                   int nent) {
+    __shared__ bf16 tile[64][66];
+    int e = 0;
+    while (e + 1 < nent && (int)blockIdx.x >= table[e + 1].w) ++e;
+    const int4 t = table[e];
+    if (t.z <= 0) return;                      // plain shadow only
+    const int off = t.x, rows = t.y, cols = t.z;
+    const int tiles_c = (cols + 63) >> 6;
+    const int lt = (int)blockIdx.x - t.w;
+    const int r0 = (lt / tiles_c) << 6, c0 = (lt % tiles_c) << 6;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < rows && c < cols) ? src[(size_t)off + (size_t)r * cols + c] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) dstT[(size_t)off + (size_t)c * rows + r] = tile[tx][i];
     }
 }
 
@@ -839,13 +899,26 @@ int blt_sumsq(const float* x, long n, float* out, hipStream_t s) {
 }
 
 int blt_adam_step(float* p, const float* g, float* m, float* v, long n, const float* gnorm_sq, float max_norm, float lr,
-                  float beta1, float beta2, float eps, int step, hipStream_t s) {
+                  float beta1, float beta2, float eps, int step, hipStream_t s, void* shadow_bf16) {
     BLT_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam: bad args");
     BLT_REQUIRE(max_norm <= 0.f || gnorm_sq != nullptr, "adam: clipping needs gnorm_sq");
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, 1024)), dim3(256), 0, s, p, g, m, v, n, gnorm_sq, max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt);
+    const bool vec = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) % 16) == 0 && ((uintptr_t)shadow_bf16 % 8) == 0;
+    const long nvec = vec ? n / 4 * 4 : 0;
+    if (nvec > 0)
+        hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(nvec / 4, 2048)), dim3(256), 0, s, (float4*)p, (const float4*)g, (float4*)m, (float4*)v, nvec / 4,
+                           gnorm_sq, max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt, (s16x4*)shadow_bf16);
+    if (nvec < n)
+        hipLaunchKernelGGL(adam_scalar_kernel, dim3(ew_grid(n - nvec, 1024)), dim3(256), 0, s, p + nvec, g + nvec, m + nvec, v + nvec, n - nvec, gnorm_sq,
+                           max_norm, lr, beta1, beta2, eps, bc1, bc2_sqrt, shadow_bf16 ? (bf16*)shadow_bf16 + nvec : nullptr);
     return blt_check_launch("adam");
+}
+
+int blt_shadow_transpose_bf16(const void* src_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s) {
+    BLT_REQUIRE(src_bf16 && dstT_bf16 && table_dev && nent > 0 && total_tiles > 0, "shadow_transpose_bf16: bad args");
+    hipLaunchKernelGGL(shadow_transpose_bf16_kernel, dim3(total_tiles), dim3(256), 0, s, (const bf16*)src_bf16, (bf16*)dstT_bf16, (const int4*)table_dev, nent);
+    return blt_check_launch("shadow_transpose_bf16");
 }
 
 int blt_dropout_mask(uint64_t seed, uint32_t stream_id, long rows, int cols, int ld_index, float p, unsigned char* out, hipStream_t s) {

@@ -159,6 +159,15 @@ class StepEngine(object):
                                                    ptr(tokens), ptr(top_idx), ptr(top_val), stream_ptr()), "engine_decode_greedy")
         return tokens, top_idx, top_val
 
+    def trust_shadows(self, on=True):
+        """Promise that parameters change only through this engine family's optimizer_step (or are reported via load_state /
+        params_changed): the bf16 weight shadow is then written by the update itself instead of being rebuilt every forward."""
+        check(self.lib.bltvqg_engine_trust_shadows(self.h, 1 if on else 0), "engine_trust_shadows")
+
+    def params_changed(self):
+        """Call after writing flat_train / flat_frozen from outside the engine (a broadcast, an in-place edit)."""
+        self.lib.bltvqg_engine_invalidate_frozen(self.h)
+
     def set_bn_train(self, train):
         check(self.lib.bltvqg_engine_set_bn_train(self.h, 1 if train else 0), "engine_set_bn_train")
 

@@ -150,6 +150,11 @@ class DataParallelStep(object):
             # buffers and must not repeat it
             dist.broadcast(engine.flat_train, 0)
             dist.broadcast(engine.flat_frozen, 0)
+            if hasattr(engine, "params_changed"):
+                engine.params_changed()
+        # this driver updates the parameters only through the engine's own optimiser: the update may keep the bf16 weight shadows current
+        if hasattr(engine, "trust_shadows"):
+            engine.trust_shadows(True)
 
     def _on_comm(self):
         import contextlib

@@ -51,6 +51,24 @@ int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, in
                 const void* maskY, int ldm, float mask_scale, const void* R, int ldr, int accumulate, int out_f32,
                 int force_tile, int split_k, void* stream);
 
+/* bf16 Linear forward / input gradient C = epilogue(A[M,K] B[N,K]^T) on the planned-tile kernel (gemm2.hip) with EVERY epilogue term
+ * exposed: v = acc + bias[n] + rowtab[rowidx[m]][n]; relu; dropout(seed, stream_id); (maskY[m,n] != 0) * mask_scale; -> C2 (optional
+ * copy); + R[m,n]; (+ old C); -> C.  tile_m x tile_n selects one of the compiled tile shapes (0, 0 = the planner's choice for this
+ * problem; tile_m < 0 = the round-1 64x64 ring kernel, for A/B comparisons). */
+int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const float* rowtab,
+                   const int32_t* rowidx, int ldt, int relu, float drop_p, uint64_t seed, uint32_t stream_id, const void* maskY, int ldm, float mask_scale,
+                   void* C2, int ldc2, const void* R, int ldr, int accumulate, int tile_m, int tile_n, void* stream);
+/* Weight gradients of n Linear layers in ONE launch (bf16 operands, fp32 results): dW_i[N_i, K_i] = dY_i[rows_i, N_i]^T X_i[rows_i, K_i]
+ * and dbias_i[N_i] = column sums of dY_i (dbias_i may be NULL).  Results are STORED unless the launch is short of tiles and slices
+ * the contraction (then they are atomically added: dW / dbias must be zero on entry, as the engine's gradient buffer is).  The
+ * pointer / size arrays are HOST arrays; table_dev is caller-owned device scratch for the problem table (128 + 80 * n bytes). */
+int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, const void* const* X, const int32_t* ldx, float* const* dW,
+                              const int32_t* ldw, float* const* dbias, const int32_t* rows, const int32_t* N, const int32_t* K, void* table_dev,
+                              int64_t table_bytes, void* stream);
+/* Timing aid: `reps` back-to-back launches of the Linear forward C = [relu](A B^T + bias) (+ R) from inside the library, so that a
+ * host-side event pair measures device time per launch (a Python call per launch costs more than these kernels run). */
+int bltvqg_gemm_repeat(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu,
+                       const void* R, int ldr, int reps, void* stream);
 /* Backward of y = x W^T + b w.r.t. the parameters (autograd of nn.Linear, transformer_layers.py:453-456,400-408):
  * dW[N,K] += dY[rows,N]^T X[rows,K] and, when dbias is non-null, dbias[N] += column sums of dY — both fp32, in ONE launch (the bias
  * gradient falls out of the staging registers of the dY operand).  split_k > 0: up to that many slices of `rows`, fp32 atomics. */
@@ -245,8 +263,14 @@ int64_t bltvqg_engine_workspace_bytes(const bltvqg_engine* e);
 /* Binds caller-owned device memory.  workspace must be 256-byte aligned and is zeroed by bind (synchronously). */
 int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_m, float* adam_v, float* frozen,
                        void* workspace, int64_t workspace_bytes);
-/* Frozen backbone weights changed (load_state_dict): repack on next forward. */
+/* Parameters were written from outside the engine (load_state_dict, a broadcast): the frozen backbone is repacked and the bf16
+ * weight shadows of EVERY engine sharing these parameters are rebuilt on their next forward. */
 void bltvqg_engine_invalidate_frozen(bltvqg_engine* e);
+/* bf16 engines keep a bf16 mirror ("shadow") of the weight matrices.  By default every forward rebuilds it from the fp32 parameters
+ * (anyone may have written them: a torch optimiser on the autograd path).  A caller that updates the parameters ONLY through
+ * bltvqg_engine_optimizer_step[_async] (and reports every other write with bltvqg_engine_invalidate_frozen) sets on = 1: the update
+ * then writes the shadow in the same pass and forward only derives the transposed copies (saves a 0.5 GB pass per step). */
+int bltvqg_engine_trust_shadows(bltvqg_engine* e, int on);
 
 /* The engine's stem input: zero-bordered NHWC4 [batch, *Hp, *Wp, 4] of *dtype inside the bound workspace, image at (3,3).  A caller
  * that fills it itself (bltvqg_batch_images_packed) passes images = NULL to bltvqg_engine_forward / decode_greedy, which then skip

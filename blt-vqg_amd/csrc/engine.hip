@@ -183,6 +183,16 @@ struct bltvqg_engine {
     // optional in-stream timing of the two dominant kernel families: one event pair per launch, on the stream of the launch.
     // class 0 = the convolution launches of the frozen ResNet-18 stack, class 1 = every Linear-layer GEMM (forward, input gradient,
     // weight gradient) of the transformer stacks / embedding / vocabulary projection / latent nets.  prof_mask bit c enables class c.
+    // diagnostic: hipEvent stamps on the MAIN stream at the phase boundaries of a step (debug key 12 = 1): where the critical path spends
+    // its time, measured without a profiler (rocprofv3 makes the host the bottleneck and distorts the overlap)
+    hipEvent_t stamp_ev[12] = {};
+    bool stamp_used[12] = {};
+    void stamp(int i, hipStream_t s) {
+        if (blt_debug_get(12) != 1 || i < 0 || i >= 12) return;
+        if (!stamp_ev[i] && hipEventCreate(&stamp_ev[i]) != hipSuccess) return;
+        (void)hipEventRecord(stamp_ev[i], s);
+        stamp_used[i] = true;
+    }
     int prof_mask = 0;
     struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; double flops = 0.0; };
     std::vector<ProfRec> prof;
@@ -945,6 +955,7 @@ struct bltvqg_engine {
         BLT_REQUIRE((images || !regions) && ctx && post && tgt, "engine_forward: null input");
         BLT_REQUIRE(!p2 || eps, "engine_forward: eps required in phase 2");
         phase2 = p2; seed = seed_; fwd_done = false;
+        stamp(0, s);
         // with an optimiser update still in flight only the streams that read trainable parameters wait for it (below)
         const bool overlap_opt = opt_pending && use_streams;
         if (opt_pending && !overlap_opt) { RC(sync_opt(s)); opt_pending = false; }
@@ -1017,6 +1028,7 @@ struct bltvqg_engine {
 
     // everything after the image feature exists: latent, decoder, vocabulary projection, reconstructor (all on `s`)
     int forward_tail(const float* eps, hipStream_t s) {
+        stamp(1, s);           // CNN + both encoders done (the side streams were joined just before)
         kv_hoisted = false;
         RC(blt_rows_add(dt, enc.out, (long)Sa * H, feats, H, nullptr, 0, B, H, 1, s));   // encoder_outputs[:,0] += image_features
         // Branch stream: everything below that the decoder stack does not need (z_classifier, image reconstructor) or needs only
@@ -1053,10 +1065,13 @@ struct bltvqg_engine {
             RC(gemm(dt, g, sb));
             RC(gemm(dt, lin(hrec, F, "image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc1.bias", recon, H, B), sb));
         }
+        stamp(2, s);           // latent / injections done, decoder starts
         RC(stack_fwd(dec, enc.out, ctx32, s));
+        stamp(3, s);
         kv_hoisted = false;
         RC(gemm(dt, lin(dec.out, H, "decoder.output.weight", "decoder.output.bias", logits, ldV, Mt), s));
         if (sb != s) RC(fork(sb, s, fj[14]));
+        stamp(4, s);           // vocabulary projection done: end of forward
         fwd_done = true;
         return BLT_OK;
     }
@@ -1198,6 +1213,10 @@ struct bltvqg_engine {
             void* ngY = (l > 0) ? st.layers[l - 1].gY : nullptr;
             RC(ln_bwd(gB, x, ln1, y.m1, y.r1, cur, out, M, s, nmask, relu_ks(), ngY));
             cur = out;
+            // debug key 11 = N >= 2: hand the collected weight gradients to the side stream every N layers instead of once per stack, so
+            // that they run under the rest of THIS chain rather than under the next one (A/B switch)
+            const int every = blt_debug_get(11);
+            if (defer_wgrads && every >= 2 && l > 0 && ((L - l) % (every - 1)) == 0) RC(flush_wgrads(s, side[1], fj[6]));
         }
         return BLT_OK;
     }
@@ -1252,12 +1271,10 @@ struct bltvqg_engine {
             RC(ln_bwd(gA, xL, "decoder.decoder.layer_norm", dec.mF, dec.rF, nullptr, dxT, Mt, s, dec.layers[L - 1].y2, relu_ks(),
                       dec.layers[L - 1].gY));
         }
+        stamp(6, s);           // vocabulary input gradient + final LayerNorm backward done
         RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
+        stamp(7, s);
         if (sbr != s && hipStreamWaitEvent(s, fj[12], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
-        // the decoder's weight gradients run on side[1] from here on, under the rest of backward; bucket 0 (decoder.*) is complete when
-        // that stream gets here
-        RC(flush_wgrads(s, side[1], fj[6]));
-        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], use_streams ? side[1] : s);
         // target_embedding[:,0] += image_features (+ z); r_in = encoder row 0 (+ z); zc_in = z + image_features
         RC(blt_row0_sums(dt, dxT, (long)T * H, g_rin, phase2 ? g_zc : nullptr, d_feats, phase2 ? d_zproj : nullptr, d_enc, (long)Sa * H, B, H, s));
         if (phase2) {
@@ -1274,6 +1291,12 @@ struct bltvqg_engine {
         }
         // encoder_outputs[:,0] += image_features
         RC(blt_rows_add(dt, d_feats, H, d_enc, (long)Sa * H, nullptr, 0, B, H, 1, s));
+        // The decoder's weight gradients (one grouped launch: six rounds of the whole chip) go to side[1] only HERE, behind the latent
+        // section: its dozen [B, *]-sized launches sit on the critical path between the decoder chain and the two encoder chains, and
+        // launched beside the grouped kernel they waited for its 40 us workgroups to free a CU one by one (0.55 ms instead of 0.1).  The
+        // latent nets' own weight gradients ride in the same launch; bucket 0 (decoder.*) is complete when side[1] gets past it.
+        RC(flush_wgrads(s, side[1], fj[6]));
+        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], use_streams ? side[1] : s);
         // d(image feature) is final here, long before the encoder chains are: the CNN head's backward (BatchNorm1d -> fc) goes to the
         // weight-gradient stream now instead of closing the chain
         if (use_streams) { RC(fork(s, side[1], fj[13])); RC(cnn_head_bwd(side[1])); }
@@ -1301,7 +1324,9 @@ struct bltvqg_engine {
             RC(ln_bwd(d_enc, xL, "answer_encoder.encoder.layer_norm", enc.mF, enc.rF, nullptr, dX_all, Ma, s, enc.layers[L - 1].y2, relu_ks(),
                       enc.layers[L - 1].gY));
         }
+        stamp(8, s);           // latent backward done, context-encoder backward starts (posterior encoder runs beside it)
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
+        stamp(9, s);
         RC(flush_wgrads(s, side[1], fj[8]));
         defer_wgrads = false;
         if (s0 != s && hipStreamWaitEvent(s, fj[5], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
@@ -1328,6 +1353,7 @@ struct bltvqg_engine {
         if (bucket_ev[1]) (void)hipEventRecord(bucket_ev[1], s);
         if (bucket_ev[2]) (void)hipEventRecord(bucket_ev[2], s);
         last_bwd_phase2 = phase2;
+        stamp(10, s);          // every stream joined: end of backward
         return BLT_OK;
     }
     int zero_grads(hipStream_t s) {
@@ -1355,6 +1381,7 @@ struct bltvqg_engine {
             kld_g = c.kl_ceiling * kl_weight;
         }
         RC(blt_ce_fwd_bwd(dt, logits, ldV, tgt32, Mt, V, counters, 1.f, stats + 0, 1, s));
+        stamp(5, s);           // loss kernels enqueued
         return backward_core(kld_g, s);
     }
 
@@ -1664,6 +1691,20 @@ int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms
 }
 int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host) {
     return bltvqg_engine_profile_read_class(e, 0, total_ms_host, launches_host, flops_host);
+}
+
+int bltvqg_engine_phase_stamps(bltvqg_engine* e, float* ms_host12) {
+    BLT_REQUIRE(e && ms_host12, "engine_phase_stamps: bad args");
+    for (int i = 0; i < 12; ++i) ms_host12[i] = -1.f;
+    if (!e->stamp_used[0]) return BLT_OK;
+    for (int i = 1; i < 12; ++i) {
+        if (!e->stamp_used[i]) continue;
+        if (hipEventSynchronize(e->stamp_ev[i]) != hipSuccess) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->stamp_ev[0], e->stamp_ev[i]) == hipSuccess) ms_host12[i] = ms;
+    }
+    ms_host12[0] = 0.f;
+    return BLT_OK;
 }
 
 int bltvqg_engine_num_buckets(const bltvqg_engine* e) { return e ? 3 : 0; }

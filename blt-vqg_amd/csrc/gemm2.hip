@@ -20,6 +20,7 @@
 //
 // Replaces torch.nn.Linear forward / backward call sites of the reference hot path (models/transformer_layers.py:453-456,489-491,530,
 // 400-408; models/iq.py:39,72-78; models/decoder_transformer.py:19-20,40).
+#include <type_traits>
 #include <vector>
 #include "kernels.h"
 
@@ -35,8 +36,15 @@ __device__ __forceinline__ void dma16b(const void* gsrc, char* lds_dst_wave_base
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_dst_wave_base, 16, 0, 0);
 }
+// ds_read_b64_tr_b16 as inline asm: behind the builtin hipcc (ROCm 7.2) puts `s_waitcnt vmcnt(0)` in front of every group of
+// transposed reads while LDS-DMA is in flight (it treats the DMA as a pending store the read may alias), which drains the whole ring
+// every K-step.  The asm form is invisible to that pass: the data dependency is carried by lds_tr_wait() (every destination "+v",
+// cdna_hip_programming.md 5.7 form (ii)) and the MFMAs are fenced below it with sched_barrier (rule 18).
 __device__ __forceinline__ s16x4 lds_tr16b(const char* p) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+    s16x4 r;
+    const unsigned a = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(a));
+    return r;
 }
 typedef __attribute__((ext_vector_type(8))) short s16x8b;
 
@@ -334,13 +342,17 @@ int launch_nt2(const GemmArgs& a, hipStream_t s) {
 // 16-byte chunks of a row XOR-swizzled by f(row) on the SOURCE side) and the MFMA operands come out of LDS through
 // ds_read_b64_tr_b16 (cdna_hip_programming.md T10, image (b): conflict-free for the 16x16x32 operand).
 // ---------------------------------------------------------------------------------------------------------------
+// 16 waves (4 x 4, wave tile 32 x 32): four waves per SIMD.  The per-wave chain of a K-step (transposed reads -> lgkmcnt wait -> MFMAs,
+// twice) is latency-bound, so it is the number of waves interleaving on a SIMD that keeps the matrix pipe and the DMA queue fed: with 8
+// waves (2 per SIMD, wave tile 64 x 32) a K-step took 1.27 us against 0.47 us of LDS-DMA intake (PMC: 40 % of wave cycles in waits).
 struct WgCfg {
-    static constexpr int BM = 128, BN = 128, BK = 64, NW = 8, NT = 512, NWN = 4;
-    static constexpr int WM = 64, WN = 32, TM = 4, TN = 2;
+    static constexpr int BM = 128, BN = 128, BK = 64, NWM = 4, NWN = 4, NW = NWM * NWN, NT = NW * 64;
+    static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
     static constexpr int A_BYTES = BK * 256, B_BYTES = BK * 256, STAGE = A_BYTES + B_BYTES;      // 32 KB
-    static constexpr int CH = 2, PER_STAGE = 4;          // DMA wave-instructions per wave per stage: 2 for A, 2 for B
+    static constexpr int CH = 1024 / NT, PER_STAGE = 2 * CH;          // DMA wave-instructions per wave per stage: CH for A, CH for B
     static constexpr int NST = 4, AHEAD = 3;
     static constexpr int LDS = NST * STAGE + 1024;       // + the table's workgroup offsets
+    static_assert(CH >= 1 && TM >= 1 && TN == 2, "wave layout");
 };
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -355,14 +367,22 @@ __global__ __launch_bounds__(WgCfg::NT) void wgrad_group_kernel(const blt_wg_pro
     int* s_wg0 = reinterpret_cast<int*>(smem + C::NST * C::STAGE);
     if (tid <= nprob) s_wg0[tid] = wg0[tid];
     __syncthreads();
+    // XCD-aware order (cdna_hip_programming.md T1, bijective form): workgroups are dealt round-robin over the 8 XCDs, each with its own
+    // L2; the remap gives every XCD a CONTIGUOUS run of the launch's work list, so that the tiles that stream the same dY / X panel (1.3 MB
+    // each at 5 120 tokens) run side by side on one L2 instead of every tile pulling its own copy through the Infinity Cache
+    int vid;
+    {
+        const int nwg = (int)gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = (int)blockIdx.x & 7, idx = (int)blockIdx.x >> 3;
+        vid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
     int pi = 0;
     {
-        int lo = 0, hi = nprob;            // largest p with wg0[p] <= blockIdx.x
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wg0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+        int lo = 0, hi = nprob;            // largest p with wg0[p] <= vid
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (s_wg0[mid] <= vid) lo = mid; else hi = mid; }
         pi = __builtin_amdgcn_readfirstlane(lo);
     }
     const blt_wg_problem P = probs[pi];
-    const int local = (int)blockIdx.x - s_wg0[pi];
+    const int local = vid - s_wg0[pi];
     const int split = local % P.splits, tile = local / P.splits;
     const int tile_m = tile / P.tiles_n, tile_n = tile % P.tiles_n;
     const int m0 = tile_m * C::BM, n0 = tile_n * C::BN;
@@ -423,44 +443,68 @@ __global__ __launch_bounds__(WgCfg::NT) void wgrad_group_kernel(const blt_wg_pro
 #pragma unroll
         for (int d = 0; d < C::PER_STAGE; ++d) issue_one(d, t, t);
 
+    // the K loop exists twice — with and without the bias-gradient MFMAs — selected by a wave-uniform branch OUTSIDE the loop: as a
+    // condition inside it, every MFMA group carried a set of accumulator copies (phi nodes) and the loop was VALU-bound on v_mov
+    auto k_loop = [&](auto with_bias) {
     int st_cur = 0, st_nxt = C::AHEAD % C::NST;
-    for (int kt = 0; kt < nk; ++kt) {
-        wait_vmcnt2<(C::AHEAD - 1) * C::PER_STAGE>();
-        __builtin_amdgcn_s_barrier();
-        const char* a_st = smem + st_cur * C::STAGE;
-        const char* b_st = a_st + C::A_BYTES;
+        for (int kt = 0; kt < nk; ++kt) {
+            wait_vmcnt2<(C::AHEAD - 1) * C::PER_STAGE>();
+            __builtin_amdgcn_s_barrier();
+            const char* a_st = smem + st_cur * C::STAGE;
+            const char* b_st = a_st + C::A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int r0 = ks * 32 + lg * 8 + tq;            // token row of the first transposed read (the second: + 4)
-            const int f0 = wg_swz(r0), f1 = wg_swz(r0 + 4);
-            bf16x8 bfr[C::TN], af[C::TM];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int r0 = ks * 32 + lg * 8 + tq;            // token row of the first transposed read (the second: + 4)
+                const int f0 = wg_swz(r0), f1 = wg_swz(r0 + 4);
+                bf16x8 bfr[C::TN], af[C::TM];
+                s16x4 blo[C::TN], bhi[C::TN], alo[C::TM], ahi[C::TM];
 #pragma unroll
-            for (int j = 0; j < C::TN; ++j) {
-                const int cb = wn * C::WN + j * 16 + tp * 4;           // first of the lane's 4 columns
-                const s16x4 lo = lds_tr16b(b_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
-                const s16x4 hi = lds_tr16b(b_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
-                bfr[j] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                for (int j = 0; j < C::TN; ++j) {
+                    const int cb = wn * C::WN + j * 16 + tp * 4;           // first of the lane's 4 columns
+                    blo[j] = lds_tr16b(b_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
+                    bhi[j] = lds_tr16b(b_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
+                }
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) {
+                    const int cb = wm * C::WM + i * 16 + tp * 4;
+                    alo[i] = lds_tr16b(a_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
+                    ahi[i] = lds_tr16b(a_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
+                }
+                if constexpr (C::TM == 4) {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]),
+                                   "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3])
+                                 :: "memory");
+                } else {
+                    static_assert(C::TM == 2 || C::TM == 4, "lds_tr wait lists");
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1])
+                                 :: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < C::TN; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) af[i] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+#pragma unroll
+                for (int i = 0; i < C::TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    if constexpr (decltype(with_bias)::value) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+                    // K-step kt + AHEAD goes out between the MFMA groups: PER_STAGE DMA wave-instructions over the 2 * TM slots of a K-step
+                    constexpr int SLOTS = 2 * C::TM;
+                    const int slot = ks * C::TM + i;
+#pragma unroll
+                    for (int d = 0; d < C::PER_STAGE; ++d)
+                        if (d * SLOTS / C::PER_STAGE == slot) issue_one(d, kt + C::AHEAD, st_nxt);
+                }
             }
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i) {
-                const int cb = wm * C::WM + i * 16 + tp * 4;
-                const s16x4 lo = lds_tr16b(a_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
-                const s16x4 hi = lds_tr16b(a_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
-                af[i] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-            }
-#pragma unroll
-            for (int i = 0; i < C::TM; ++i) {
-#pragma unroll
-                for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                if (do_bias) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
-                // K-step kt + AHEAD goes out between the MFMA groups: 4 DMA wave-instructions over the 8 slots of a K-step
-                const int slot = ks * C::TM + i;
-                if ((slot & 1) == 0) issue_one(slot >> 1, kt + C::AHEAD, st_nxt);
-            }
+            st_cur = (st_cur + 1 == C::NST) ? 0 : st_cur + 1;
+            st_nxt = (st_nxt + 1 == C::NST) ? 0 : st_nxt + 1;
         }
-        st_cur = (st_cur + 1 == C::NST) ? 0 : st_cur + 1;
-        st_nxt = (st_nxt + 1 == C::NST) ? 0 : st_nxt + 1;
-    }
+    };
+    if (do_bias) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     wait_vmcnt2<0>();          // the null K-steps issued past the end must have landed before the workgroup retires its LDS
 
     // ---- results: fp32, stored (one K-slice) or added (split-K: atomics into the zeroed gradient buffer) ----

@@ -331,6 +331,10 @@ uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site);
 int bltvqg_engine_profile_enable(bltvqg_engine* e, int mask);
 int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host);
 int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host);
+/* Diagnostic (bltvqg_debug_set(12, 1)): milliseconds from the start of the last forward to the phase boundaries of the step on the
+ * caller's stream — [1] CNN + encoders joined, [2] decoder starts, [3] decoder done, [4] end of forward, [5] losses, [6] decoder backward
+ * starts, [7] decoder backward done, [8] encoder backward starts, [9] done, [10] end of backward; -1 = not recorded. */
+int bltvqg_engine_phase_stamps(bltvqg_engine* e, float* ms_host12);
 /* gradient buckets for data-parallel overlap: contiguous float ranges of the flat gradient buffer in the order backward
  * completes them; bltvqg_engine_bucket_wait makes `stream` wait until bucket i of the last backward is complete. */
 int bltvqg_engine_num_buckets(const bltvqg_engine* e);

@@ -47,7 +47,8 @@ int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, 
     }
     std::vector<blt_wg_problem> probs;
     std::vector<int> wg0;
-    const int nwg = blt_wgrad_group_plan(gs, probs, wg0);
+    int bm = 128;
+    const int nwg = blt_wgrad_group_plan(gs, probs, wg0, &bm);
     const size_t pb = probs.size() * sizeof(blt_wg_problem), pb_al = (pb + 63) / 64 * 64;
     BLT_REQUIRE((int64_t)(pb_al + wg0.size() * 4) <= table_bytes, "linear_wgrad_group: table_dev too small (%lld bytes needed)", (long long)(pb_al + wg0.size() * 4));
     // synchronous copies: the host vectors die at return
@@ -56,7 +57,7 @@ int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, 
         blt_set_error("linear_wgrad_group: table upload failed");
         return BLT_ERR_HIP;
     }
-    return blt_wgrad_group_launch((const blt_wg_problem*)table_dev, (const int*)((char*)table_dev + pb_al), n, nwg, (hipStream_t)stream);
+    return blt_wgrad_group_launch((const blt_wg_problem*)table_dev, (const int*)((char*)table_dev + pb_al), n, nwg, bm, (hipStream_t)stream);
 }
 
 int bltvqg_gemm_repeat(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu,

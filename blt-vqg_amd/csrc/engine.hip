@@ -578,7 +578,7 @@ struct bltvqg_engine {
     // issue the collected weight-gradient GEMMs on `to`, ordered after everything enqueued on `from` so far.  bf16: ONE grouped launch
     // (gemm2.hip::wgrad_group_kernel) over a device-side problem table; the table of a flush point is the same every step (static
     // workspace pointers), so it is uploaded once and only re-uploaded when its content changes (phase switch).
-    struct WgTable { std::vector<blt_wg_problem> probs; std::vector<int> wg0; int nwg = 0; bool valid = false; };
+    struct WgTable { std::vector<blt_wg_problem> probs; std::vector<int> wg0; int nwg = 0, bm = 128; bool valid = false; };
     std::vector<WgTable> wg_tables;
     int flush_idx = 0;
     char* wg_pool = nullptr;
@@ -594,11 +594,12 @@ struct bltvqg_engine {
             WgTable& t = wg_tables[flush_idx];
             std::vector<blt_wg_problem> probs;
             std::vector<int> wg0;
-            const int nwg = blt_wgrad_group_plan(pending_wgrads, probs, wg0);
+            int bm = 128;
+            const int nwg = blt_wgrad_group_plan(pending_wgrads, probs, wg0, &bm);
             char* dev = wg_pool + (size_t)flush_idx * WG_SLOT_BYTES;
             const size_t pb = probs.size() * sizeof(blt_wg_problem), pb_al = (pb + 63) / 64 * 64;
-            if (!t.valid || t.nwg != nwg || t.probs.size() != probs.size() || memcmp(t.probs.data(), probs.data(), pb) != 0) {
-                t.probs = probs; t.wg0 = wg0; t.nwg = nwg; t.valid = true;
+            if (!t.valid || t.nwg != nwg || t.bm != bm || t.probs.size() != probs.size() || memcmp(t.probs.data(), probs.data(), pb) != 0) {
+                t.probs = probs; t.wg0 = wg0; t.nwg = nwg; t.bm = bm; t.valid = true;
                 if (hipMemcpyAsync(dev, t.probs.data(), pb, hipMemcpyHostToDevice, to) != hipSuccess ||
                     hipMemcpyAsync(dev + pb_al, t.wg0.data(), t.wg0.size() * 4, hipMemcpyHostToDevice, to) != hipSuccess) {
                     blt_set_error("flush_wgrads: table upload failed");
@@ -608,7 +609,7 @@ struct bltvqg_engine {
             double fl = 0.0;
             for (const GemmArgs& g : pending_wgrads) fl += 2.0 * (double)g.M * (double)g.N * (double)g.K;
             const int pi = (prof_mask & 2) ? prof_begin(1, to) : -1;
-            rc = blt_wgrad_group_launch((const blt_wg_problem*)dev, (const int*)(dev + pb_al), (int)t.probs.size(), nwg, to);
+            rc = blt_wgrad_group_launch((const blt_wg_problem*)dev, (const int*)(dev + pb_al), (int)t.probs.size(), nwg, bm, to);
             prof_end(pi, to, fl);
             ++flush_idx;
         } else {

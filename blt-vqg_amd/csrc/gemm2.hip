@@ -345,20 +345,24 @@ int launch_nt2(const GemmArgs& a, hipStream_t s) {
 // 16 waves (4 x 4, wave tile 32 x 32): four waves per SIMD.  The per-wave chain of a K-step (transposed reads -> lgkmcnt wait -> MFMAs,
 // twice) is latency-bound, so it is the number of waves interleaving on a SIMD that keeps the matrix pipe and the DMA queue fed: with 8
 // waves (2 per SIMD, wave tile 64 x 32) a K-step took 1.27 us against 0.47 us of LDS-DMA intake (PMC: 40 % of wave cycles in waits).
-struct WgCfg {
-    static constexpr int BM = 128, BN = 128, BK = 64, NWM = 4, NWN = 4, NW = NWM * NWN, NT = NW * 64;
+// Tile BM x 128 with BM = 256 (wave tile 64 x 32; 48 KB per K-step for twice the MFMA work of a 128 x 128 tile: 25 % less intake per flop
+// and the fixed cost of a K-step — barrier, waits — spread over twice the flops) or 128 (narrow gradients).
+template <int BM_>
+struct WgCfgT {
+    static constexpr int BM = BM_, BN = 128, BK = 64, NWM = 4, NWN = 4, NW = NWM * NWN, NT = NW * 64;
     static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
-    static constexpr int A_BYTES = BK * 256, B_BYTES = BK * 256, STAGE = A_BYTES + B_BYTES;      // 32 KB
-    static constexpr int CH = 1024 / NT, PER_STAGE = 2 * CH;          // DMA wave-instructions per wave per stage: CH for A, CH for B
-    static constexpr int NST = 4, AHEAD = 3;
+    static constexpr int A_ROW = BM * 2, A_BYTES = BK * A_ROW, B_BYTES = BK * 256, STAGE = A_BYTES + B_BYTES;      // 32 / 48 KB
+    static constexpr int CH_A = BK * (BM / 8) / NT, CH_B = BK * 16 / NT, PER_STAGE = CH_A + CH_B;      // DMA wave-instructions per wave per stage
+    static constexpr int NST = (BM == 256) ? 3 : 4, AHEAD = NST - 1;
     static constexpr int LDS = NST * STAGE + 1024;       // + the table's workgroup offsets
-    static_assert(CH >= 1 && TM >= 1 && TN == 2, "wave layout");
+    static_assert(CH_A >= 1 && CH_B >= 1 && (TM == 2 || TM == 4) && TN == 2 && LDS <= 160 * 1024, "wave layout");
 };
+typedef WgCfgT<128> WgCfg;
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
-__global__ __launch_bounds__(WgCfg::NT) void wgrad_group_kernel(const blt_wg_problem* __restrict__ probs, const int* __restrict__ wg0, int nprob) {
-    typedef WgCfg C;
+template <typename C>
+__global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem* __restrict__ probs, const int* __restrict__ wg0, int nprob) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -398,26 +402,34 @@ __global__ __launch_bounds__(WgCfg::NT) void wgrad_group_kernel(const blt_wg_pro
 
     // DMA instruction j of this wave covers chunks c = (j*8 + wave)*64 + lane of a [64][16-chunk] tile: token row c >> 4, LDS slot
     // c & 15 <- source chunk (c & 15) ^ f(row)
-    int a_row[C::CH], b_row[C::CH];
-    long a_off[C::CH], b_off[C::CH];
+    // (A rows are BM * 2 bytes: BM / 8 chunks, swizzled inside each 256-byte half)
+    int a_row[C::CH_A], b_row[C::CH_B];
+    long a_off[C::CH_A], b_off[C::CH_B];
+    constexpr int ACH = C::BM / 8;          // chunks per A row (16 or 32)
 #pragma unroll
-    for (int j = 0; j < C::CH; ++j) {
+    for (int j = 0; j < C::CH_A; ++j) {
+        const int c = (j * C::NW + wave) * 64 + lane;
+        const int row = c / ACH, slot = c % ACH, gc = (slot & ~15) | ((slot & 15) ^ wg_swz(row));
+        a_row[j] = row;
+        a_off[j] = (m0 + gc * 8 < a_cols) ? (long)row * P.lda + m0 + gc * 8 : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < C::CH_B; ++j) {
         const int c = (j * C::NW + wave) * 64 + lane;
         const int row = c >> 4, gc = (c & 15) ^ wg_swz(row);
-        a_row[j] = row; b_row[j] = row;
-        a_off[j] = (m0 + gc * 8 < a_cols) ? (long)row * P.lda + m0 + gc * 8 : -1;
+        b_row[j] = row;
         b_off[j] = (n0 + gc * 8 < b_cols) ? (long)row * P.ldb + n0 + gc * 8 : -1;
     }
     auto issue_one = [&](int d, int kt, int stage) {      // kt relative to kt0; K-steps beyond the slice come from the zero page
         char* a_st = smem + stage * C::STAGE;
         char* b_st = a_st + C::A_BYTES;
         const long t0 = (long)(kt0 + kt) * C::BK;
-        if (d < C::CH) {
+        if (d < C::CH_A) {
             const int j = d;
             const bool ok = kt < nk && a_off[j] >= 0 && t0 + a_row[j] < P.Mtok;
             dma16b(ok ? (const void*)(Ag + t0 * P.lda + a_off[j]) : zero, a_st + (j * C::NW + wave) * 1024);
         } else {
-            const int j = d - C::CH;
+            const int j = d - C::CH_A;
             const bool ok = kt < nk && b_off[j] >= 0 && t0 + b_row[j] < P.Mtok;
             dma16b(ok ? (const void*)(Bg + t0 * P.ldb + b_off[j]) : zero, b_st + (j * C::NW + wave) * 1024);
         }
@@ -466,9 +478,9 @@ __global__ __launch_bounds__(WgCfg::NT) void wgrad_group_kernel(const blt_wg_pro
                 }
 #pragma unroll
                 for (int i = 0; i < C::TM; ++i) {
-                    const int cb = wm * C::WM + i * 16 + tp * 4;
-                    alo[i] = lds_tr16b(a_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
-                    ahi[i] = lds_tr16b(a_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
+                    const int cb = wm * C::WM + i * 16 + tp * 4, hb = (cb >> 7) * 256, cl = cb & 127;      // 256-byte half of the row, column inside it
+                    alo[i] = lds_tr16b(a_st + r0 * C::A_ROW + hb + (((cl >> 3) ^ f0) << 4) + (cl & 4) * 2);
+                    ahi[i] = lds_tr16b(a_st + (r0 + 4) * C::A_ROW + hb + (((cl >> 3) ^ f1) << 4) + (cl & 4) * 2);
                 }
                 if constexpr (C::TM == 4) {
                     asm volatile("s_waitcnt lgkmcnt(0)"
@@ -597,10 +609,15 @@ bool blt_wgrad_group_ok(int dtype, const GemmArgs& a) {
            !a.R && !a.rowtab && !a.stat_sum && a.alpha == 1.f && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.lda >= ((a.M + 7) & ~7) &&
            a.ldb >= ((a.N + 7) & ~7) && ((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.B % 16) == 0;
 }
-// host table -> (problems, wg0); returns the number of workgroups.  Split-K only when the whole launch is short of tiles.
-int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_problem>& probs, std::vector<int>& wg0) {
+// host table -> (problems, wg0, tile rows); returns the number of workgroups.  256-row tiles when they still fill the chip; split-K only
+// when the whole launch is short of tiles.
+int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_problem>& probs, std::vector<int>& wg0, int* bm_out) {
+    long t256 = 0;
+    for (const GemmArgs& a : g) t256 += (long)cdiv(a.M, 256) * cdiv(a.N, 128);
+    const int forced = blt_debug_get(13);
+    const int bm = forced == 128 || forced == 256 ? forced : (t256 >= 256 ? 256 : 128);
     long tiles = 0;
-    for (const GemmArgs& a : g) tiles += (long)cdiv(a.M, 128) * cdiv(a.N, 128);
+    for (const GemmArgs& a : g) tiles += (long)cdiv(a.M, bm) * cdiv(a.N, 128);
     probs.clear(); wg0.clear();
     int wg = 0;
     for (const GemmArgs& a : g) {
@@ -608,7 +625,7 @@ int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_prob
         p.A = a.A; p.B = a.B; p.C = (float*)a.C; p.bias = a.a_rowsum;
         p.Nw = a.M; p.Kw = a.N; p.Mtok = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
         p.tiles_n = cdiv(a.N, 128);
-        const int t = cdiv(a.M, 128) * p.tiles_n;
+        const int t = cdiv(a.M, bm) * p.tiles_n;
         const int nk = cdiv(a.K, 64);
         int s = 1;
         if (tiles < 192) {                 // fewer tiles than CUs in the whole launch: slice K (>= 4 K-steps per slice)
@@ -625,18 +642,24 @@ int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_prob
         wg += t * s;
     }
     wg0.push_back(wg);
+    *bm_out = bm;
     return wg;
 }
-int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, hipStream_t s) {
-    BLT_REQUIRE(probs_dev && wg0_dev && nprob > 0 && nprob < 250 && nwg > 0, "wgrad_group: bad table");
+template <typename C>
+static int launch_wg(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, hipStream_t s) {
     static bool attr_set = false;
+    auto kern = wgrad_group_kernel<C>;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WgCfg::LDS) != hipSuccess) {
-            blt_set_error("wgrad_group: hipFuncSetAttribute(%d) failed", WgCfg::LDS);
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
+            blt_set_error("wgrad_group: hipFuncSetAttribute(%d) failed", C::LDS);
             return BLT_ERR_HIP;
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(wgrad_group_kernel, dim3((unsigned)nwg), dim3(WgCfg::NT), WgCfg::LDS, s, probs_dev, wg0_dev, nprob);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(C::NT), C::LDS, s, probs_dev, wg0_dev, nprob);
     return blt_check_launch("wgrad_group");
+}
+int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, int bm, hipStream_t s) {
+    BLT_REQUIRE(probs_dev && wg0_dev && nprob > 0 && nprob < 250 && nwg > 0 && (bm == 128 || bm == 256), "wgrad_group: bad table");
+    return bm == 256 ? launch_wg<WgCfgT<256>>(probs_dev, wg0_dev, nprob, nwg, s) : launch_wg<WgCfgT<128>>(probs_dev, wg0_dev, nprob, nwg, s);
 }

@@ -95,8 +95,8 @@ struct blt_wg_problem {
     int Nw, Kw, Mtok, lda, ldb, ldc, tiles_n, splits, accumulate, pad;
 };
 bool blt_wgrad_group_ok(int dtype, const GemmArgs& a);
-int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_problem>& probs, std::vector<int>& wg0);
-int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, hipStream_t s);
+int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_problem>& probs, std::vector<int>& wg0, int* tile_rows);
+int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, int tile_rows, hipStream_t s);
 
 // ---- padded-pitch 3x3 stride-1 convolution (conv_pp.hip), bf16 only ----------------
 long blt_pp_pixels(int N, int H, int W);                 // N*(H+1)*(W+1) positions (without the guards)

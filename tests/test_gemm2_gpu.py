@@ -111,7 +111,17 @@ def _wgrad_group(problems, table_bytes=1 << 16):
     return outs
 
 
-def test_wgrad_group_exact_stored_and_split():
+@pytest.mark.parametrize("tile_rows", [128, 256])
+def test_wgrad_group_exact_stored_and_split(tile_rows):
+    import gpu_ops as G
+    G.lib().bltvqg_debug_set(13, tile_rows)          # force the 128- / 256-row tile variant (the planner picks by launch size)
+    try:
+        _wgrad_group_cases()
+    finally:
+        G.lib().bltvqg_debug_set(13, 0)
+
+
+def _wgrad_group_cases():
     g = torch.Generator().manual_seed(11)
     # a "stack" of problems: enough tiles for the stored form (no split-K): ragged rows, widths that are not tile multiples, a padded ld
     big = []
@@ -136,8 +146,18 @@ def test_wgrad_group_exact_stored_and_split():
     assert torch.equal(b.cpu().double(), y.double().cpu().sum(0))
 
 
-def test_wgrad_group_strided_views_like_the_engine():
+@pytest.mark.parametrize("tile_rows", [128, 256])
+def test_wgrad_group_strided_views_like_the_engine(tile_rows):
     """The engine's fused q|k|v gradient [rows, 3H] against xn [rows, H], and the embedding's [rows, 320]-pitched operand with K = 300."""
+    import gpu_ops as G
+    G.lib().bltvqg_debug_set(13, tile_rows)
+    try:
+        _wgrad_strided_cases()
+    finally:
+        G.lib().bltvqg_debug_set(13, 0)
+
+
+def _wgrad_strided_cases():
     g = torch.Generator().manual_seed(3)
     rows, H = 1260, 256
     gqkv = _ints((rows, 3 * H), -2, 2, g).bfloat16().cuda()

@@ -394,3 +394,42 @@ def test_out_of_range_token_ids_are_reported_not_dereferenced():
     # the next clean batch clears the flag
     _run(e, batch, True, 0.5)
     assert e.stats()["bad_ids"] == 0.0
+
+
+def test_trusted_weight_shadows_equal_a_full_refresh():
+    """bf16 engine driven by DataParallelStep (which promises that only the engine's optimiser writes the parameters): the update writes
+    the plain bf16 weight shadow itself and forward only derives the transposed copies.  After steps on both sides of the phase switch the
+    forward must be BIT-identical to that of a fresh engine that loads the same parameters (and rebuilds every shadow from fp32)."""
+    import bltvqg_amd.synthetic as synthetic
+    from bltvqg_amd.trainer import DataParallelStep
+    z, cfg, state, batch0 = load_golden("tiny")
+    B, hw = int(z["meta_cfg"][7]), int(z["meta_cfg"][8])
+    e = _engine(cfg, B, hw, 1)
+    e.load_state(state)
+    dp = DataParallelStep(e, None, overlap_optimizer=True)
+    for i, phase2 in enumerate((False, False, True, True)):
+        b = synthetic.make_batch(B, cfg.vocab_size, cfg.latent_dim, seed=700 + i, image_hw=hw)
+        d = {k: v.cuda() for k, v in b.items()}
+        dp.run(d["images"], d["answers"], d["posteriors"], d["questions"], d["eps"] if phase2 else None, phase2, seed=i, kl_weight=0.3, lr=1e-3)
+    dp.finish()
+    probe = {k: v.cuda() for k, v in batch0.items()}
+    e.forward(probe["images"], probe["answers"], probe["posteriors"], probe["questions"], probe["eps"], True, 0)
+    out1, zl1 = e.read(0).clone(), e.read(1).clone()
+    e.loss_backward(0.3)
+    g1 = e.flat_grad.clone()
+    torch.cuda.synchronize()
+    fresh = _engine(cfg, B, hw, 1)
+    fresh.load_state({n: e.view(n, 0).clone() for n in e.train_info} | {n: e.view(n, 1).clone() for n in e.frozen_info})
+    fresh.forward(probe["images"], probe["answers"], probe["posteriors"], probe["questions"], probe["eps"], True, 0)
+    out2, zl2 = fresh.read(0), fresh.read(1)
+    fresh.loss_backward(0.3)
+    torch.cuda.synchronize()
+    assert torch.equal(out1, out2) and torch.equal(zl1, zl2)                    # forward: same shadows, bit for bit
+    assert rel_err(g1.cpu(), fresh.flat_grad.cpu()) < 1e-4                       # backward reads the TRANSPOSED shadows (float-atomic order only)
+    # a write from outside (load_state) must invalidate the shortcut: perturb, reload, compare with the fresh engine again
+    pert = {n: e.view(n, 0).clone() for n in e.train_info} | {n: e.view(n, 1).clone() for n in e.frozen_info}
+    pert["decoder.output.weight"] = pert["decoder.output.weight"] * 1.5
+    e.load_state(pert); fresh.load_state(pert)
+    e.forward(probe["images"], probe["answers"], probe["posteriors"], probe["questions"], probe["eps"], True, 0)
+    fresh.forward(probe["images"], probe["answers"], probe["posteriors"], probe["questions"], probe["eps"], True, 0)
+    assert torch.equal(e.read(0), fresh.read(0))

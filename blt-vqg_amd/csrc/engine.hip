@@ -76,6 +76,9 @@ struct bltvqg_engine {
     size_t ln_pool_floats = 0, ln_pool_used = 0;
     std::vector<LnRed> pending_ln;
     bool regions = false;       // BASELINE configs[4]: the image input is [B, num_regions, region_dim] precomputed features
+    bool region_attn = false;   // ... pooled by region attention instead of the mean
+    void *xr = nullptr, *Pr = nullptr, *dPr = nullptr;      // bf16/fp32 copy of the regions [B*R, D], projected regions [B*R, H] and their gradient
+    float* ralpha = nullptr;    // attention weights [B, R]
     int FD = 512;               // width of the pooled feature the trainable head projects (512 = ResNet-18, region_dim in region mode)
     std::string fcw, fcb;       // the head's projection: encoder_cnn.cnn.fc.* (encoder_cnn.py:20) or encoder_cnn.region_proj.*
     std::vector<PInfo> tp, fp;
@@ -297,6 +300,7 @@ struct bltvqg_engine {
         add_t("embedding.0.weight", V, E, 0);
         add_t(fcw, H, FD, 0);
         add_t(fcb, H, 0, 0);
+        if (region_attn) add_t("encoder_cnn.region_attn.weight", 1, H, 0);
         add_t("encoder_cnn.bn.weight", H, 0, 0);
         add_t("encoder_cnn.bn.bias", H, 0, 0);
         bucket_off[1] = bucket_len[0]; bucket_len[1] = tsize - bucket_len[0]; bucket_late[1] = 0;
@@ -321,14 +325,15 @@ struct bltvqg_engine {
         // ---- transposed-shadow table: every weight that appears as the B operand of an input-gradient GEMM ----
         auto ends_with = [](const std::string& a, const char* suf) { const size_t n = strlen(suf); return a.size() >= n && a.compare(a.size() - n, n, suf) == 0; };
         for (const PInfo& p : tp) {
-            if (p.ndim != 2 || p.name == "embedding.0.weight" || p.name == fcw) continue;
+            if (p.ndim != 2 || p.name == "embedding.0.weight" || p.name == "encoder_cnn.region_attn.weight") continue;
+            if (p.name == fcw && !region_attn) continue;      // the CNN / mean-pool head runs in fp32 on the master weights: no shadow
             int rows = p.dims[0];
             const bool encdec = p.name.find("multi_head_attention_enc_dec.") != std::string::npos;
             if (ends_with(p.name, "value_linear.weight")) continue;                       // part of a fused group
             if (ends_with(p.name, "key_linear.weight")) { if (!encdec) continue; rows = 2 * H; }      // enc-dec k|v
             if (ends_with(p.name, "query_linear.weight") && !encdec) rows = 3 * H;          // self-attention q|k|v
             // ld of the transposed operand must be 16-byte aligned; otherwise only the plain shadow is written (cols < 0 flags it)
-            const bool tr = (rows % 8 == 0);
+            const bool tr = (rows % 8 == 0) && p.name != fcw;      // (the region projection's input has no gradient: plain shadow only)
             TEnt t; t.off = (int)p.off; t.rows = rows; t.cols = tr ? p.dims[1] : -p.dims[1]; t.tile0 = ttiles;
             ttiles += ((rows + 63) / 64) * ((p.dims[1] + 63) / 64);
             tlist.push_back(t);
@@ -429,6 +434,11 @@ struct bltvqg_engine {
             char* base_ = (char*)AT((BLT_PP_GUARD_FRONT + blt_pp_pixels(B, ph, pw) + BLT_PP_GUARD_TAIL) * 64);
             pool0 = (void*)((uintptr_t)base_ + (size_t)BLT_PP_GUARD_FRONT * 64 * es);
         }
+        if (region_attn) {
+            const int64_t BR = (int64_t)B * c.num_regions;
+            xr = AT(BR * FD); Pr = AT(BR * H); dPr = AT(BR * H);
+            ralpha = AF(BR);
+        }
         pooled = AF((int64_t)B * FD);
         featpre = AF((int64_t)B * H); feats32 = AF((int64_t)B * H); dfeats32 = AF((int64_t)B * H); dfeatpre32 = AF((int64_t)B * H);
         feats = AT((int64_t)B * H);
@@ -497,6 +507,7 @@ struct bltvqg_engine {
             imgWp = (imgWp + 1) / 2 * 2;
         }
         regions = c.num_regions > 0;
+        region_attn = regions && c.region_pool == 1;
         FD = regions ? c.region_dim : 512;
         fcw = regions ? "encoder_cnn.region_proj.weight" : "encoder_cnn.cnn.fc.weight";
         fcb = regions ? "encoder_cnn.region_proj.bias" : "encoder_cnn.cnn.fc.bias";
@@ -861,6 +872,14 @@ struct bltvqg_engine {
     int cnn_fwd(const float* images, hipStream_t s) {
         if (regions) {
             RC(sync_opt(s));
+            if (region_attn) {
+                // p_r = Linear(D -> H)(x_r) for every region (one GEMM over [B*R, D]), then attention pooling -> the BatchNorm1d input
+                const int BR = B * c.num_regions;
+                RC(blt_cast_rows(BLT_F32, images, FD, dt, xr, FD, BR, FD, s));
+                RC(gemm(dt, lin(xr, FD, fcw, fcb.c_str(), Pr, H, BR), s));
+                RC(blt_region_attn_fwd(dt, Pr, P("encoder_cnn.region_attn.weight"), featpre, ralpha, B, c.num_regions, H, s));
+                return cnn_head_fwd(s);
+            }
             RC(blt_avgpool(BLT_F32, images, pooled, B, c.num_regions, FD, 1, s));
             return cnn_head_fwd(s);
         }
@@ -906,7 +925,7 @@ struct bltvqg_engine {
     }
 
     int cnn_head_fwd(hipStream_t s) {
-        {
+        if (!region_attn) {      // (region attention: featpre already holds the pooled projection)
             const PInfo& pw = tpi(fcw);
             GemmArgs g = mk(pooled, FD, 0, train + pw.off, FD, 0, featpre, H, B, H, FD);
             g.bias = P(fcb);
@@ -1228,6 +1247,12 @@ struct bltvqg_engine {
         RC(blt_cast_rows(dt, d_feats, H, BLT_F32, dfeats32, H, B, H, s));
         RC(blt_bn1d_bwd(BLT_F32, dfeats32, featpre, P("encoder_cnn.bn.weight"), bn1_mean, bn1_rstd, dfeatpre32, G("encoder_cnn.bn.weight"),
                         G("encoder_cnn.bn.bias"), B, H, s));
+        if (region_attn) {
+            const int BR = B * c.num_regions;
+            RC(blt_region_attn_bwd(dt, Pr, P("encoder_cnn.region_attn.weight"), ralpha, dfeatpre32, dPr, G("encoder_cnn.region_attn.weight"), B,
+                                   c.num_regions, H, s));
+            return wgrad(dPr, H, xr, FD, fcw, fcb.c_str(), BR, s);      // dW = dP^T X, db = column sums of dP (the regions have no gradient)
+        }
         const PInfo& pw = tpi(fcw);
         GemmArgs g = mk(dfeatpre32, H, 1, pooled, FD, 1, grad + pw.off, FD, H, FD, B);
         g.accumulate = 1; g.a_rowsum = G(fcb);
@@ -1458,7 +1483,8 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
         c.pwffn_dim % 8 != 0 || c.latent_dim % 8 != 0 || c.emb_dim <= 0 || c.num_layers <= 0 || c.vocab_size < 6 ||
         c.len_context <= 0 || c.len_context > 64 || c.len_posterior <= 0 || c.len_posterior > 64 || c.len_target < 2 || c.len_target > 64 ||
         (c.num_regions <= 0 && (c.image_h < 32 || c.image_w < 32)) || c.num_regions < 0 ||
-        (c.num_regions > 0 && (c.region_dim < 8 || c.region_dim % 8 != 0)) || (c.dtype != BLT_F32 && c.dtype != BLT_BF16) || c.hidden_dim > 2048 ||
+        (c.num_regions > 0 && (c.region_dim < 8 || c.region_dim % 8 != 0)) || c.region_pool < 0 || c.region_pool > 1 ||
+        (c.region_pool == 1 && (c.num_regions <= 0 || c.num_regions > 64)) || (c.dtype != BLT_F32 && c.dtype != BLT_BF16) || c.hidden_dim > 2048 ||
         c.attention_dropout < 0.f || c.attention_dropout >= 1.f || c.relu_dropout < 0.f || c.relu_dropout >= 1.f) {
         blt_set_error("engine_create: unsupported configuration (need H,F,Z %% 8 == 0, H %% heads == 0, H <= 2048, sequence lengths <= 64, images >= 32x32 or region_dim %% 8 == 0)");
         return nullptr;

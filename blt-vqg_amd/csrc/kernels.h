@@ -221,6 +221,12 @@ int blt_latent_fwd(int dtype, const void* mlv_p, const void* mlv_q, const float*
 int blt_latent_bwd(int dtype, const void* mlv_p, const void* mlv_q, const float* eps, const void* dz, float kld_gscale,
                    void* dmlv_p, void* dmlv_q, int B, int Z, int ld, hipStream_t s);
 
+// ---- region-attention pooling (bottom-up mode) ---------------------------------------------------------
+// P [B, R, H] projected regions; w [H]; out [B, H] fp32; alpha [B, R] fp32 (saved for backward); dP [B, R, H]; dw [H] += (atomics)
+int blt_region_attn_fwd(int dtype, const void* P, const float* w, float* out, float* alpha, int B, int R, int H, hipStream_t s);
+int blt_region_attn_bwd(int dtype, const void* P, const float* w, const float* alpha, const float* dout, void* dP, float* dw, int B, int R, int H,
+                        hipStream_t s);
+
 // ---- greedy decoding ----------------------------------------------------------------------------------
 int blt_prep_decode(const long long* ctx, int B, int Sa, int T, int* ids_all, int* pos_all, int* ctx32, int V, float* bad_ids, hipStream_t s);
 int blt_argmax_top6(int dtype, const void* logits, int ld, int B, int V, int t, int T, int* ys, int* tokens, int* top_idx, float* top_val,

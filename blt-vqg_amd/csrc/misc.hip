@@ -689,6 +689,72 @@ __global__ __launch_bounds__(256) void shadow_transpose_bf16_kernel(const bf16* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Region-attention pooling of the bottom-up mode (bltvqg_config::region_pool = 1): one workgroup per sample.
+//   s_r = w . tanh(p_r);  alpha = softmax_r(s);  out[h] = sum_r alpha_r p[r][h]        (p = projected regions [B, R, H])
+// backward: dalpha_r = dout . p_r; ds = alpha * (dalpha - sum alpha dalpha); dp[r][h] = alpha_r dout[h] + ds_r w[h] (1 - tanh^2 p[r][h]);
+//           dw[h] += sum_r ds_r tanh(p[r][h])
+// ---------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void region_attn_fwd_kernel(const T* __restrict__ P, const float* __restrict__ w, float* __restrict__ out,
+                                                             float* __restrict__ alpha, int R, int H) {
+    __shared__ float sc[64];
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* p = P + (size_t)b * R * H;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int h = lane; h < H; h += 64) acc += w[h] * tanhf(to_f32(p[(size_t)r * H + h]));
+        acc = wave_sum(acc);
+        if (lane == 0) sc[r] = acc;
+    }
+    __syncthreads();
+    float v = (tid < R) ? sc[tid] : -INFINITY;
+    const float m = block_max(v, red);
+    const float e = (tid < R) ? __expf(v - m) : 0.f;
+    const float tot = block_sum(e, red);
+    __syncthreads();
+    if (tid < R) { sc[tid] = e / tot; alpha[(size_t)b * R + tid] = e / tot; }
+    __syncthreads();
+    for (int h = tid; h < H; h += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += sc[r] * to_f32(p[(size_t)r * H + h]);
+        out[(size_t)b * H + h] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void region_attn_bwd_kernel(const T* __restrict__ P, const float* __restrict__ w, const float* __restrict__ alpha,
+                                                             const float* __restrict__ dout, T* __restrict__ dP, float* __restrict__ dw, int R, int H) {
+    __shared__ float da[64], ds[64];
+    __shared__ float red[16];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* p = P + (size_t)b * R * H;
+    const float* g = dout + (size_t)b * H;
+    for (int r = wave; r < R; r += 4) {
+        float acc = 0.f;
+        for (int h = lane; h < H; h += 64) acc += g[h] * to_f32(p[(size_t)r * H + h]);
+        acc = wave_sum(acc);
+        if (lane == 0) da[r] = acc;
+    }
+    __syncthreads();
+    const float a = (tid < R) ? alpha[(size_t)b * R + tid] : 0.f;
+    const float dot = block_sum((tid < R) ? a * da[tid] : 0.f, red);
+    __syncthreads();
+    if (tid < R) { ds[tid] = a * (da[tid] - dot); da[tid] = a; }          // da now holds alpha
+    __syncthreads();
+    for (int h = tid; h < H; h += 256) {
+        const float gh = g[h], wh = w[h];
+        float dwh = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const float t = tanhf(to_f32(p[(size_t)r * H + h]));
+            dP[((size_t)b * R + r) * H + h] = from_f32<T>(da[r] * gh + ds[r] * wh * (1.f - t * t));
+            dwh += ds[r] * t;
+        }
+        atomicAdd(dw + h, dwh);
+    }
+}
+
 __global__ void dropout_mask_kernel(uint64_t seed, uint32_t stream_id, long rows, int cols, int ld_index, uint32_t thresh,
                                     unsigned char* __restrict__ out) {
     const long total = rows * cols;
@@ -946,4 +1012,20 @@ int blt_dropout_mask(uint64_t seed, uint32_t stream_id, long rows, int cols, int
     BLT_REQUIRE(out && rows > 0 && cols > 0 && ld_index >= cols && p >= 0.f && p < 1.f, "dropout_mask: bad args");
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(ew_grid(rows * cols)), dim3(256), 0, s, seed, stream_id, rows, cols, ld_index, dropout_threshold(p), out);
     return blt_check_launch("dropout_mask");
+}
+
+int blt_region_attn_fwd(int dtype, const void* P, const float* w, float* out, float* alpha, int B, int R, int H, hipStream_t s) {
+    CHECK_DTYPE(dtype, "region_attn_fwd");
+    BLT_REQUIRE(P && w && out && alpha && B > 0 && R > 0 && R <= 64 && H > 0, "region_attn_fwd: bad args (regions <= 64)");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(region_attn_fwd_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)P, w, out, alpha, R, H);
+    else hipLaunchKernelGGL(region_attn_fwd_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)P, w, out, alpha, R, H);
+    return blt_check_launch("region_attn_fwd");
+}
+int blt_region_attn_bwd(int dtype, const void* P, const float* w, const float* alpha, const float* dout, void* dP, float* dw, int B, int R, int H,
+                        hipStream_t s) {
+    CHECK_DTYPE(dtype, "region_attn_bwd");
+    BLT_REQUIRE(P && w && alpha && dout && dP && dw && B > 0 && R > 0 && R <= 64 && H > 0, "region_attn_bwd: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(region_attn_bwd_kernel<float>, dim3(B), dim3(256), 0, s, (const float*)P, w, alpha, dout, (float*)dP, dw, R, H);
+    else hipLaunchKernelGGL(region_attn_bwd_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)P, w, alpha, dout, (bf16*)dP, dw, R, H);
+    return blt_check_launch("region_attn_bwd");
 }

@@ -101,7 +101,8 @@ class IQ(nn.Module):
     latent_dim, pwffn_dim, num_layers, num_heads, device, emb_file, root_dir (+ optional: precision in {"bf16","fp32"},
     attention_dropout, relu_dropout, resnet_weights = path of a torchvision resnet18 state dict; num_regions + region_dim > 0 =
     bottom-up feature mode, BASELINE configs[4]: `images` is then a [B, num_regions, region_dim] tensor of precomputed region
-    features and `encoder_cnn` holds `region_proj` + `bn` instead of the ResNet — the reference has no such mode, SURVEY A2')."""
+    features and `encoder_cnn` holds `region_proj` + `bn` instead of the ResNet — the reference has no such mode, SURVEY A2';
+    region_pool = "attention" adds region-attention pooling with the extra parameter `encoder_cnn.region_attn.weight`)."""
 
     def __init__(self, latent_transformer, vocab, args, num_att_layers=2):
         super().__init__()
@@ -149,7 +150,7 @@ class IQ(nn.Module):
                           (h, w), self._dtype, p_attn, p_relu,
                           float(getattr(a, "kl_ceiling", 0.5)), float(getattr(a, "aux_ceiling", 1.0)),
                           float(getattr(a, "image_recon_lambda", 0.1)), int(getattr(a, "num_regions", 0) or 0),
-                          int(getattr(a, "region_dim", 0) or 0))
+                          int(getattr(a, "region_dim", 0) or 0), getattr(a, "region_pool", 0) or 0)
         e = StepEngine(cfg, device if allocate else "cpu")
         return e
 
@@ -295,7 +296,7 @@ class IQ(nn.Module):
             a = self.args
             cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size,
                               answers.shape[1], 21, T, (h, w), self._dtype, 0.0, 0.0, num_regions=int(getattr(a, "num_regions", 0) or 0),
-                              region_dim=int(getattr(a, "region_dim", 0) or 0))
+                              region_dim=int(getattr(a, "region_dim", 0) or 0), region_pool=getattr(a, "region_pool", 0) or 0)
             eng = StepEngine(cfg, images.device)
             if self._primary is None:
                 eng.allocate()

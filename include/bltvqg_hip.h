@@ -243,6 +243,11 @@ typedef struct bltvqg_config {
      * replaces the ResNet by mean_r(Linear(region_dim -> H)(x_r)) -> the same BatchNorm1d (parameters encoder_cnn.region_proj.{weight,
      * bias}, encoder_cnn.bn.*); image_h / image_w are ignored.  0 = image mode.  region_dim % 8 == 0. */
     int32_t num_regions, region_dim;
+    /* Region pooling of the bottom-up mode (the reference names the model "Bottom-Up" but has no region code, README.md:2):
+     * 0 = mean over the regions (above); 1 = region-attention pooling: p_r = Linear(region_dim -> H)(x_r), s_r = w_a . tanh(p_r),
+     * alpha = softmax_r(s), feature = sum_r alpha_r p_r -> the same BatchNorm1d.  w_a is the extra parameter
+     * encoder_cnn.region_attn.weight [1, H].  Defined by this build, parity against the oracle's restatement only. */
+    int32_t region_pool;
 } bltvqg_config;
 
 typedef struct bltvqg_engine bltvqg_engine;

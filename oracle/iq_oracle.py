@@ -66,6 +66,8 @@ def iq_spec(cfg):
     if getattr(cfg, "num_regions", 0) > 0:       # BASELINE configs[4] / SURVEY A2': precomputed region features, no backbone
         spec["encoder_cnn.region_proj.weight"] = (H, cfg.region_dim)
         spec["encoder_cnn.region_proj.bias"] = (H,)
+        if getattr(cfg, "region_pool", 0) in (1, "attention"):      # region-attention pooling (build-defined)
+            spec["encoder_cnn.region_attn.weight"] = (1, H)
     else:
         for k, s in resnet18_spec().items():
             spec["encoder_cnn.cnn." + k] = s
@@ -279,7 +281,14 @@ def encoder_cnn(P, images, train=True, buffers_out=None):
         # Bottom-up path (BASELINE configs[4]).  NO reference symbol exists (SURVEY A2'): the build's definition, as the survey proposes,
         # is mean over the regions of Linear(D -> H)(x_r), then the same BatchNorm1d.  images: [B, regions, D].  Parity for this path is
         # against this restatement only ("parity unpinned").
-        f = F.linear(images, P["encoder_cnn.region_proj.weight"], P["encoder_cnn.region_proj.bias"]).mean(dim=1)
+        p = F.linear(images, P["encoder_cnn.region_proj.weight"], P["encoder_cnn.region_proj.bias"])      # [B, regions, H]
+        if "encoder_cnn.region_attn.weight" in P:
+            # Region-attention pooling (no reference symbol either — README.md:2 only names the model "Bottom-Up"): a learned
+            # vector scores every projected region, s_r = w_a . tanh(p_r); alpha = softmax over the regions; feature = sum_r alpha_r p_r
+            sc = F.linear(torch.tanh(p), P["encoder_cnn.region_attn.weight"]).squeeze(-1)              # [B, regions]
+            f = (torch.softmax(sc, dim=1).unsqueeze(-1) * p).sum(dim=1)
+        else:
+            f = p.mean(dim=1)
     else:
         pooled = resnet18_features(P, "encoder_cnn.cnn.", images, train, buffers_out)
         f = F.linear(pooled, P["encoder_cnn.cnn.fc.weight"], P["encoder_cnn.cnn.fc.bias"])

@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
 
 def test_config_struct_layout():
     import ctypes
-    assert ctypes.sizeof(_lib.Config) == 14 * 4 + 5 * 4 + 2 * 4      # + num_regions, region_dim
+    assert ctypes.sizeof(_lib.Config) == 14 * 4 + 5 * 4 + 3 * 4      # + num_regions, region_dim, region_pool
 
 
 def test_argument_validation_without_gpu():

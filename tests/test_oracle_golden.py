@@ -100,3 +100,28 @@ def test_oracle_greedy_decode_matches_reference(name, phase2):
     assert np.array_equal(tidx.numpy().astype(np.int32), z[tag + ".top_idx"])
     assert np.array_equal(toks.numpy().astype(np.int32), z[tag + ".top_idx"][:, :, 0])
     assert np.allclose(tval.numpy(), z[tag + ".top_val"], rtol=1e-4, atol=1e-7)
+
+
+def test_region_attention_oracle_definition():
+    """SURVEY N4 (build-defined, parity unpinned): the oracle's region-attention pooling equals its mean pooling when the scoring vector is
+    zero, is a convex combination of the projected regions otherwise, and follows the argmax region when the scores are sharp."""
+    from types import SimpleNamespace
+    from oracle import iq_oracle as O
+    torch.manual_seed(0)
+    B, R, D, H = 3, 5, 16, 8
+    x = torch.randn(B, R, D)
+    P = {"encoder_cnn.region_proj.weight": torch.randn(H, D) * 0.3, "encoder_cnn.region_proj.bias": torch.randn(H) * 0.1,
+         "encoder_cnn.bn.weight": torch.ones(H), "encoder_cnn.bn.bias": torch.zeros(H), "encoder_cnn.bn.running_mean": torch.zeros(H),
+         "encoder_cnn.bn.running_var": torch.ones(H), "encoder_cnn.bn.num_batches_tracked": torch.zeros((), dtype=torch.long)}
+    mean = O.encoder_cnn(dict(P), x, train=False)
+    Pa = dict(P)
+    Pa["encoder_cnn.region_attn.weight"] = torch.zeros(1, H)
+    assert torch.allclose(O.encoder_cnn(Pa, x, train=False), mean, atol=1e-6)
+    Pa["encoder_cnn.region_attn.weight"] = torch.randn(1, H) * 50.0
+    p = x @ P["encoder_cnn.region_proj.weight"].t() + P["encoder_cnn.region_proj.bias"]
+    best = (torch.tanh(p) @ Pa["encoder_cnn.region_attn.weight"].t()).squeeze(-1).argmax(dim=1)
+    want = p[torch.arange(B), best] / (1.0 + 1e-5) ** 0.5          # eval-mode BatchNorm with unit statistics
+    assert torch.allclose(O.encoder_cnn(Pa, x, train=False), want, atol=2e-2)      # softmax of scores 50x apart is one-hot up to ~1e-2
+    spec = O.iq_spec(SimpleNamespace(emb_dim=20, hidden_dim=64, latent_dim=64, pwffn_dim=128, num_layers=1, num_heads=4, vocab_size=97,
+                                     num_regions=36, region_dim=256, region_pool="attention"))
+    assert spec["encoder_cnn.region_attn.weight"] == (1, 64)

@@ -16,9 +16,9 @@ from synth import synth_state
 pytestmark = pytest.mark.gpu
 
 
-def _cfg(H, F, Z, L, h, E, V, R, D):
+def _cfg(H, F, Z, L, h, E, V, R, D, pool=0):
     return SimpleNamespace(emb_dim=E, hidden_dim=H, latent_dim=Z, pwffn_dim=F, num_layers=L, num_heads=h, vocab_size=V, num_regions=R,
-                           region_dim=D)
+                           region_dim=D, region_pool=pool)
 
 
 def _batch(cfg, B, seed):
@@ -34,7 +34,8 @@ def _batch(cfg, B, seed):
 def _engine(cfg, B, dtype):
     from bltvqg_amd.engine import StepEngine, make_config
     c = make_config(B, cfg.hidden_dim, cfg.pwffn_dim, cfg.latent_dim, cfg.emb_dim, cfg.num_layers, cfg.num_heads, cfg.vocab_size,
-                    dtype=dtype, attention_dropout=0.0, relu_dropout=0.0, num_regions=cfg.num_regions, region_dim=cfg.region_dim)
+                    dtype=dtype, attention_dropout=0.0, relu_dropout=0.0, num_regions=cfg.num_regions, region_dim=cfg.region_dim,
+                    region_pool=getattr(cfg, "region_pool", 0))
     e = StepEngine(c)
     e.allocate()
     return e
@@ -136,3 +137,66 @@ def test_region_mode_through_the_drop_in_api():
     for _ in range(3):
         t.fused_training_step(b)
     assert t.latent_transformer and np.isfinite(t.last_stats()["loss"])
+
+
+# ---- region-attention pooling (bltvqg_config::region_pool = 1).  Like the mean-pool head it has no reference symbol (README.md:2
+# only names the model "Bottom-Up"): the definition is this build's, the checker is the oracle's restatement of
+# it — "parity unpinned" — plus a property that ties it to the mean-pool definition: with a zero scoring vector the attention is uniform.
+@pytest.mark.parametrize("phase2", [False, True])
+def test_region_attention_fp32_matches_oracle(phase2):
+    from oracle import iq_oracle as O
+    cfg = _cfg(64, 128, 64, 2, 4, 20, 97, 36, 256, pool=1)
+    B = 6
+    state = synth_state(O.iq_spec(cfg), seed=31)
+    assert state["encoder_cnn.region_attn.weight"].shape == (1, 64)
+    state["encoder_cnn.region_attn.weight"] = state["encoder_cnn.region_attn.weight"] * 8.0      # far from uniform attention
+    batch = _batch(cfg, B, 31)
+    kliter = 5000 if phase2 else 0
+    ref = oracle_run(cfg, state, batch, phase2, kliter=kliter)
+    e = _engine(cfg, B, 0)
+    assert set(e.train_info) | set(e.frozen_info) | {"encoder_cnn.bn.num_batches_tracked"} == set(state)
+    e.load_state(state)
+    kl_w = O.kl_weight(kliter, 15000)
+    r = _run(e, batch, phase2, kl_w)
+    assert rel_err(r["feats"], ref["feats"]) < 2e-4
+    assert rel_err(r["output"], ref["out"]) < 2e-4
+    assert np.array_equal(r["output"].argmax(-1).numpy(), ref["out"].argmax(-1).numpy())
+    st = r["stats"]
+    total = st["rec"] + 0.1 * st["img"] + (0.5 * kl_w * st["kld"] + st["aux"] if phase2 else 0.0)
+    assert abs(total - float(ref["loss"])) < 1e-3
+    for n in ("encoder_cnn.region_proj.weight", "encoder_cnn.region_attn.weight", "encoder_cnn.bn.weight", "embedding.0.weight",
+              "decoder.decoder.dec.0.multi_head_attention_dec.query_linear.weight"):
+        g = ref["grads"][n]
+        assert rel_err(e.grad_view(n).cpu(), g) < 3e-3, (n, rel_err(e.grad_view(n).cpu(), g))
+
+
+def test_region_attention_with_zero_scores_is_mean_pooling_and_bf16_runs():
+    from oracle import iq_oracle as O
+    cfg_a = _cfg(64, 128, 64, 1, 4, 20, 97, 36, 256, pool=1)
+    cfg_m = _cfg(64, 128, 64, 1, 4, 20, 97, 36, 256, pool=0)
+    B = 8
+    state = synth_state(O.iq_spec(cfg_a), seed=32)
+    state["encoder_cnn.region_attn.weight"] = torch.zeros_like(state["encoder_cnn.region_attn.weight"])
+    batch = _batch(cfg_a, B, 32)
+    ea, em = _engine(cfg_a, B, 0), _engine(cfg_m, B, 0)
+    ea.load_state(state)
+    em.load_state({k: v for k, v in state.items() if k != "encoder_cnn.region_attn.weight"})
+    ra, rm = _run(ea, batch, True, 0.3), _run(em, batch, True, 0.3)
+    assert rel_err(ra["feats"], rm["feats"]) < 1e-5 and rel_err(ra["output"], rm["output"]) < 1e-5
+    assert rel_err(ea.grad_view("encoder_cnn.region_proj.weight").cpu(), em.grad_view("encoder_cnn.region_proj.weight").cpu()) < 1e-4
+    # bf16 engine at the configs[4] width: stated bf16 tolerance against the oracle
+    cfg = _cfg(512, 2048, 512, 2, 8, 300, 8000, 36, 2048, pool=1)
+    state = synth_state(O.iq_spec(cfg), seed=33)
+    batch = _batch(cfg, B, 33)
+    ref = oracle_run(cfg, state, batch, True, kliter=5000)
+    kl_w = O.kl_weight(5000, 15000)
+    e = _engine(cfg, B, 1)
+    e.load_state(state)
+    r = _run(e, batch, True, kl_w)
+    st = r["stats"]
+    total = st["rec"] + 0.1 * st["img"] + 0.5 * kl_w * st["kld"] + st["aux"]
+    print("region attention bf16: loss %.5f vs %.5f, logits rel %.4f" % (total, float(ref["loss"]), rel_err(r["output"], ref["out"])))
+    assert abs(total - float(ref["loss"])) < 2e-2 * float(ref["loss"]) and rel_err(r["output"], ref["out"]) < 5e-2
+    e.optimizer_step(1e-4, 5.0)
+    torch.cuda.synchronize()
+    assert torch.isfinite(e.flat_train).all()

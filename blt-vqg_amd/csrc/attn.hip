@@ -219,6 +219,377 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const AttnArgs a)
     matmul_store<T, true>(Pd, tp, a.Tq, a.Tk, dOs, dp, a.d, 1.f, (T*)a.dV, a.lddv, b, h, lane);      // dV = Pd^T dO
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// MFMA form (bf16, head dim 32/64/128, <= 32 queries and keys): ONE WAVE per (batch, head), no workgroup barrier anywhere.
+//
+// The VALU kernels above keep the head slices in LDS as fp32 and every product re-reads them: 2048 (batch, head) pairs x 5 products
+// x ~200 KB of LDS reads is ~27 us of LDS time per CU for the big configuration's backward — what they measured (32 us).  Here the
+// five products are v_mfma_f32_16x16x32_bf16 tiles on operands that sit in registers:
+//   * S^T = K.Q^T (not Q.K^T): the result has the QUERY on the lane (n = lane & 15) and 4 consecutive KEYS in the registers of lane
+//     group g, so (a) the softmax reduction over keys is 8 in-lane values + two cross-group shuffles, (b) the 4 keys share one Philox
+//     block of the dropout stream, and (c) P^T / dS^T are already the B operand of the products that sum over keys (O^T = V^T.P^T,
+//     dQ^T = K^T.dS^T) — with the key order inside the 32-wide k-step permuted (slot e of group g = key 4g+e for e < 4, 16+4g+e-4
+//     otherwise), which the other operand follows.
+//   * operands with the token on the k axis (V^T, K^T, Q^T, dO^T) come from a wave-private row-major LDS image of the head slice
+//     through ds_read_b64_tr_b16 (the transposing read), products that sum over QUERIES (dK, dV) take P / dS from a 32x32 LDS image
+//     the same way.  One wave writes and reads its own images: LDS operations of one wave complete in order, no barrier.
+// Rows / keys past Tq / Tk are zero operands; padded queries produce P = dS = 0 so that the query-summed products stay exact.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ s16x4 tr16(const char* p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)(p));
+}
+__device__ __forceinline__ bf16x8 join8(s16x4 lo, s16x4 hi) {
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& lo, const f32x4& hi) {
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { v[e] = (bf16)lo[e]; v[4 + e] = (bf16)hi[e]; }
+    return v;
+}
+// keep decisions of the 4 consecutive dropout elements e0 .. e0+3 (bit r = element e0 + r), same stream as dropout_keep()
+__device__ __forceinline__ uint32_t keep4(uint64_t seed, uint32_t sid, uint64_t e0, uint32_t thresh) {
+    uint32_t w[4];
+    dropout_words(seed, sid, e0 >> 3, w);
+    uint64_t lo = (uint64_t)w[0] | ((uint64_t)w[1] << 32), hi = (uint64_t)w[2] | ((uint64_t)w[3] << 32);
+    const int o = (int)(e0 & 7);
+    uint64_t lo2 = 0;
+    if (o > 4) {      // the 4 elements straddle two Philox blocks (only when Tk is not a multiple of 4)
+        dropout_words(seed, sid, (e0 >> 3) + 1, w);
+        lo2 = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+    }
+    uint32_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int k = o + r;
+        const uint64_t x = k < 4 ? lo : (k < 8 ? hi : lo2);
+        const uint32_t v = (uint32_t)(x >> ((k & 3) * 16)) & 0xFFFFu;
+        bits |= (v >= thresh ? 1u : 0u) << r;
+    }
+    return bits;
+}
+
+struct MfmaHead {
+    int b, h, hb, n16, g;
+};
+
+// S^T tile registers -> normalised probabilities (same layout).  st[jt][it][r]: key j = 16 jt + 4 g + r, query i = 16 it + n16.
+__device__ __forceinline__ void softmax_t(const AttnArgs& a, const MfmaHead& m, f32x4 (&st)[2][2], uint32_t (&masked)[2]) {
+    // masked[it] bit (4 jt + r): the logit was REPLACED (pad key / causal), no gradient flows through it
+    int kid[2][4];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * jt + 4 * m.g + r;
+            kid[jt][r] = (a.key_ids != nullptr && j < a.Tk) ? a.key_ids[m.b * a.Tk + j] : 1;
+        }
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 16 * it + m.n16;
+        float mx = -INFINITY;
+        masked[it] = 0;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * jt + 4 * m.g + r;
+                const bool msk = kid[jt][r] == 0 || (a.causal != 0 && j > i);
+                float v = st[jt][it][r] * a.scale;
+                if (msk) v = -1e18f;
+                if (j >= a.Tk || (a.causal == 2 && j > i)) v = -INFINITY;
+                if (msk) masked[it] |= 1u << (4 * jt + r);
+                st[jt][it][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(st[jt][it][r] - mx);      // -inf (key past Tk) -> 0
+                st[jt][it][r] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = (i < a.Tq) ? 1.f / sum : 0.f;       // padded queries: P = 0
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) st[jt][it][r] *= inv;
+    }
+}
+
+template <int D>
+__device__ __forceinline__ void load_slice(const bf16* __restrict__ X, int ld, int T, const MfmaHead& m, bf16x8 (&f)[2][D / 32], char* img) {
+    constexpr int PITCH = D * 2 + 16;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int row = 16 * t + m.n16;
+#pragma unroll
+        for (int ks = 0; ks < D / 32; ++ks) {
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            if (row < T) v = *reinterpret_cast<const bf16x8*>(X + (size_t)row * ld + ks * 32 + m.g * 8);
+            f[t][ks] = v;
+            if (img != nullptr) *reinterpret_cast<bf16x8*>(img + row * PITCH + (ks * 32 + m.g * 8) * 2) = v;
+        }
+    }
+}
+
+// X^T operand of c-tile ct from a row-major [token][D] image: PERM = keys in the permuted slot order of P^T / dS^T, else tokens 8g..8g+7
+template <int D, bool PERM>
+__device__ __forceinline__ bf16x8 tr_operand(const char* img, int ct, const MfmaHead& m) {
+    constexpr int PITCH = D * 2 + 16;
+    const int q = m.n16 >> 2, p = m.n16 & 3;
+    const int r0 = PERM ? 4 * m.g : 8 * m.g, r1 = PERM ? 16 + 4 * m.g : 8 * m.g + 4;
+    const s16x4 lo = tr16(img + (r0 + q) * PITCH + (ct * 16 + 4 * p) * 2);
+    const s16x4 hi = tr16(img + (r1 + q) * PITCH + (ct * 16 + 4 * p) * 2);
+    return join8(lo, hi);
+}
+
+constexpr int ATT_PP = 72;      // row pitch (bytes) of the 32 x 32 bf16 P / dS images
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
+    constexpr int KS = D / 32, CT = D / 16, PITCH = D * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    MfmaHead m;
+    m.hb = blockIdx.x * 4 + w;
+    if (m.hb >= a.B * a.heads) return;          // whole wave leaves: the transposing reads below need a full EXEC mask
+    m.b = m.hb / a.heads; m.h = m.hb % a.heads; m.n16 = lane & 15; m.g = lane >> 4;
+    char* vimg = smc + w * (32 * PITCH);
+    bf16x8 kf[2][KS], qf[2][KS], vf[2][KS];
+    load_slice<D>((const bf16*)a.K + (size_t)m.b * a.Tk * a.ldk + m.h * D, a.ldk, a.Tk, m, kf, nullptr);
+    load_slice<D>((const bf16*)a.Q + (size_t)m.b * a.Tq * a.ldq + m.h * D, a.ldq, a.Tq, m, qf, nullptr);
+    load_slice<D>((const bf16*)a.V + (size_t)m.b * a.Tk * a.ldv + m.h * D, a.ldv, a.Tk, m, vf, vimg);
+    f32x4 st[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            st[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) st[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[it][ks], st[jt][it], 0, 0, 0);
+        }
+    uint32_t masked[2];
+    softmax_t(a, m, st, masked);
+    if (a.drop_p > 0.f) {
+        const uint32_t thresh = dropout_threshold(a.drop_p);
+        const float ks_ = 1.f / (1.f - a.drop_p);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = 16 * it + m.n16;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int j0 = 16 * jt + 4 * m.g;
+                if (i < a.Tq && j0 < a.Tk) {
+                    const uint32_t keep = keep4(a.seed, a.stream_id, ((uint64_t)m.hb * a.Tq + i) * a.Tk + j0, thresh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[jt][it][r] = ((keep >> r) & 1u) ? st[jt][it][r] * ks_ : 0.f;
+                }
+            }
+        }
+    }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) pb[it] = pack8(st[0][it], st[1][it]);
+    bf16* O = (bf16*)a.O + (size_t)m.b * a.Tq * a.ldo + m.h * D;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const bf16x8 vt = tr_operand<D, true>(vimg, ct, m);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int i = 16 * it + m.n16;
+            if (i < a.Tq) {
+                s16x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = __builtin_bit_cast(short, (bf16)o[e]);
+                *reinterpret_cast<s16x4*>(O + (size_t)i * a.ldo + ct * 16 + 4 * m.g) = r;
+            }
+        }
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
+    constexpr int KS = D / 32, CT = D / 16, PITCH = D * 2 + 16;
+    constexpr int WAVE_LDS = 3 * 32 * PITCH + 2 * 32 * ATT_PP;
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    MfmaHead m;
+    m.hb = blockIdx.x * 4 + w;
+    if (m.hb >= a.B * a.heads) return;
+    m.b = m.hb / a.heads; m.h = m.hb % a.heads; m.n16 = lane & 15; m.g = lane >> 4;
+    char* kimg = smc + w * WAVE_LDS;
+    char* qimg = kimg + 32 * PITCH;
+    char* doimg = qimg + 32 * PITCH;
+    char* pdimg = doimg + 32 * PITCH;       // [query][key] dropped / rescaled probabilities
+    char* dsimg = pdimg + 32 * ATT_PP;      // [query][key] d(logits)
+    bf16x8 kf[2][KS], qf[2][KS], vf[2][KS], dof[2][KS];
+    load_slice<D>((const bf16*)a.K + (size_t)m.b * a.Tk * a.ldk + m.h * D, a.ldk, a.Tk, m, kf, kimg);
+    load_slice<D>((const bf16*)a.Q + (size_t)m.b * a.Tq * a.ldq + m.h * D, a.ldq, a.Tq, m, qf, qimg);
+    load_slice<D>((const bf16*)a.V + (size_t)m.b * a.Tk * a.ldv + m.h * D, a.ldv, a.Tk, m, vf, nullptr);
+    load_slice<D>((const bf16*)a.dO + (size_t)m.b * a.Tq * a.lddo + m.h * D, a.lddo, a.Tq, m, dof, doimg);
+    f32x4 st[2][2], dp[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            st[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dp[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                st[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[it][ks], st[jt][it], 0, 0, 0);
+                dp[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[jt][ks], dof[it][ks], dp[jt][it], 0, 0, 0);     // dP^T = V.dO^T
+            }
+        }
+    uint32_t masked[2];
+    softmax_t(a, m, st, masked);
+    const uint32_t thresh = dropout_threshold(a.drop_p);
+    const float ks_ = (a.drop_p > 0.f) ? 1.f / (1.f - a.drop_p) : 1.f;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int i = 16 * it + m.n16;
+        float delta = 0.f;
+        f32x4 pd[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int j0 = 16 * jt + 4 * m.g;
+            uint32_t keep = 0xFu;
+            if (a.drop_p > 0.f && i < a.Tq && j0 < a.Tk) keep = keep4(a.seed, a.stream_id, ((uint64_t)m.hb * a.Tq + i) * a.Tk + j0, thresh);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool kp = (keep >> r) & 1u;
+                pd[jt][r] = kp ? st[jt][it][r] * ks_ : 0.f;
+                dp[jt][it][r] = kp ? dp[jt][it][r] * ks_ : 0.f;          // d(normalised P)
+                delta += st[jt][it][r] * dp[jt][it][r];
+            }
+        }
+        delta += __shfl_xor(delta, 16, 64);
+        delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // masked_fill REPLACES the logit: no gradient reaches a masked position (a fully masked row has uniform, non-zero P)
+                const bool msk = (masked[it] >> (4 * jt + r)) & 1u;
+                dp[jt][it][r] = msk ? 0.f : st[jt][it][r] * (dp[jt][it][r] - delta) * a.scale;      // now dS^T
+            }
+            // [query][key] images for the products that sum over queries: 4 consecutive keys of query i, 8 bytes
+            s16x4 pk, dk;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pk[r] = __builtin_bit_cast(short, (bf16)pd[jt][r]);
+                dk[r] = __builtin_bit_cast(short, (bf16)dp[jt][it][r]);
+            }
+            *reinterpret_cast<s16x4*>(pdimg + i * ATT_PP + (16 * jt + 4 * m.g) * 2) = pk;
+            *reinterpret_cast<s16x4*>(dsimg + i * ATT_PP + (16 * jt + 4 * m.g) * 2) = dk;
+        }
+    }
+    // dQ^T[c][i] = sum_j K^T[c][j] dS^T[j][i]
+    {
+        bf16x8 dsb[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) dsb[it] = pack8(dp[0][it], dp[1][it]);
+        bf16* dQ = (bf16*)a.dQ + (size_t)m.b * a.Tq * a.lddq + m.h * D;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const bf16x8 kt = tr_operand<D, true>(kimg, ct, m);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt, dsb[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const int i = 16 * it + m.n16;
+                if (i < a.Tq) {
+                    s16x4 r;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = __builtin_bit_cast(short, (bf16)o[e]);
+                    *reinterpret_cast<s16x4*>(dQ + (size_t)i * a.lddq + ct * 16 + 4 * m.g) = r;
+                }
+            }
+        }
+    }
+    // dK^T[c][j] = sum_i Q^T[c][i] dS[i][j],  dV^T[c][j] = sum_i dO^T[c][i] Pd[i][j]: B operand = key column j of 8 queries
+    {
+        const int q = m.n16 >> 2, p = m.n16 & 3;
+        bf16x8 dsq[2], pdq[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            const int off = (8 * m.g + q) * ATT_PP + (16 * jt + 4 * p) * 2;
+            dsq[jt] = join8(tr16(dsimg + off), tr16(dsimg + off + 4 * ATT_PP));
+            pdq[jt] = join8(tr16(pdimg + off), tr16(pdimg + off + 4 * ATT_PP));
+        }
+        bf16* dK = (bf16*)a.dK + (size_t)m.b * a.Tk * a.lddk + m.h * D;
+        bf16* dV = (bf16*)a.dV + (size_t)m.b * a.Tk * a.lddv + m.h * D;
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const bf16x8 qt = tr_operand<D, false>(qimg, ct, m);
+            const bf16x8 dot = tr_operand<D, false>(doimg, ct, m);
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const f32x4 ok = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt, dsq[jt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const f32x4 ov = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot, pdq[jt], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                const int j = 16 * jt + m.n16;
+                if (j < a.Tk) {
+                    s16x4 rk, rv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { rk[e] = __builtin_bit_cast(short, (bf16)ok[e]); rv[e] = __builtin_bit_cast(short, (bf16)ov[e]); }
+                    *reinterpret_cast<s16x4*>(dK + (size_t)j * a.lddk + ct * 16 + 4 * m.g) = rk;
+                    *reinterpret_cast<s16x4*>(dV + (size_t)j * a.lddv + ct * 16 + 4 * m.g) = rv;
+                }
+            }
+        }
+    }
+}
+
+// bf16, head dim 32 / 64 / 128, <= 32 queries and keys, 16-byte-aligned row slices
+bool mfma_ok(int dtype, const AttnArgs& a, bool bwd) {
+    if (dtype != BLT_BF16 || blt_debug_get(16) == 1) return false;      // debug key 16 = 1: the VALU kernels (A/B)
+    if (!(a.d == 32 || a.d == 64 || a.d == 128) || a.Tq > 32 || a.Tk > 32) return false;
+    auto al = [](const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 7) == 0; };
+    if (!al(a.Q, a.ldq) || !al(a.K, a.ldk) || !al(a.V, a.ldv)) return false;
+    if (!bwd) return (((uintptr_t)a.O) & 7) == 0 && (a.ldo & 3) == 0;
+    return al(a.dO, a.lddo) && (((uintptr_t)a.dQ) & 7) == 0 && (((uintptr_t)a.dK) & 7) == 0 && (((uintptr_t)a.dV) & 7) == 0 && (a.lddq & 3) == 0 &&
+           (a.lddk & 3) == 0 && (a.lddv & 3) == 0;
+}
+
+template <int D>
+int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t s) {
+    const unsigned grid = (unsigned)((a.B * a.heads + 3) / 4);
+    constexpr int PITCH = D * 2 + 16;
+    if (!bwd) {
+        hipLaunchKernelGGL(attn_fwd_mfma_kernel<D>, dim3(grid), dim3(256), 4 * 32 * PITCH, s, a);
+        return blt_check_launch("attn_fwd");
+    }
+    const size_t lds = 4 * (3 * 32 * PITCH + 2 * 32 * ATT_PP);
+    if (lds > 64 * 1024) {
+        static bool set = false;
+        if (!set) {
+            if (hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                blt_set_error("attn_bwd: hipFuncSetAttribute failed");
+                return BLT_ERR_HIP;
+            }
+            set = true;
+        }
+    }
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel<D>, dim3(grid), dim3(256), lds, s, a);
+    return blt_check_launch("attn_bwd");
+}
+int launch_mfma_d(const AttnArgs& a, bool bwd, hipStream_t s) {
+    if (a.d == 32) return launch_mfma<32>(a, bwd, s);
+    if (a.d == 64) return launch_mfma<64>(a, bwd, s);
+    return launch_mfma<128>(a, bwd, s);
+}
+
 int check(const AttnArgs& a, bool bwd) {
     BLT_REQUIRE(a.Q && a.K && a.V, "attn: null Q/K/V");
     BLT_REQUIRE(a.B > 0 && a.heads > 0 && a.d > 0, "attn: bad sizes");
@@ -257,6 +628,7 @@ int blt_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "attn_fwd: bad dtype");
     int rc = check(a, false);
     if (rc) return rc;
+    if (mfma_ok(dtype, a, false)) return launch_mfma_d(a, false, s);
     const size_t lds = lds_bytes(a, false);
     if (dtype == BLT_F32) {
         if ((rc = set_lds(attn_fwd_kernel<float>, lds, "attn_fwd"))) return rc;
@@ -272,6 +644,7 @@ int blt_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s) {
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "attn_bwd: bad dtype");
     int rc = check(a, true);
     if (rc) return rc;
+    if (mfma_ok(dtype, a, true)) return launch_mfma_d(a, true, s);
     const size_t lds = lds_bytes(a, true);
     if (dtype == BLT_F32) {
         if ((rc = set_lds(attn_bwd_kernel<float>, lds, "attn_bwd"))) return rc;

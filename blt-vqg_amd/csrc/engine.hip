@@ -620,7 +620,8 @@ struct bltvqg_engine {
             double fl = 0.0;
             for (const GemmArgs& g : pending_wgrads) fl += 2.0 * (double)g.M * (double)g.N * (double)g.K;
             const int pi = (prof_mask & 2) ? prof_begin(1, to) : -1;
-            rc = blt_wgrad_group_launch((const blt_wg_problem*)dev, (const int*)(dev + pb_al), (int)t.probs.size(), nwg, bm, to);
+            // debug key 14: timing ablation only (weight gradients are NOT computed) — bounds what the side-stream launches cost the chain
+            if (blt_debug_get(14) != 1) rc = blt_wgrad_group_launch((const blt_wg_problem*)dev, (const int*)(dev + pb_al), (int)t.probs.size(), nwg, bm, to);
             prof_end(pi, to, fl);
             ++flush_idx;
         } else {
@@ -888,6 +889,7 @@ struct bltvqg_engine {
                 RC(blt_conv_pack_w(dt, FZ(cs.wname), cs.wpacked, cs.Cout, cs.Cin, cs.K, cs.K, cs.CinPad, cs.Cin < 8 ? 8 : cs.K, s));
             frozen_dirty = false;
         }
+        if (blt_debug_get(15) == 1) return cnn_head_fwd(s);      // timing ablation only: the conv stack is skipped, `pooled` keeps the last step's features
         if (images) RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 4, 3, 3, imgHp, imgWp, s));      // NULL: the caller filled `img`
         size_t ci = 0;
         ConvSpec& c1 = convs[ci++];

@@ -1126,9 +1126,9 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 // process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode,
 // [3] = ring depth of the DMA kernels (0 = by grid size; 128x128: 1 = always 4 stages, 2 = always 2; 64x64: 3 = always 5, 4 = always 3)
 // [8] = 1: round-1 kernels for the Linear GEMMs instead of gemm2.hip's planned-tile kernel (A/B); [9] / [10] = force its BM / BN
-static int g_debug[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-void blt_debug_set(int key, int value) { if (key >= 0 && key < 16) g_debug[key] = value; }
-int blt_debug_get(int key) { return (key >= 0 && key < 16) ? g_debug[key] : 0; }
+static int g_debug[24] = {0};
+void blt_debug_set(int key, int value) { if (key >= 0 && key < 24) g_debug[key] = value; }
+int blt_debug_get(int key) { return (key >= 0 && key < 24) ? g_debug[key] : 0; }
 
 struct Choice { int bm, bn, no_dma; };
 static std::unordered_map<uint64_t, Choice> g_tuned;     // filled by autotune mode: measured best kernel per GEMM descriptor

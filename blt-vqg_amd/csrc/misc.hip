@@ -216,6 +216,32 @@ __global__ void img_pack_kernel(const float* __restrict__ src, T* __restrict__ d
     }
 }
 
+// The stem's case (3 planes -> 4 channels): one workgroup per padded output ROW, one thread per pixel, so no per-thread div/mod; the three
+// plane reads are coalesced along w and the pixel's 4 channels leave as ONE 8-byte (bf16) / 16-byte (fp32) store.
+template <typename T>
+__global__ __launch_bounds__(256) void img_pack_c3_kernel(const float* __restrict__ src, T* __restrict__ dst, int H, int W, int pt, int pl, int Hp, int Wp) {
+    const int hp = blockIdx.x % Hp;
+    const long n = blockIdx.x / Hp;
+    const int h = hp - pt;
+    const bool row_in = (unsigned)h < (unsigned)H;
+    const float* p = src + (n * 3 * H + (row_in ? h : 0)) * W;
+    const long plane = (long)H * W;
+    T* o = dst + ((n * Hp + hp) * (long)Wp) * 4;
+    for (int wp = threadIdx.x; wp < Wp; wp += 256) {
+        const int w = wp - pl;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if (row_in && (unsigned)w < (unsigned)W) { v0 = p[w]; v1 = p[plane + w]; v2 = p[2 * plane + w]; }
+        if constexpr (sizeof(T) == 2) {
+            s16x4 r;
+            r[0] = __builtin_bit_cast(short, from_f32<T>(v0)); r[1] = __builtin_bit_cast(short, from_f32<T>(v1));
+            r[2] = __builtin_bit_cast(short, from_f32<T>(v2)); r[3] = 0;
+            *reinterpret_cast<s16x4*>(o + (long)wp * 4) = r;
+        } else {
+            *reinterpret_cast<float4*>(o + (long)wp * 4) = make_float4(v0, v1, v2, 0.f);
+        }
+    }
+}
+
 // conv weight [Cout, Cin, KH, KW] fp32 -> [Cout, KH, KWpad, Cpad] T (k index = (r*KWpad + s)*Cpad + c)
 template <typename T>
 __global__ void conv_pack_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad) {
@@ -880,6 +906,11 @@ int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, 
     CHECK_DTYPE(dtype, "img_pack");
     BLT_REQUIRE(nchw && nhwc && N > 0 && C > 0 && C <= Cpad && H > 0 && W > 0 && pt >= 0 && pl >= 0 && Hp >= H + pt && Wp >= W + pl, "img_pack: bad args");
     const long n = (long)N * Hp * Wp;
+    if (C == 3 && Cpad == 4 && (long)N * Hp < (1l << 31) && ((uintptr_t)nhwc % 16) == 0) {
+        if (dtype == BLT_F32) hipLaunchKernelGGL(img_pack_c3_kernel<float>, dim3((unsigned)(N * Hp)), dim3(256), 0, s, nchw, (float*)nhwc, H, W, pt, pl, Hp, Wp);
+        else hipLaunchKernelGGL(img_pack_c3_kernel<bf16>, dim3((unsigned)(N * Hp)), dim3(256), 0, s, nchw, (bf16*)nhwc, H, W, pt, pl, Hp, Wp);
+        return blt_check_launch("img_pack");
+    }
     if (dtype == BLT_F32) hipLaunchKernelGGL(img_pack_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (float*)nhwc, N, C, H, W, Cpad, pt, pl, Hp, Wp);
     else hipLaunchKernelGGL(img_pack_kernel<bf16>, dim3(ew_grid(n)), dim3(256), 0, s, nchw, (bf16*)nhwc, N, C, H, W, Cpad, pt, pl, Hp, Wp);
     return blt_check_launch("img_pack");

@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // global fp32 gradient once at the end (one float atomic per column per block).  Rows of <= 256 columns need only 32 lanes
 // (8 columns each), so a wave then carries TWO rows at once (`lpr` lanes per row) — the kernel is latency-bound, rows in flight
 // are what count.
-template <typename T>
+// NCH = chunk groups per lane (cols <= 512 NCH), R = rows a wave keeps in flight per iteration: every load of the R rows is issued
+// before the first reduction, so a wave pays the memory round trip once per R rows (with R = 1 and ~2.5 serial iterations per wave the
+// [5120 x 512] launch took 13.4 us against 3 us of traffic).
+template <typename T, int NCH, int R>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const T* dres,
@@ -72,60 +75,79 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const int nch = cols >> 3;
     const int lpr = (nch <= 32) ? 32 : 64, rpw = 64 / lpr;
     const int l = lane & (lpr - 1), sub = lane / lpr;
-    float ag[LN_MAX_CHUNKS][8], ab[LN_MAX_CHUNKS][8], g[LN_MAX_CHUNKS][8];
+    float ag[NCH][8], ab[NCH][8], g[NCH][8];
 #pragma unroll
-    for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+    for (int j = 0; j < NCH; ++j) {
         const int c = l + lpr * j;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; g[j][e] = 0.f; }
         if (c < nch) Vec8<float>::load(gamma + c * 8, g[j]);
     }
-    for (long row = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub; row < rows; row += (long)gridDim.x * 4 * rpw) {
-        const float mu = mean[row], rs = rstd[row];
-        float xh[LN_MAX_CHUNKS][8], dxh[LN_MAX_CHUNKS][8];
-        float s1 = 0.f, s2 = 0.f;
+    const long rstride = (long)gridDim.x * 4 * rpw;
+    for (long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub; row0 < rows; row0 += rstride * R) {
+        float d[R][NCH][8], xh[R][NCH][8], rr[R][NCH][8];
+        float mu[R], rs[R];
 #pragma unroll
-        for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
-            const int c = l + lpr * j;
-            if (c < nch) {
-                float d[8];
-                Vec8<T>::load(dy + row * cols + c * 8, d);
-                Vec8<T>::load(x + row * cols + c * 8, xh[j]);
+        for (int r = 0; r < R; ++r) {
+            const long row = row0 + r * rstride;
+            const bool rok = row < rows;
+            mu[r] = rok ? mean[row] : 0.f;
+            rs[r] = rok ? rstd[row] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    xh[j][e] = (xh[j][e] - mu) * rs;
-                    dxh[j][e] = d[e] * g[j][e];
-                    s1 += dxh[j][e];
-                    s2 += dxh[j][e] * xh[j][e];
-                    ag[j][e] += d[e] * xh[j][e];
-                    ab[j][e] += d[e];
+            for (int j = 0; j < NCH; ++j) {
+                const int c = l + lpr * j;
+                if (rok && c < nch) {
+                    Vec8<T>::load(dy + row * cols + c * 8, d[r][j]);
+                    Vec8<T>::load(x + row * cols + c * 8, xh[r][j]);
+                    if (dres != nullptr) Vec8<T>::load(dres + row * cols + c * 8, rr[r][j]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { d[r][j][e] = 0.f; xh[r][j][e] = 0.f; }
                 }
             }
         }
-        for (int o = lpr >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-        const float c1 = s1 / (float)cols, c2 = s2 / (float)cols;
 #pragma unroll
-        for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
-            const int c = l + lpr * j;
-            if (c < nch) {
-                float o[8];
+        for (int r = 0; r < R; ++r) {
+            const long row = row0 + r * rstride;
+            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = rs * (dxh[j][e] - c1 - xh[j][e] * c2);
-                if (dres != nullptr) {
-                    float r[8];
-                    Vec8<T>::load(dres + row * cols + c * 8, r);
+            for (int j = 0; j < NCH; ++j)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] += r[e];
+                for (int e = 0; e < 8; ++e) {
+                    const float xn = (xh[r][j][e] - mu[r]) * rs[r];
+                    const float dg = d[r][j][e] * g[j][e];
+                    s1 += dg;
+                    s2 += dg * xn;
+                    ag[j][e] += d[r][j][e] * xn;
+                    ab[j][e] += d[r][j][e];
+                    xh[r][j][e] = xn;
+                    d[r][j][e] = dg;
                 }
-                Vec8<T>::store(dx + row * cols + c * 8, o);
-                if (out2 != nullptr) {
-                    // the consumer of dx is a ReLU + dropout backward (the FFN output of the next layer down): emit its masked,
-                    // rescaled gradient here instead of in a launch of its own
-                    float mk[8];
-                    Vec8<T>::load(maskY + row * cols + c * 8, mk);
+            for (int o = lpr >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            const float c1 = s1 / (float)cols, c2 = s2 / (float)cols;
+            if (row < rows) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (mk[e] != 0.f) ? o[e] * mask_scale : 0.f;
-                    Vec8<T>::store(out2 + row * cols + c * 8, o);
+                for (int j = 0; j < NCH; ++j) {
+                    const int c = l + lpr * j;
+                    if (c < nch) {
+                        float o[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = rs[r] * (d[r][j][e] - c1 - xh[r][j][e] * c2);
+                        if (dres != nullptr) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] += rr[r][j][e];
+                        }
+                        Vec8<T>::store(dx + row * cols + c * 8, o);
+                        if (out2 != nullptr) {
+                            // the consumer of dx is a ReLU + dropout backward (the FFN output of the next layer down): emit its masked,
+                            // rescaled gradient here instead of in a launch of its own
+                            float mk[8];
+                            Vec8<T>::load(maskY + row * cols + c * 8, mk);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) o[e] = (mk[e] != 0.f) ? o[e] * mask_scale : 0.f;
+                            Vec8<T>::store(out2 + row * cols + c * 8, o);
+                        }
+                    }
                 }
             }
         }
@@ -136,26 +158,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[0][e] += __shfl_xor(ag[0][e], 32, 64); ab[0][e] += __shfl_xor(ab[0][e], 32, 64); }
     }
-    // combine the 4 waves of the block through LDS, then one atomic per column per block
-    __shared__ float red[4][LN_MAX_CHUNKS * 64 * 8 / 4];   // reused in two passes (gamma then beta), 512 cols per pass
+    // combine the 4 waves of the block through LDS, then one partial row (or one atomic) per column per block
+    __shared__ float red[2][4][512];   // [gamma|beta][wave][512 columns of one chunk group]
     const int w = threadIdx.x >> 6;
-    for (int pass = 0; pass < 2; ++pass) {
-        for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
-            if (64 * 8 * j >= cols) break;
-            __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 8; ++e) red[w][lane * 8 + e] = pass == 0 ? ag[j][e] : ab[j][e];
-            __syncthreads();
-            // 512 columns of chunk-group j: column = (lane' + 64 j) * 8 + e  -> index lane'*8+e in red
-            for (int i = threadIdx.x; i < 512; i += 256) {
-                const int col = 64 * 8 * j + i;
-                if (col < cols) {
-                    const float t = red[0][i] + red[1][i] + red[2][i] + red[3][i];
-                    // partials: one row of dgamma and one of dbeta per workgroup, summed later by ln_param_reduce_kernel (off the
-                    // dependent chain) instead of gridDim.x same-address atomics per column at the tail of this launch
-                    if (partials != nullptr) partials[((size_t)blockIdx.x * 2 + pass) * cols + col] = t;
-                    else atomicAdd((pass == 0 ? dgamma : dbeta) + col, t);
-                }
+    for (int j = 0; j < NCH; ++j) {
+        if (64 * 8 * j >= cols) break;
+        if (j > 0) __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][w][lane * 8 + e] = ag[j][e]; red[1][w][lane * 8 + e] = ab[j][e]; }
+        __syncthreads();
+        // 512 columns of chunk-group j: column = (lane' + 64 j) * 8 + e  -> index lane'*8+e in red
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            const int pass = i >> 9, ii = i & 511;
+            const int col = 64 * 8 * j + ii;
+            if (col < cols) {
+                const float t = red[pass][0][ii] + red[pass][1][ii] + red[pass][2][ii] + red[pass][3][ii];
+                // partials: one row of dgamma and one of dbeta per workgroup, summed later by ln_param_reduce_kernel (off the
+                // dependent chain) instead of gridDim.x same-address atomics per column at the tail of this launch
+                if (partials != nullptr) partials[((size_t)blockIdx.x * 2 + pass) * cols + col] = t;
+                else atomicAdd((pass == 0 ? dgamma : dbeta) + col, t);
             }
         }
     }
@@ -512,9 +534,11 @@ int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
     return blt_check_launch("layernorm_fwd");
 }
 
+static inline int ln_bwd_rows_in_flight(int cols) { return cols <= 512 ? 4 : (cols <= 1024 ? 2 : 1); }
+
 int blt_layernorm_bwd_grid(long rows, int cols) {
     const int rpw = (cols <= 256) ? 2 : 1;
-    int grid = cdiv(rows, 4 * rpw * 2);
+    int grid = cdiv(rows, 4 * rpw * ln_bwd_rows_in_flight(cols));      // one iteration per wave where that fits in 512 workgroups
     if (grid > 512) grid = 512;
     return grid < 1 ? 1 : grid;
 }
@@ -555,12 +579,21 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_bwd: bad dtype");
     BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_bwd: bad cols=%d", cols);
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
-    // ~2 row-iterations per wave (rows <= 256 columns: two rows per wave): latency-bound, yet few enough blocks for the dgamma/dbeta atomics
     int grid = blt_layernorm_bwd_grid(rows, cols);
     if (grid < 1) grid = 1;
-    DISPATCH_T(dtype,
-               hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)dy, (const float*)x, gamma, mean, rstd, (const float*)dres, (float*)dx, dgamma, dbeta, rows, cols, (const float*)maskY, mask_scale, (float*)out2, partials),
-               hipLaunchKernelGGL(layernorm_bwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (const bf16*)dres, (bf16*)dx, dgamma, dbeta, rows, cols, (const bf16*)maskY, mask_scale, (bf16*)out2, partials));
+#define LN_BWD_LAUNCH(T_, NCH_, R_)                                                                                                         \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NCH_, R_>), dim3(grid), dim3(256), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, \
+                       (const T_*)dres, (T_*)dx, dgamma, dbeta, rows, cols, (const T_*)maskY, mask_scale, (T_*)out2, partials)
+#define LN_BWD_BY_COLS(T_)                                                                                                                 \
+    do {                                                                                                                                    \
+        if (cols <= 512) LN_BWD_LAUNCH(T_, 1, 4);                                                                                           \
+        else if (cols <= 1024) LN_BWD_LAUNCH(T_, 2, 2);                                                                                     \
+        else LN_BWD_LAUNCH(T_, 4, 1);                                                                                                       \
+    } while (0)
+    if (dtype == BLT_F32) LN_BWD_BY_COLS(float);
+    else LN_BWD_BY_COLS(bf16);
+#undef LN_BWD_BY_COLS
+#undef LN_BWD_LAUNCH
     return blt_check_launch("layernorm_bwd");
 }
 

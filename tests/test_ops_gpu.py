@@ -350,6 +350,55 @@ def test_attention_fwd_bwd(dtype, case, p):
         assert torch.allclose(got.float().cpu(), want, atol=tol * 8, rtol=tol * 4)
 
 
+@pytest.mark.parametrize("case", [dict(B=5, h=3, Tq=7, Tk=21, d=64, causal=0), dict(B=2, h=2, Tq=32, Tk=32, d=128, causal=1),
+                                  dict(B=3, h=1, Tq=1, Tk=1, d=32, causal=0), dict(B=9, h=8, Tq=20, Tk=21, d=64, causal=0),
+                                  dict(B=4, h=4, Tq=17, Tk=17, d=64, causal=2), dict(B=256, h=8, Tq=20, Tk=20, d=64, causal=1)])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+def test_attention_mfma_form_matches_reference_and_valu_form(case, p):
+    """bf16 attention runs as one wave per (batch, head) on MFMA tiles (attn.hip, `attn_*_mfma_kernel`); debug key 16 selects the
+    VALU kernels it replaced.  Both against the fp32 torch restatement of transformer_layers.py:494-526 with the SAME dropout mask,
+    and against each other (the dropout stream is addressed identically, so the two forms drop the same weights)."""
+    import gpu_ops as G
+    B, h, Tq, Tk, d, causal = case["B"], case["h"], case["Tq"], case["Tk"], case["d"], case["causal"]
+    Hd = h * d
+    g = torch.Generator().manual_seed(B * 7 + Tq * 3 + Tk)
+    Q = torch.randn(B * Tq, Hd, generator=g).bfloat16()
+    kv = torch.randn(B * Tk, 2 * Hd, generator=g).bfloat16()
+    K, V = kv[:, :Hd], kv[:, Hd:]
+    ids = torch.randint(1, 50, (B, Tk), generator=g, dtype=torch.int32)
+    if Tk > 2:
+        ids[0, Tk - 2:] = 0
+    if causal == 0 and B > 1:
+        ids[1, :] = 0
+    dO = torch.randn(B * Tq, Hd, generator=g).bfloat16()
+    scale = d ** -0.5
+    seed, sid = 1234567, 2011
+    keep = None
+    if p > 0:
+        keep = G.dropout_mask(seed, sid, B * h * Tq, Tk, Tk, p).cpu().float().view(B, h, Tq, Tk)
+    Qd = Q.cuda(); kd = kv.cuda(); Kd, Vd = kd[:, :Hd], kd[:, Hd:]
+    res = {}
+    for form in (0, 1):
+        G.lib().bltvqg_debug_set(16, form)
+        try:
+            O = G.attn_fwd(Qd, Kd, Vd, ids.cuda(), B, h, Tq, Tk, d, causal, scale, p, seed, sid)
+            dQ, dK, dV = G.attn_bwd(Qd, Kd, Vd, dO.cuda(), ids.cuda(), B, h, Tq, Tk, d, causal, scale, p, seed, sid)
+        finally:
+            G.lib().bltvqg_debug_set(16, 0)
+        res[form] = [t.float().cpu() for t in (O, dQ, dK, dV)]
+        assert all(torch.isfinite(t).all() for t in res[form])
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.allclose(a_, b_, atol=6e-2, rtol=4e-2), float((a_ - b_).abs().max())
+    if causal != 2:       # causal == 2 is the greedy decoder's prefix form (no torch restatement here; compared against the VALU form above)
+        Qr, Kr, Vr = [t.float().clone().requires_grad_(True) for t in (Q, K, V)]
+        ref = _attn_ref(Qr, Kr, Vr, ids, B, h, Tq, Tk, d, bool(causal), scale, keep, p)
+        ref.backward(dO.float())
+        tol = 2e-2
+        assert torch.allclose(res[0][0], ref.detach(), atol=tol * 4, rtol=tol)
+        for got, want in zip(res[0][1:], (Qr.grad, Kr.grad, Vr.grad)):
+            assert torch.allclose(got, want, atol=tol * 8, rtol=tol * 4), float((got - want).abs().max())
+
+
 # --------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("V", [97, 8000])

@@ -51,6 +51,7 @@ SIGNATURES = {
     "bltvqg_pp_guard_front": (I, []),
     "bltvqg_pp_guard_tail": (I, []),
     "bltvqg_conv3x3_pp": (I, [P, P, P, I, I, I, I, I, P, P, P]),
+    "bltvqg_conv3x3_pp_bn_relu_in": (I, [P, P, P, P, P, I, I, I, I, I, P, P, P]),
     "bltvqg_conv3x3_pp_stat_rows": (I, [I, I, I]),
     "bltvqg_conv2d_pp": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv2d_pp_stat_rows": (I, [I, I, I, I, I, I, I, I, I, I, I]),

@@ -131,6 +131,11 @@ int bltvqg_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W
                       void* stream) {
     return blt_conv3x3_pp(x, w, y, N, H, W, Cin, Cout, stat_sum, stat_sq, (hipStream_t)stream);
 }
+int bltvqg_conv3x3_pp_bn_relu_in(const void* x_raw, const float* in_scale, const float* in_shift, const void* w, void* y, int N, int H, int W, int Cin,
+                                 int Cout, float* stat_sum, float* stat_sq, void* stream) {
+    BLT_REQUIRE(in_scale && in_shift, "conv3x3_pp_bn_relu_in: null scale / shift");
+    return blt_conv3x3_pp(x_raw, w, y, N, H, W, Cin, Cout, stat_sum, stat_sq, (hipStream_t)stream, in_scale, in_shift);
+}
 int bltvqg_conv3x3_pp_stat_rows(int N, int H, int W) { return blt_conv3x3_pp_stat_rows(N, H, W); }
 
 static GemmArgs conv_args_pp(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad,

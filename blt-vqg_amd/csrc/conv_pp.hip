@@ -39,11 +39,14 @@ struct ConvPPArgs {
     int nblocks, tiles_n;
     int chunked;        // 1: consecutive tiles go to the same XCD (patch halos and tile rows shared in its L2)
     int valid_off;      // byte offset of the 128-float row-validity table (epilogue only: behind the staged output tile)
+    // FUSE_IN: X is the RAW output of the previous convolution; its train-mode BatchNorm + ReLU (y = max(x*scale + shift, 0), zeros at
+    // PP pad positions) is applied to each 64-channel patch slice in LDS after it has landed, instead of in a bn_apply_pp pass of its own
+    const float *in_scale, *in_shift;
 };
 
 // NSTB = stages of the weight ring: 2 (one tap in flight; two workgroups per CU cover each other's waits) or 4 (three taps in flight, for
 // grids that leave a workgroup alone on its CU, e.g. the 7x7x512 layer: 256 tiles)
-template <int BN, int NSTB>
+template <int BN, int NSTB, bool FUSE_IN>
 __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     constexpr int WN = BN / 2, TN = WN / 16, TM = 4, CH_B = BN * 8 / 256, B_STAGE = BN * 128, CSB = BN + 8, AHEAD = NSTB - 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -89,7 +92,48 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
         }
     };
 
-    for (int j = 0; j < p.pw; ++j) issue_patch(0, j);
+    // FUSE_IN: this thread transforms chunk (j*256 + tid) of a patch slice, j < pw: patch row j*32 + (tid >> 3), always the same 8
+    // channels of the slice.  Which of its rows are real pixels (not PP pads, guards or past the end) is one bit each, computed once.
+    unsigned vbits = 0;
+    if constexpr (FUSE_IN) {
+        for (int j = 0; j < p.pw; ++j) {
+            const long q = q0 - pitch - 1 + j * 32 + (tid >> 3);
+            if (q >= 0 && q < p.Mq) {
+                const unsigned row = (unsigned)q / (unsigned)pitch;
+                const int w = (int)((unsigned)q - row * (unsigned)pitch), h = (int)(row % (unsigned)(p.H + 1));
+                if (w != p.W && h != p.H) vbits |= 1u << j;
+            }
+        }
+    }
+    // FUSE_IN staging: the piece goes global -> registers -> (BatchNorm + ReLU, pad mask) -> LDS, into the slot the DMA would have
+    // filled; an in-place LDS pass after a DMA was measured at +26 us per launch (LDS bandwidth is what bounds this kernel)
+    auto load_piece = [&](int sl_, int j) -> bf16x8 {
+        const int pp = (j * 4 + wave) * 8 + (lane >> 3);
+        return *reinterpret_cast<const bf16x8*>(xb + (long)pp * p.Cin + ((((lane & 7) ^ (pp & 7))) << 3) + (sl_ << 6));
+    };
+    auto load_bn = [&](int sl_, float (&sc)[8], float (&sh)[8]) {
+        const int cc = (tid & 7) ^ ((tid >> 3) & 7);
+        Vec8<float>::load(p.in_scale + (sl_ << 6) + cc * 8, sc);
+        Vec8<float>::load(p.in_shift + (sl_ << 6) + cc * 8, sh);
+    };
+    auto store_piece = [&](int sl_, int j, bf16x8 v, const float (&sc)[8], const float (&sh)[8]) {
+        const bool ok = (vbits >> j) & 1u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ok ? (bf16)fmaxf((float)v[e] * sc[e] + sh[e], 0.f) : (bf16)0.f;
+        *reinterpret_cast<bf16x8*>(((sl_ & 1) ? patch1 : patch0) + (j * 256 + tid) * 16) = v;
+    };
+    float nsc[8], nsh[8];      // FUSE_IN: scale / shift of this thread's 8 channels of the slice being staged
+    bf16x8 staged;
+
+    bf16x8 first[8];                                         // FUSE_IN: slice 0's pieces, pw <= 8 (P <= 256 patch pixels)
+    if constexpr (FUSE_IN) {
+        load_bn(0, nsc, nsh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < p.pw) first[j] = load_piece(0, j);
+    } else {
+        for (int j = 0; j < p.pw; ++j) issue_patch(0, j);
+    }
     // the tap steps run s = sl*9 + t; (sa, ta) walks AHEAD steps in front of (sl, t) for the weight ring
     int sa = 0, ta = 0;
     for (int s = 0; s < AHEAD && s < nsteps; ++s) {
@@ -101,6 +145,13 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (FUSE_IN) {
+        // behind the weight ring's first DMAs in program order: waiting for the pieces leaves those in flight
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < p.pw) store_piece(0, j, first[j], nsc, nsh);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // visible to the other waves at the first barrier of the tap loop
+    }
 
     int sl = 0, t = 0;
     for (int s = 0; s < nsteps; ++s) {
@@ -111,13 +162,23 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
         else if (AHEAD > 1 && younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CH_B) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                        // ... everyone's has; ring stage (s-1) % NSTB and the idle patch buffer are free
-        if (sl + 1 < NS && t < p.pw) issue_patch(sl + 1, t);
+        if constexpr (FUSE_IN) {
+            if (sl + 1 < NS) {
+                if (t >= 1 && t <= p.pw) store_piece(sl + 1, t - 1, staged, nsc, nsh);      // the piece loaded one tap ago
+                if (t == 0) load_bn(sl + 1, nsc, nsh);
+                if (t < p.pw) staged = load_piece(sl + 1, t);
+            }
+        } else {
+            if (sl + 1 < NS && t < p.pw) issue_patch(sl + 1, t);
+        }
         if (s + AHEAD < nsteps) {
             issue_b(s + AHEAD, sa, ta);
             if (++ta == 9) { ta = 0; ++sa; }
         }
         const char* pa = (sl & 1) ? patch1 : patch0;
         const char* bs = ring + (s % NSTB) * B_STAGE;
+        // (reading tap t+1's A fragments under tap t's MFMAs was measured: no change — with two workgroups per CU the partner's MFMAs
+        // already cover these LDS reads)
         const int tr = (t >= 6) ? 2 : (t >= 3) ? 1 : 0;
         const int toff = tr * pitch + (t - 3 * tr);
 #pragma unroll
@@ -194,10 +255,10 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     }
 }
 
-template <int BN, int NSTB>
+template <int BN, int NSTB, bool FUSE_IN>
 int launch(const ConvPPArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<BN, NSTB>;
+    auto kern = conv3x3_pp_kernel<BN, NSTB, FUSE_IN>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             blt_set_error("conv3x3_pp: hipFuncSetAttribute failed");
@@ -215,8 +276,10 @@ long blt_pp_pixels(int N, int H, int W) { return (long)N * (H + 1) * (W + 1); }
 int blt_conv3x3_pp_stat_rows(int N, int H, int W) { return 2 * cdiv(blt_pp_pixels(N, H, W), 128); }
 
 int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
-                   hipStream_t s) {
+                   hipStream_t s, const float* in_scale, const float* in_shift) {
     BLT_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, "conv3x3_pp: bad args");
+    BLT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "conv3x3_pp: in_scale and in_shift go together");
+    BLT_REQUIRE(((uintptr_t)in_scale % 16) == 0 && ((uintptr_t)in_shift % 16) == 0, "conv3x3_pp: in_scale / in_shift must be 16-byte aligned");
     BLT_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "conv3x3_pp: Cin=%d / Cout=%d must be multiples of 64", Cin, Cout);
     BLT_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv3x3_pp: stat_sum and stat_sq go together");
     BLT_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv3x3_pp: operands must be 16-byte aligned");
@@ -225,6 +288,7 @@ int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, i
     ConvPPArgs a;
     a.X = (const bf16*)x; a.Wt = (const bf16*)w; a.Y = (bf16*)y;
     a.Mq = blt_pp_pixels(N, H, W); a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+    a.in_scale = in_scale; a.in_shift = in_shift;
     a.pw = cdiv(cdiv(P, 8), 4);
     int BN = (Cout % 128 == 0) ? 128 : 64;
     // a grid that would leave most CUs with a single workgroup (7x7x512: 256 tiles of 128 channels) runs twice as many half-width
@@ -251,8 +315,12 @@ int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, i
     BLT_REQUIRE(a.Mq < (1L << 31), "conv3x3_pp: too many positions");
     // the tile overhang of the last workgroup's patch must stay inside the tail guard
     BLT_REQUIRE(a.pw * 32 - (W + 2) <= BLT_PP_GUARD_TAIL, "conv3x3_pp: tail guard too small");
-    if (BN == 128) return deep ? launch<128, 4>(a, grid, lds, s) : launch<128, 2>(a, grid, lds, s);
-    return deep ? launch<64, 4>(a, grid, lds, s) : launch<64, 2>(a, grid, lds, s);
+    if (in_scale != nullptr) {
+        if (BN == 128) return deep ? launch<128, 4, true>(a, grid, lds, s) : launch<128, 2, true>(a, grid, lds, s);
+        return deep ? launch<64, 4, true>(a, grid, lds, s) : launch<64, 2, true>(a, grid, lds, s);
+    }
+    if (BN == 128) return deep ? launch<128, 4, false>(a, grid, lds, s) : launch<128, 2, false>(a, grid, lds, s);
+    return deep ? launch<64, 4, false>(a, grid, lds, s) : launch<64, 2, false>(a, grid, lds, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

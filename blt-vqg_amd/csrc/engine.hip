@@ -826,12 +826,16 @@ struct bltvqg_engine {
         return BLT_OK;
     }
 
-    int conv_fwd(ConvSpec& cs, const void* x, hipStream_t s) {
+    // the LDS-patch kernel can take the previous convolution's raw output and apply its BatchNorm + ReLU on the staged patch
+    bool conv_is_direct(const ConvSpec& cs) const {
+        return cs.pp && dt == BLT_BF16 && cs.K == 3 && cs.stride == 1 && cs.pad == 1 && cs.Cin % 64 == 0 && cs.Cout % 64 == 0 && cs.Wo <= 62;
+    }
+    int conv_fwd(ConvSpec& cs, const void* x, hipStream_t s, const ConvSpec* in_bn = nullptr) {
         const bool stem = cs.Cin < 8;
         // 3x3 stride-1 convolutions on padded-pitch bf16 activations: the LDS-patch kernel (conv_pp.hip); everything else (stem,
         // stride-2, 1x1, fp32 mode) is an implicit GEMM, reading / writing the padded-pitch layout through the generalised loader
-        const bool direct = cs.pp && dt == BLT_BF16 && cs.K == 3 && cs.stride == 1 && cs.pad == 1 && cs.Cin % 64 == 0 && cs.Cout % 64 == 0 &&
-                            cs.Wo <= 62;
+        const bool direct = conv_is_direct(cs);
+        if (in_bn != nullptr && !direct) { blt_set_error("conv_fwd: fused input BatchNorm needs the LDS-patch kernel"); return BLT_ERR_STATE; }
         GemmArgs g;
         g.A = x; g.B = cs.wpacked; g.C = cs.out;
         g.M = B * cs.Ho * cs.Wo; g.N = cs.Cout; g.K = stem ? 224 : cs.K * cs.K * cs.CinPad;
@@ -848,7 +852,8 @@ struct bltvqg_engine {
         if (bn_train) { g.stat_sum = stat_sum; g.stat_sq = stat_sq; }
         const int pi = prof_begin(0, s);
         const bool direct_stem = stem && blt_conv_stem_direct_ok(dt, c.image_h, c.image_w, imgHp, imgWp, cs.Cout);
-        if (direct) RC(blt_conv3x3_pp(x, cs.wpacked, cs.out, B, cs.Ho, cs.Wo, cs.Cin, cs.Cout, g.stat_sum, g.stat_sq, s));
+        if (direct) RC(blt_conv3x3_pp(x, cs.wpacked, cs.out, B, cs.Ho, cs.Wo, cs.Cin, cs.Cout, g.stat_sum, g.stat_sq, s, in_bn ? in_bn->scale : nullptr,
+                                      in_bn ? in_bn->shift : nullptr));
         else if (direct_stem) RC(blt_conv_stem_direct(x, cs.wpacked, cs.out, B, c.image_h, c.image_w, imgHp, imgWp, g.stat_sum, g.stat_sq, s));
         else RC(blt_gemm(dt, g, s));
         prof_end(pi, s, 2.0 * (double)B * cs.Ho * cs.Wo * (double)cs.Cout * (double)(cs.K * cs.K * cs.Cin));   // algorithmic: real pixels, unpadded Cin
@@ -905,8 +910,10 @@ struct bltvqg_engine {
                 ConvSpec& ca = convs[ci++];
                 ConvSpec& cb = convs[ci++];
                 RC(conv_fwd(ca, x, s));
-                RC(bn_act(ca, nullptr, nullptr, 1, s));
-                RC(conv_fwd(cb, ca.out, s));
+                // bn1 + ReLU: inside conv2's patch staging when conv2 is the LDS-patch kernel (debug key 17 = 1: the separate pass)
+                const bool fuse_bn1 = conv_is_direct(cb) && blt_debug_get(17) != 1;
+                if (!fuse_bn1) RC(bn_act(ca, nullptr, nullptr, 1, s));
+                RC(conv_fwd(cb, ca.out, s, fuse_bn1 ? &ca : nullptr));
                 const void* res = x;
                 const ConvSpec* res_bn = nullptr;
                 if (st != 1 || cin != cout) {      // downsample branch: its BatchNorm is applied inside the block's final BN + add + ReLU pass

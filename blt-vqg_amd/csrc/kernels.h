@@ -101,8 +101,10 @@ int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, 
 // ---- padded-pitch 3x3 stride-1 convolution (conv_pp.hip), bf16 only ----------------
 long blt_pp_pixels(int N, int H, int W);                 // N*(H+1)*(W+1) positions (without the guards)
 int blt_conv3x3_pp_stat_rows(int N, int H, int W);       // partial rows written to stat_sum / stat_sq
+// in_scale / in_shift (both or neither, [Cin] floats): x is the previous convolution's RAW output, its BatchNorm + ReLU is applied to
+// the staged input patch in LDS (pad positions become the zeros the taps expect) — saves the bn_apply_pp pass between two convolutions
 int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
-                   hipStream_t s);
+                   hipStream_t s, const float* in_scale = nullptr, const float* in_shift = nullptr);
 // 7x7/2 stem on the zero-bordered NHWC4 image with the patch + filter staged in LDS (bf16, Cout = 64, Ho % 8 == 0, Wo % 16 == 0)
 bool blt_conv_stem_direct_ok(int dtype, int H, int W, int Hp, int Wp, int Cout);
 int blt_conv_stem_direct_stat_rows(int N, int H, int W);

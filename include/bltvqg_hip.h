@@ -109,6 +109,11 @@ int bltvqg_pp_guard_tail(void);
  * positions is staged in LDS once per 64-channel slice and serves all nine taps (csrc/conv_pp.hip).  w [Cout,3,3,Cin]. */
 int bltvqg_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
                       void* stream);
+/* The same convolution reading the RAW output x_raw of the previous convolution (PP, Cin channels): that convolution's train-mode
+ * BatchNorm + ReLU, max(x * in_scale[c] + in_shift[c], 0) with zeros at pad positions (encoder_cnn.py:17, torchvision BasicBlock
+ * bn1 + relu), is applied to the input patch in LDS — y == bltvqg_conv3x3_pp(bltvqg_bn_apply_pp(x_raw, relu)), without that pass. */
+int bltvqg_conv3x3_pp_bn_relu_in(const void* x_raw, const float* in_scale, const float* in_shift, const void* w, void* y, int N, int H, int W, int Cin,
+                                 int Cout, float* stat_sum, float* stat_sq, void* stream);
 int bltvqg_conv3x3_pp_stat_rows(int N, int H, int W);
 /* general implicit-GEMM convolution (as bltvqg_conv2d) with a PP input and / or PP output (the stride-2 and 1x1 convolutions of the
  * stack, and every convolution in fp32 mode); PP output rows at pad positions are written as zeros */

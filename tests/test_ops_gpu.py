@@ -584,6 +584,53 @@ def test_conv3x3_pp_exact_integer_and_stats(geom):
     assert torch.equal(yview[:, :H, :W].float().cpu().double(), ref.float().to(dtype).double())
 
 
+@pytest.mark.parametrize("geom", [(64, 64, 56, 56, 2), (64, 64, 24, 40, 37), (128, 128, 28, 28, 3), (256, 256, 14, 14, 2), (512, 512, 7, 7, 5),
+                                  (64, 128, 9, 13, 1), (192, 64, 5, 62, 1), (512, 512, 7, 7, 64)])
+def test_conv3x3_pp_with_input_batchnorm_relu_fused(geom):
+    """bltvqg_conv3x3_pp_bn_relu_in == bltvqg_conv3x3_pp o bltvqg_bn_apply_pp(relu): the BatchNorm + ReLU of the previous convolution
+    applied on the staged patch in LDS.  The raw input carries GARBAGE (NaN / huge values) at its pad positions and in both guards, as
+    a convolution leaves them: they must read as the zero padding.  Bit-identical outputs and statistics (same arithmetic per element)."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    lib = G.lib()
+    cin, cout, H, W, N = geom
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(cin + cout + H + N)
+    x = torch.randn(N, H, W, cin, generator=g) * 2
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    scale = torch.randn(cin, generator=g)            # both signs, and one exact zero
+    scale[3] = 0.0
+    shift = torch.randn(cin, generator=g)
+    xbuf, xbody, xview = _pp_alloc(N, H, W, cin, dtype, fill=float("nan"))
+    xbuf[:lib.bltvqg_pp_guard_front()] = 3.0e38
+    xbuf[lib.bltvqg_pp_guard_front() + xbody.shape[0]:] = float("nan")
+    xview[:, :H, :W] = x.to(dtype).cuda()
+    wp = G.conv_pack_w(w.cuda(), dtype, cin)
+    rows = lib.bltvqg_conv3x3_pp_stat_rows(N, H, W)
+    res = []
+    for fused in (True, False):
+        ybuf, ybody, yview = _pp_alloc(N, H, W, cout, dtype, fill=7.0)
+        ssum = torch.zeros(rows, cout, device="cuda")
+        ssq = torch.zeros(rows, cout, device="cuda")
+        if fused:
+            check(lib.bltvqg_conv3x3_pp_bn_relu_in(ptr(xbody), ptr(scale.cuda()), ptr(shift.cuda()), ptr(wp), ptr(ybody), N, H, W, cin, cout, ptr(ssum),
+                                                   ptr(ssq), stream_ptr()), "conv3x3_pp_bn_relu_in")
+        else:
+            abuf, abody, aview = _pp_alloc(N, H, W, cin, dtype)
+            check(lib.bltvqg_bn_apply_pp(G.DT[dtype], ptr(xbody), ptr(scale.cuda()), ptr(shift.cuda()), None, ptr(abody), N, H, W, cin, 1, stream_ptr()),
+                  "bn_apply_pp")
+            check(lib.bltvqg_conv3x3_pp(ptr(abody), ptr(wp), ptr(ybody), N, H, W, cin, cout, ptr(ssum), ptr(ssq), stream_ptr()), "conv3x3_pp")
+        torch.cuda.synchronize()
+        res.append((yview[:, :H, :W].float().cpu(), ssum.cpu(), ssq.cpu()))
+    assert torch.isfinite(res[0][0]).all()
+    assert torch.equal(res[0][0], res[1][0]), float((res[0][0] - res[1][0]).abs().max())
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+    # and against torch on the bf16-rounded activation
+    act = torch.relu(x.to(dtype).float() * scale + shift).to(dtype).float()
+    ref = F.conv2d(act.permute(0, 3, 1, 2).double(), w.to(dtype).double(), None, 1, 1).permute(0, 2, 3, 1)
+    assert (res[0][0].double() - ref).abs().max() < 2e-2 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("geom", [(64, 128, 3, 2, 1, 20, 20, 1, 1), (64, 128, 1, 2, 0, 20, 20, 1, 1), (64, 64, 3, 1, 1, 12, 10, 1, 1),
                                   (64, 64, 3, 1, 1, 12, 10, 0, 1), (64, 64, 3, 2, 1, 11, 13, 1, 0), (128, 256, 3, 2, 1, 28, 28, 1, 1)])

@@ -420,7 +420,7 @@ def main():
                     "kernel_time_ms_per_step": round(us * launches * 1e-3, 3)}
         roof = family(gemm_ms, gemm_n, gemm_flops,
                       "every Linear-layer GEMM of the step (attention q|k|v / output projections, FFN, embedding, vocabulary projection, latent "
-                      "nets: forward gemm_nt_kernel / gemm_dma_kernel<*,*,plain,*>, input gradients through the transposed weight shadow, weight "
+                      "nets: forward gemm_nt2_kernel<Nt2<BM,BN,..>> (gemm_dma_kernel<*,*,plain,*> for M < 256), input gradients through the transposed weight shadow, weight "
                       "gradients gemm_kernel<bf16,*,*,T,T> / wgrad_group_kernel); flops = 2*M*N*K per launch")
         roof_conv = family(conv_ms, conv_n, conv_flops,
                            "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), conv_stem_direct_kernel (1), "

@@ -62,6 +62,9 @@ SIGNATURES = {
     "bltvqg_conv_pack_w": (I, [I, P, P, I, I, I, I, I, I, P]),
     "bltvqg_conv_stem": (I, [I, P, P, P, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv_stem_stat_rows": (I, [I, I, I, I]),
+    "bltvqg_conv_stem_pool": (I, [P, P, P, P, I, I, I, I, I, P, P, P]),
+    "bltvqg_conv_stem_pool_ok": (I, [I, I, I, I, I, I]),
+    "bltvqg_conv_stem_pool_stat_rows": (I, [I, I, I]),
     "bltvqg_layernorm_fwd": (I, [I, P, P, P, P, P, P, L, I, F, P]),
     "bltvqg_layernorm_bwd": (I, [I, P, P, P, P, P, P, P, P, P, L, I, P]),
     "bltvqg_bn_scratch_doubles": (I, [I]),

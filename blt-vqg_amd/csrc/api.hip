@@ -202,6 +202,14 @@ int bltvqg_conv_stem(int dtype, const void* x_padded, const void* w, void* y, in
     g.stat_sum = stat_sum; g.stat_sq = stat_sq;
     return blt_gemm(dtype, g, (hipStream_t)stream);
 }
+// stem + 3x3/2 max-pool in one launch (bf16, Cout 64, Ho % 8 == 0, Wo % 14 == 0): pooling-window extrema of the raw convolution output
+// (max where gamma >= 0, min where gamma < 0) into the pooled PP tensor, BatchNorm partial sums of every output
+int bltvqg_conv_stem_pool(const void* x_padded, const void* w, const float* gamma, void* y_pool_pp, int N, int H, int W, int Hp, int Wp,
+                          float* stat_sum, float* stat_sq, void* stream) {
+    return blt_conv_stem_pool(x_padded, w, gamma, y_pool_pp, N, H, W, Hp, Wp, stat_sum, stat_sq, (hipStream_t)stream);
+}
+int bltvqg_conv_stem_pool_ok(int dtype, int H, int W, int Hp, int Wp, int Cout) { return blt_conv_stem_pool_ok(dtype, H, W, Hp, Wp, Cout) ? 1 : 0; }
+int bltvqg_conv_stem_pool_stat_rows(int N, int H, int W) { return blt_conv_stem_pool_stat_rows(N, H, W); }
 int bltvqg_conv_stem_stat_rows(int N, int H, int W, int Cout) {
     // an upper bound valid for both kernels (the bf16 LDS-patch kernel writes 2 rows per 8x16 tile, the implicit GEMM 2 per M tile);
     // rows that are not written must be zero (they are summed)

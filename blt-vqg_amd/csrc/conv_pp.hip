@@ -444,7 +444,177 @@ __global__ __launch_bounds__(256) void conv_stem_direct_kernel(const StemArgs p)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Stem + max-pool in one launch ("pooled extrema").  relu(bn(x)) is monotone in x with the sign of the BatchNorm scale, and that sign
+// is the sign of gamma (a frozen parameter, known before the batch statistics are): so max_pool(relu(bn(x))) == relu(bn(ext(x))) with
+// ext = max over the 3x3/2 window where gamma >= 0 and min where gamma < 0 — bit for bit, because the affine map is applied to
+// the same bf16-rounded convolution outputs either way.  The kernel therefore writes ONE extremum per pooled pixel and channel
+// (103 MB at B = 256) instead of the 411 MB pre-pool tensor that bn_relu_maxpool read back, plus the BatchNorm partial sums of ALL
+// convolution outputs; bn_apply_pp (+ReLU) on the pooled tensor finishes it once the statistics are known.
+//
+// A workgroup owns 4 x 7 pooled pixels = convolution rows 8th-1 .. 8th+7 and columns 14tw-1 .. 14tw+13; it computes a 10 x 16 tile
+// (rows 8th-1 .. 8th+8, columns 14tw-1 .. 14tw+14: 1.43x the MFMA work of the 8 x 16 tiles, the stem is write-bound) from a 25 x 38
+// pixel patch.  Row / column -1 are the pool's padding (never selected); a convolution output enters the statistics in exactly one
+// workgroup (tile rows 1..8, columns 1..14).  Patch chunks that would start outside the padded image read a zero page.
+// ---------------------------------------------------------------------------------------------------------------
+struct StemPoolArgs {
+    const bf16* X;
+    const bf16* Wt;
+    const float* gamma;      // [64] BatchNorm weight: its sign selects max / min
+    bf16* Y;                 // pooled PP output [N][Ho/2 + 1][Wo/2 + 1][64]: real pixels only
+    int N, Hp, Wp, Ho, Wo;
+    float *stat_sum, *stat_sq;
+};
+constexpr int STEMP_PATCH_BYTES = 8 * 1024;     // 25 rows x 19 chunks = 475 chunks -> 8 DMA instructions
+
+__global__ __launch_bounds__(256) void conv_stem_pool_kernel(const StemPoolArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
+    const int tiles_w = p.Wo / 14, tiles_h = p.Ho >> 3;
+    const int b = blockIdx.x;
+    const int n = b / (tiles_w * tiles_h), rem = b - n * (tiles_w * tiles_h);
+    const int th = rem / tiles_w, tw = rem - th * tiles_w;
+    const int or0 = 8 * th - 1, oc0 = 14 * tw - 1;          // convolution row / column of tile position (0, 0)
+    char* const patch = smem;
+    char* const wl = smem + STEMP_PATCH_BYTES;
+
+    // ---- LDS-DMA: patch (instructions 0..7), filter planes (28 instructions); instruction ii = j*4 + wave ----
+    const bf16* ximg = p.X + (size_t)n * p.Hp * p.Wp * 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int ii = j * 4 + wave;
+        const int c = ii * 64 + lane;
+        const int row = c / 19, cc = c - row * 19;
+        int ir = 2 * or0 + row;                              // padded-image row of patch row `row`
+        ir = ir < 0 ? 0 : (ir > p.Hp - 1 ? p.Hp - 1 : ir);   // clamped rows feed only tile positions outside the image (never used)
+        const int ic = 2 * oc0 + 2 * cc;                     // first of the chunk's two pixels
+        const void* src = (c < 25 * 19 && ic >= 0 && ic + 1 < p.Wp) ? (const void*)(ximg + ((size_t)ir * p.Wp + ic) * 4) : (const void*)g_zero16;
+        dma16(src, patch + ii * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+        const int ii = j * 4 + wave;
+        const int c = ii * 64 + lane;                    // chunk (r, cout, q): c = (r*64 + cout)*4 + q
+        const int q = c & 3, co = (c >> 2) & 63, r = c >> 8;
+        dma16(p.Wt + co * 224 + r * 32 + q * 8, wl + ii * 1024);
+    }
+
+    f32x4 acc[5][2];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        bf16x8 af[5], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+            af[i] = *reinterpret_cast<const bf16x8*>(patch + (2 * (wm * 5 + i) + r) * STEM_PITCH + (l15 + lg) * 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            bfr[j] = *reinterpret_cast<const bf16x8*>(wl + ((r * 64 + wn * 32 + j * 16 + l15) * 4 + lg) * 16);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+
+    // ---- BatchNorm partial statistics over the positions this workgroup OWNS (tile rows 1..8, columns 1..14): per wave row ----
+    if (p.stat_sum != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                const int orow = wm * 5 + i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ocol = lg * 4 + r;
+                    const bool own = orow >= 1 && orow <= 8 && ocol >= 1 && ocol <= 14;
+                    const float v = own ? acc[i][j][r] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lg == 0) {
+                const size_t o = (size_t)(b * 2 + wm) * 64 + wn * 32 + j * 16 + l15;
+                p.stat_sum[o] = s1;
+                p.stat_sq[o] = s2;
+            }
+        }
+    }
+    // ---- bf16 tile -> LDS (what the unfused path stored and bn_relu_maxpool read back): position (orow, ocol) at (orow*16 + ocol) ----
+    constexpr int CSB = 72;
+    bf16* Cs = reinterpret_cast<bf16*>(smem);
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Cs[((wm * 5 + i) * 16 + lg * 4 + r) * CSB + wn * 32 + j * 16 + l15] = (bf16)acc[i][j][r];
+    __syncthreads();
+    // ---- 3x3 / 2 pooling window extrema: 4 x 7 pooled pixels x 8 channel chunks = 224 items ----
+    if (tid < 28 * 8) {
+        const int pix = tid >> 3, ch = (tid & 7) * 8;
+        const int pp = pix / 7, qq = pix - pp * 7;
+        float g[8];
+        Vec8<float>::load(p.gamma + ch, g);
+        float e[8];
+        bool first = true;
+#pragma unroll
+        for (int dr = 0; dr < 3; ++dr)
+#pragma unroll
+            for (int dc = 0; dc < 3; ++dc) {
+                const int orow = 2 * pp + dr, ocol = 2 * qq + dc;
+                if (or0 + orow < 0 || oc0 + ocol < 0) continue;          // the pool's padding (only row / column -1 can be outside)
+                float v[8];
+                Vec8<bf16>::load(Cs + (orow * 16 + ocol) * CSB + ch, v);
+                if (first) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = v[k];
+                    first = false;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = (g[k] >= 0.f) ? fmaxf(e[k], v[k]) : fminf(e[k], v[k]);
+                }
+            }
+        const int Hq = (p.Ho >> 1) + 1, Wq = (p.Wo >> 1) + 1;             // PP pitch of the pooled tensor
+        bf16* dst = p.Y + (((size_t)n * Hq + 4 * th + pp) * Wq + 7 * tw + qq) * 64 + ch;
+        Vec8<bf16>::store(dst, e);
+    }
+}
+
 }  // namespace
+
+bool blt_conv_stem_pool_ok(int dtype, int H, int W, int Hp, int Wp, int Cout) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    return dtype == BLT_BF16 && Cout == 64 && Ho % 8 == 0 && Wo % 14 == 0 && Hp >= H + 6 && Wp >= W + 6 && Wp % 2 == 0;
+}
+int blt_conv_stem_pool_stat_rows(int N, int H, int W) {
+    const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
+    return 2 * N * (Ho / 8) * (Wo / 14);
+}
+int blt_conv_stem_pool(const void* x_padded, const void* w, const float* gamma, void* y_pool_pp, int N, int H, int W, int Hp, int Wp, float* stat_sum,
+                       float* stat_sq, hipStream_t s) {
+    BLT_REQUIRE(x_padded && w && gamma && y_pool_pp && N > 0 && blt_conv_stem_pool_ok(BLT_BF16, H, W, Hp, Wp, 64), "conv_stem_pool: unsupported geometry");
+    BLT_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv_stem_pool: stat_sum and stat_sq go together");
+    BLT_REQUIRE(((uintptr_t)x_padded % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y_pool_pp % 16) == 0 && ((uintptr_t)gamma % 16) == 0,
+                "conv_stem_pool: operands must be 16-byte aligned");
+    StemPoolArgs a;
+    a.X = (const bf16*)x_padded; a.Wt = (const bf16*)w; a.gamma = gamma; a.Y = (bf16*)y_pool_pp; a.N = N; a.Hp = Hp; a.Wp = Wp;
+    a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
+    const long grid = (long)N * (a.Ho / 8) * (a.Wo / 14);
+    BLT_REQUIRE(grid < (1L << 31), "conv_stem_pool: too many tiles");
+    hipLaunchKernelGGL(conv_stem_pool_kernel, dim3((unsigned)grid), dim3(256), STEMP_PATCH_BYTES + STEM_W_BYTES, s, a);
+    return blt_check_launch("conv_stem_pool");
+}
 
 bool blt_conv_stem_direct_ok(int dtype, int H, int W, int Hp, int Wp, int Cout) {
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;

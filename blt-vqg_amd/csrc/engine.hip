@@ -830,6 +830,10 @@ struct bltvqg_engine {
     bool conv_is_direct(const ConvSpec& cs) const {
         return cs.pp && dt == BLT_BF16 && cs.K == 3 && cs.stride == 1 && cs.pad == 1 && cs.Cin % 64 == 0 && cs.Cout % 64 == 0 && cs.Wo <= 62;
     }
+    // stem + max-pool as one launch writing pooling-window extrema (conv_pp.hip); debug key 18 = 1: the two-pass form
+    bool stem_pooled() const {
+        return !regions && blt_debug_get(18) != 1 && blt_conv_stem_pool_ok(dt, c.image_h, c.image_w, imgHp, imgWp, convs.empty() ? 0 : convs[0].Cout);
+    }
     int conv_fwd(ConvSpec& cs, const void* x, hipStream_t s, const ConvSpec* in_bn = nullptr) {
         const bool stem = cs.Cin < 8;
         // 3x3 stride-1 convolutions on padded-pitch bf16 activations: the LDS-patch kernel (conv_pp.hip); everything else (stem,
@@ -852,7 +856,9 @@ struct bltvqg_engine {
         if (bn_train) { g.stat_sum = stat_sum; g.stat_sq = stat_sq; }
         const int pi = prof_begin(0, s);
         const bool direct_stem = stem && blt_conv_stem_direct_ok(dt, c.image_h, c.image_w, imgHp, imgWp, cs.Cout);
-        if (direct) RC(blt_conv3x3_pp(x, cs.wpacked, cs.out, B, cs.Ho, cs.Wo, cs.Cin, cs.Cout, g.stat_sum, g.stat_sq, s, in_bn ? in_bn->scale : nullptr,
+        const bool pooled_stem = stem && stem_pooled();
+        if (pooled_stem) RC(blt_conv_stem_pool(x, cs.wpacked, FZ(cs.bnname + ".weight"), pool0, B, c.image_h, c.image_w, imgHp, imgWp, g.stat_sum, g.stat_sq, s));
+        else if (direct) RC(blt_conv3x3_pp(x, cs.wpacked, cs.out, B, cs.Ho, cs.Wo, cs.Cin, cs.Cout, g.stat_sum, g.stat_sq, s, in_bn ? in_bn->scale : nullptr,
                                       in_bn ? in_bn->shift : nullptr));
         else if (direct_stem) RC(blt_conv_stem_direct(x, cs.wpacked, cs.out, B, c.image_h, c.image_w, imgHp, imgWp, g.stat_sum, g.stat_sq, s));
         else RC(blt_gemm(dt, g, s));
@@ -860,7 +866,8 @@ struct bltvqg_engine {
         if (!bn_train)
             return blt_bn_eval_scale(FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"),
                                      1e-5f, cs.scale, cs.shift, cs.Cout, s);
-        const int nparts = direct ? blt_conv3x3_pp_stat_rows(B, cs.Ho, cs.Wo)
+        const int nparts = pooled_stem ? blt_conv_stem_pool_stat_rows(B, c.image_h, c.image_w)
+                           : direct ? blt_conv3x3_pp_stat_rows(B, cs.Ho, cs.Wo)
                            : direct_stem ? blt_conv_stem_direct_stat_rows(B, c.image_h, c.image_w) : blt_gemm_stat_rows(g, dt);
         return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)B * cs.Ho * cs.Wo, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
                                0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,
@@ -899,7 +906,8 @@ struct bltvqg_engine {
         size_t ci = 0;
         ConvSpec& c1 = convs[ci++];
         RC(conv_fwd(c1, img, s));
-        RC(blt_bn_relu_maxpool_pp(dt, c1.out, c1.scale, c1.shift, pool0, B, c1.Ho, c1.Wo, 64, s));
+        if (stem_pooled()) RC(blt_bn_apply_pp(dt, pool0, c1.scale, c1.shift, nullptr, nullptr, nullptr, pool0, B, c1.Ho / 2, c1.Wo / 2, 64, 1, s));
+        else RC(blt_bn_relu_maxpool_pp(dt, c1.out, c1.scale, c1.shift, pool0, B, c1.Ho, c1.Wo, 64, s));
         const void* x = pool0;
         int cin = 64;
         const int couts[4] = {64, 128, 256, 512};

@@ -106,6 +106,12 @@ int blt_conv3x3_pp_stat_rows(int N, int H, int W);       // partial rows written
 int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
                    hipStream_t s, const float* in_scale = nullptr, const float* in_shift = nullptr);
 // 7x7/2 stem on the zero-bordered NHWC4 image with the patch + filter staged in LDS (bf16, Cout = 64, Ho % 8 == 0, Wo % 16 == 0)
+// stem + 3x3/2 max-pool in one launch: writes the pooling-window EXTREMUM (max where gamma >= 0, min where gamma < 0) of the raw
+// convolution output into the pooled PP tensor + the BatchNorm partial sums of all outputs; bn_apply_pp(relu) finishes it
+bool blt_conv_stem_pool_ok(int dtype, int H, int W, int Hp, int Wp, int Cout);
+int blt_conv_stem_pool_stat_rows(int N, int H, int W);
+int blt_conv_stem_pool(const void* x_padded, const void* w, const float* gamma, void* y_pool_pp, int N, int H, int W, int Hp, int Wp, float* stat_sum,
+                       float* stat_sq, hipStream_t s);
 bool blt_conv_stem_direct_ok(int dtype, int H, int W, int Hp, int Wp, int Cout);
 int blt_conv_stem_direct_stat_rows(int N, int H, int W);
 int blt_conv_stem_direct(const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, float* stat_sum, float* stat_sq,

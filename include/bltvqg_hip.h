@@ -139,6 +139,16 @@ int bltvqg_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, 
 int bltvqg_conv_stem(int dtype, const void* x_padded, const void* w, void* y, int N, int H, int W, int Hp, int Wp, int Cout,
                      float* stat_sum, float* stat_sq, void* stream);
 int bltvqg_conv_stem_stat_rows(int N, int H, int W, int Cout);
+/* Stem + MaxPool2d(3, 2, 1) in ONE launch (torchvision resnet conv1 -> bn1 -> relu -> maxpool, encoder_cnn.py:17,33).  relu(bn(x)) is monotone
+ * in x with the sign of the BatchNorm scale = the sign of gamma, so the kernel writes the pooling-window EXTREMUM of the raw convolution
+ * output (max where gamma[c] >= 0, min where gamma[c] < 0) into the pooled padded-pitch tensor y_pool_pp [N][Ho/2+1][Wo/2+1][64] (real pixels
+ * only) and the BatchNorm partial sums of ALL convolution outputs (bltvqg_conv_stem_pool_stat_rows() rows of 64); bltvqg_bn_apply_pp(relu)
+ * on y_pool_pp with the finalised scale / shift then equals bn -> relu -> maxpool of the stored pre-pool tensor bit for bit, without
+ * writing and re-reading that tensor.  bf16, Cout = 64, Ho % 8 == 0 and Wo % 14 == 0 (bltvqg_conv_stem_pool_ok). */
+int bltvqg_conv_stem_pool(const void* x_padded, const void* w, const float* gamma, void* y_pool_pp, int N, int H, int W, int Hp, int Wp,
+                          float* stat_sum, float* stat_sq, void* stream);
+int bltvqg_conv_stem_pool_ok(int dtype, int H, int W, int Hp, int Wp, int Cout);
+int bltvqg_conv_stem_pool_stat_rows(int N, int H, int W);
 
 int bltvqg_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                          int64_t rows, int cols, float eps, void* stream);

@@ -184,6 +184,57 @@ def test_conv2d_exact_integer_and_stats(dtype, geom):
     assert torch.equal(ssq.double().sum(0).cpu(), (ref.reshape(-1, cout) ** 2).sum(0))
 
 
+@pytest.mark.parametrize("geom", [(2, 224, 224), (5, 32, 56), (1, 16, 28), (3, 48, 84)])
+def test_stem_with_pooled_extrema_equals_conv_bn_relu_maxpool(geom):
+    """bltvqg_conv_stem_pool + bn_apply_pp(relu) == conv_stem -> bn -> relu -> maxpool(3, 2, 1) (encoder_cnn.py:17,33): the pooling
+    window's max (gamma >= 0) / min (gamma < 0) of the raw convolution output commutes with the monotone BatchNorm + ReLU.  Real-valued
+    data, gammas of both signs and an exact zero: the pooled tensors are bit-identical; the statistics equal the direct kernel's sums."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    lib = G.lib()
+    N, Hi, Wi = geom
+    dtype = torch.bfloat16
+    g = torch.Generator().manual_seed(N + Hi + Wi)
+    x = torch.randn(N, 3, Hi, Wi, generator=g)
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.1
+    gamma = torch.randn(64, generator=g)
+    gamma[5] = 0.0
+    gamma[6] = -0.0
+    beta = torch.randn(64, generator=g)
+    Ho, Wo = Hi // 2, Wi // 2
+    Hp, Wp = Hi + 6, Wi + 6
+    assert lib.bltvqg_conv_stem_pool_ok(G.DT[dtype], Hi, Wi, Hp, Wp, 64) == 1
+    xp = G.img_pack(x.cuda(), dtype, 4, 3, 3, Hp, Wp)
+    wp = G.conv_pack_w(w.cuda(), dtype, 4, 8)
+    # two-pass reference on the GPU: stem -> (scale, shift) -> bn + relu + maxpool into a PP tensor
+    y, ssum, ssq = G.conv_stem(xp, wp, N, Hi, Wi, 64, stats=True)
+    cnt = N * Ho * Wo
+    mean = ssum.double().sum(0) / cnt
+    var = ssq.double().sum(0) / cnt - mean * mean
+    scale = (gamma.double().cuda() / torch.sqrt(var + 1e-5)).float()
+    shift = (beta.double().cuda() - mean * scale.double()).float()
+    Hq, Wq = Ho // 2, Wo // 2
+    pbuf, pbody, pview = _pp_alloc(N, Hq, Wq, 64, dtype)
+    check(lib.bltvqg_bn_relu_maxpool_pp(G.DT[dtype], ptr(y), ptr(scale), ptr(shift), ptr(pbody), N, Ho, Wo, 64, stream_ptr()), "bn_relu_maxpool_pp")
+    # fused: extrema + statistics, then the affine + ReLU on the pooled tensor
+    qbuf, qbody, qview = _pp_alloc(N, Hq, Wq, 64, dtype, fill=9.0)
+    rows = lib.bltvqg_conv_stem_pool_stat_rows(N, Hi, Wi)
+    s1 = torch.zeros(rows, 64, device="cuda"); s2 = torch.zeros(rows, 64, device="cuda")
+    check(lib.bltvqg_conv_stem_pool(ptr(xp), ptr(wp), ptr(gamma.cuda()), ptr(qbody), N, Hi, Wi, Hp, Wp, ptr(s1), ptr(s2), stream_ptr()), "conv_stem_pool")
+    check(lib.bltvqg_bn_apply_pp(G.DT[dtype], ptr(qbody), ptr(scale), ptr(shift), None, ptr(qbody), N, Hq, Wq, 64, 1, stream_ptr()), "bn_apply_pp")
+    torch.cuda.synchronize()
+    assert torch.equal(qview[:, :Hq, :Wq].float().cpu(), pview[:, :Hq, :Wq].float().cpu())
+    assert float(qview[:, Hq].abs().max()) == 0.0 and float(qview[:, :, Wq].abs().max()) == 0.0
+    a, b = s1.double().sum(0).cpu(), ssum.double().sum(0).cpu()
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-3), float((a - b).abs().max())
+    a, b = s2.double().sum(0).cpu(), ssq.double().sum(0).cpu()
+    assert torch.allclose(a, b, rtol=1e-5, atol=1e-3), float((a - b).abs().max())
+    # and against torch end to end (bf16 tolerance)
+    conv = F.conv2d(x.to(dtype).float(), w.to(dtype).float(), None, 2, 3)
+    ref = F.max_pool2d(torch.relu(conv * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)), 3, 2, 1).permute(0, 2, 3, 1)
+    assert (qview[:, :Hq, :Wq].float().cpu() - ref).abs().max() < 3e-2 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_batchnorm2d_train_pipeline(dtype):
     """conv statistics -> finalize (scale/shift + running stats) -> apply(+residual, relu) / relu+maxpool / avgpool."""

@@ -46,9 +46,15 @@ struct ConvPPArgs {
 
 // NSTB = stages of the weight ring: 2 (one tap in flight; two workgroups per CU cover each other's waits) or 4 (three taps in flight, for
 // grids that leave a workgroup alone on its CU, e.g. the 7x7x512 layer: 256 tiles)
-template <int BN, int NSTB, bool FUSE_IN>
-__global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
-    constexpr int WN = BN / 2, TN = WN / 16, TM = 4, CH_B = BN * 8 / 256, B_STAGE = BN * 128, CSB = BN + 8, AHEAD = NSTB - 1;
+// NWM = wave rows: 2 -> 128 positions per workgroup, 4 waves (two or three workgroups per CU); 4 -> 256 positions, 8 waves, ONE workgroup per
+// CU with a 4-stage ring: with a single tap in flight every tap of the 128-position form waits a full L2->LDS round trip (1.1-1.4 us per tap
+// measured against 0.2 us of MFMAs per wave), and LDS has no room for a deeper ring beside a second workgroup; the 256-position form keeps
+// three taps (3 x 0.43 us of MFMA time per SIMD) in flight and halves the weight bytes per output position
+template <int BN, int NSTB, bool FUSE_IN, int NWM>
+__global__ __launch_bounds__(NWM * 128) void conv3x3_pp_kernel(const ConvPPArgs p) {
+    constexpr int NW = NWM * 2, NT = NW * 64, BM = NWM * 64;
+    constexpr int WN = BN / 2, TN = WN / 16, TM = 4, CH_B = BN * 8 / NT, B_STAGE = BN * 128, CSB = BN + 8, AHEAD = NSTB - 1;
+    static_assert(BN * 8 % NT == 0, "weight tile chunks per thread");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,28 +64,28 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     if (p.chunked) b = (b & 7) * ((int)gridDim.x >> 3) + (b >> 3);     // hardware deals workgroup ids round-robin over the 8 XCDs
     if (b >= p.nblocks) return;
     const int tile_m = b / p.tiles_n, tile_n = b - tile_m * p.tiles_n;
-    const long q0 = (long)tile_m * 128;
+    const long q0 = (long)tile_m * BM;
     const int n0 = tile_n * BN;
     const int pitch = p.W + 1;
     const int NS = p.Cin >> 6, nsteps = 9 * NS;
-    const int patch_bytes = p.pw * 4096;
+    const int patch_bytes = p.pw * NW * 1024;
     char* const patch0 = smem;
     char* const patch1 = smem + (NS > 1 ? patch_bytes : 0);
     char* const ring = smem + (NS > 1 ? 2 : 1) * patch_bytes;
     float* const valid = reinterpret_cast<float*>(smem + p.valid_off);
 
-    // patch row pp <-> input pixel q0 - pitch - 1 + pp; DMA instruction ii = j*4 + wave covers rows ii*8 .. ii*8+7, LDS slot
+    // patch row pp <-> input pixel q0 - pitch - 1 + pp; DMA instruction ii = j*NW + wave covers rows ii*8 .. ii*8+7, LDS slot
     // (lane & 7) of row pp holds global chunk (lane & 7) ^ (pp & 7)
     const bf16* const xb = p.X + (q0 - pitch - 1) * (long)p.Cin;
     auto issue_patch = [&](int sl, int j) {
-        const int pp = (j * 4 + wave) * 8 + (lane >> 3);
+        const int pp = (j * NW + wave) * 8 + (lane >> 3);
         const int off = pp * p.Cin + ((((lane & 7) ^ (pp & 7))) << 3) + (sl << 6);
-        dma16(xb + off, ((sl & 1) ? patch1 : patch0) + (j * 4 + wave) * 1024);
+        dma16(xb + off, ((sl & 1) ? patch1 : patch0) + (j * NW + wave) * 1024);
     };
     long b_off[CH_B];
 #pragma unroll
     for (int j = 0; j < CH_B; ++j) {
-        const int r = (j * 4 + wave) * 8 + (lane >> 3);
+        const int r = (j * NW + wave) * 8 + (lane >> 3);
         b_off[j] = (n0 + r < p.Cout) ? (long)(n0 + r) * (9 * p.Cin) + ((((lane & 7) ^ (r & 7))) << 3) : -1;
     }
     auto issue_b = [&](int s, int sl, int t) {
@@ -88,16 +94,16 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
 #pragma unroll
         for (int j = 0; j < CH_B; ++j) {
             const void* src = (b_off[j] >= 0) ? (const void*)(p.Wt + b_off[j] + k0) : (const void*)g_zero16;
-            dma16(src, st + (j * 4 + wave) * 1024);
+            dma16(src, st + (j * NW + wave) * 1024);
         }
     };
 
-    // FUSE_IN: this thread transforms chunk (j*256 + tid) of a patch slice, j < pw: patch row j*32 + (tid >> 3), always the same 8
+    // FUSE_IN: this thread transforms chunk (j*NT + tid) of a patch slice, j < pw: patch row j*NW*8 + (tid >> 3), always the same 8
     // channels of the slice.  Which of its rows are real pixels (not PP pads, guards or past the end) is one bit each, computed once.
     unsigned vbits = 0;
     if constexpr (FUSE_IN) {
         for (int j = 0; j < p.pw; ++j) {
-            const long q = q0 - pitch - 1 + j * 32 + (tid >> 3);
+            const long q = q0 - pitch - 1 + j * (NW * 8) + (tid >> 3);
             if (q >= 0 && q < p.Mq) {
                 const unsigned row = (unsigned)q / (unsigned)pitch;
                 const int w = (int)((unsigned)q - row * (unsigned)pitch), h = (int)(row % (unsigned)(p.H + 1));
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     // FUSE_IN staging: the piece goes global -> registers -> (BatchNorm + ReLU, pad mask) -> LDS, into the slot the DMA would have
     // filled; an in-place LDS pass after a DMA was measured at +26 us per launch (LDS bandwidth is what bounds this kernel)
     auto load_piece = [&](int sl_, int j) -> bf16x8 {
-        const int pp = (j * 4 + wave) * 8 + (lane >> 3);
+        const int pp = (j * NW + wave) * 8 + (lane >> 3);
         return *reinterpret_cast<const bf16x8*>(xb + (long)pp * p.Cin + ((((lane & 7) ^ (pp & 7))) << 3) + (sl_ << 6));
     };
     auto load_bn = [&](int sl_, float (&sc)[8], float (&sh)[8]) {
@@ -120,7 +126,7 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
         const bool ok = (vbits >> j) & 1u;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = ok ? (bf16)fmaxf((float)v[e] * sc[e] + sh[e], 0.f) : (bf16)0.f;
-        *reinterpret_cast<bf16x8*>(((sl_ & 1) ? patch1 : patch0) + (j * 256 + tid) * 16) = v;
+        *reinterpret_cast<bf16x8*>(((sl_ & 1) ? patch1 : patch0) + (j * NT + tid) * 16) = v;
     };
     float nsc[8], nsh[8];      // FUSE_IN: scale / shift of this thread's 8 channels of the slice being staged
     bf16x8 staged;
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     // ---- BatchNorm partial statistics of the raw result: rows of wave row wm = half tile wm (encoder_cnn.py:33) ----
     if (p.stat_sum != nullptr) {
         // which of the 128 output positions are real pixels (not PP pads, not beyond the end): a table behind the staging area
-        if (tid < 128) {
+        if (tid < BM) {
             const unsigned q = (unsigned)(q0 + tid);                  // < 2^31 positions (checked on the host)
             const unsigned row = q / (unsigned)pitch;
             const int w = (int)(q - row * (unsigned)pitch), h = (int)(row % (unsigned)(p.H + 1));
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
             s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
             if (lg == 0) {
-                const size_t o = (size_t)(tile_m * 2 + wm) * p.Cout + n0 + wn * WN + j * 16 + l15;
+                const size_t o = (size_t)(tile_m * NWM + wm) * p.Cout + n0 + wn * WN + j * 16 + l15;
                 p.stat_sum[o] = s1;
                 p.stat_sq[o] = s2;
             }
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     __syncthreads();
     constexpr int CPR = BN / 8;
 #pragma unroll
-    for (int c = tid; c < 128 * CPR; c += 256) {
+    for (int c = tid; c < BM * CPR; c += NT) {
         const int row = c / CPR, ch = c - row * CPR;
         const long q = q0 + row;
         if (q < p.Mq)
@@ -255,10 +261,10 @@ __global__ __launch_bounds__(256) void conv3x3_pp_kernel(const ConvPPArgs p) {
     }
 }
 
-template <int BN, int NSTB, bool FUSE_IN>
+template <int BN, int NSTB, bool FUSE_IN, int NWM = 2>
 int launch(const ConvPPArgs& a, int grid, size_t lds, hipStream_t s) {
     static bool attr_set = false;
-    auto kern = conv3x3_pp_kernel<BN, NSTB, FUSE_IN>;
+    auto kern = conv3x3_pp_kernel<BN, NSTB, FUSE_IN, NWM>;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             blt_set_error("conv3x3_pp: hipFuncSetAttribute failed");
@@ -266,14 +272,41 @@ int launch(const ConvPPArgs& a, int grid, size_t lds, hipStream_t s) {
         }
         attr_set = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * 128), lds, s, a);
     return blt_check_launch("conv3x3_pp");
 }
 
 }  // namespace
 
 long blt_pp_pixels(int N, int H, int W) { return (long)N * (H + 1) * (W + 1); }
-int blt_conv3x3_pp_stat_rows(int N, int H, int W) { return 2 * cdiv(blt_pp_pixels(N, H, W), 128); }
+// Tile plan shared by the launch and by the count of statistics rows: `wide` = the 256-position / 8-wave / 4-stage form (layers with
+// Cout % 128 == 0 whose patch slices and ring fit 160 KB; debug key 19 = 2 — OFF by default: measured 90-94 us against 82-88 us for the
+// 128-position form at B = 256), else 128 positions with BN = 128 or 64.
+struct ConvPPPlan { bool wide; int BN; int pw; };
+static ConvPPPlan conv_pp_plan(int N, int H, int W, int Cin, int Cout) {
+    ConvPPPlan pl;
+    const int NS = Cin / 64;
+    const int Pw = 256 + 2 * (W + 1) + 2;
+    const int pww = cdiv(cdiv(Pw, 8), 8);
+    const size_t ldsw = (size_t)(NS > 1 ? 2 : 1) * pww * 8192 + 4 * (size_t)128 * 128;
+    pl.wide = Cout % 128 == 0 && pww <= 8 && ldsw <= 160 * 1024 && pww * 64 - (W + 2) <= BLT_PP_GUARD_TAIL && blt_debug_get(19) == 2;
+    if (pl.wide) { pl.BN = 128; pl.pw = pww; return pl; }
+    pl.pw = cdiv(cdiv(128 + 2 * (W + 1) + 2, 8), 4);
+    pl.BN = (Cout % 128 == 0) ? 128 : 64;
+    // a grid that would leave most CUs with a single workgroup (7x7x512: 256 tiles of 128 channels) runs twice as many half-width
+    // tiles instead: two workgroups per CU cover each other's DMA waits (measured 50 -> 42 us; a deeper ring did not help)
+    if (pl.BN == 128 && (long)cdiv(blt_pp_pixels(N, H, W), 128) * (Cout / 128) <= 320) pl.BN = 64;
+    if (blt_debug_get(4) == 64) pl.BN = 64;
+    if (blt_debug_get(4) == 128 && Cout % 128 == 0) pl.BN = 128;
+    return pl;
+}
+// upper bound for any plan (rows that a launch does not write must be zero: they are summed)
+int blt_conv3x3_pp_stat_rows(int N, int H, int W) { return 4 * cdiv(blt_pp_pixels(N, H, W), 256); }
+// the rows the launch for this layer writes
+int blt_conv3x3_pp_stat_rows_for(int N, int H, int W, int Cin, int Cout) {
+    const ConvPPPlan pl = conv_pp_plan(N, H, W, Cin, Cout);
+    return pl.wide ? 4 * cdiv(blt_pp_pixels(N, H, W), 256) : 2 * cdiv(blt_pp_pixels(N, H, W), 128);
+}
 
 int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,
                    hipStream_t s, const float* in_scale, const float* in_shift) {
@@ -283,36 +316,39 @@ int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, i
     BLT_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "conv3x3_pp: Cin=%d / Cout=%d must be multiples of 64", Cin, Cout);
     BLT_REQUIRE((stat_sum == nullptr) == (stat_sq == nullptr), "conv3x3_pp: stat_sum and stat_sq go together");
     BLT_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 16) == 0, "conv3x3_pp: operands must be 16-byte aligned");
-    const int P = 128 + 2 * (W + 1) + 2;                     // patch pixels
+    const int P = 128 + 2 * (W + 1) + 2;                     // patch pixels of the 128-position form
     BLT_REQUIRE(W + 2 <= BLT_PP_GUARD_FRONT && P <= 256, "conv3x3_pp: W=%d too wide for the patch / guards", W);
+    const ConvPPPlan pl = conv_pp_plan(N, H, W, Cin, Cout);
     ConvPPArgs a;
     a.X = (const bf16*)x; a.Wt = (const bf16*)w; a.Y = (bf16*)y;
     a.Mq = blt_pp_pixels(N, H, W); a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
     a.in_scale = in_scale; a.in_shift = in_shift;
-    a.pw = cdiv(cdiv(P, 8), 4);
-    int BN = (Cout % 128 == 0) ? 128 : 64;
-    // a grid that would leave most CUs with a single workgroup (7x7x512: 256 tiles of 128 channels) runs twice as many half-width
-    // tiles instead: two workgroups per CU cover each other's DMA waits (measured 50 -> 42 us; a deeper ring did not help)
-    if (BN == 128 && (long)cdiv(blt_pp_pixels(N, H, W), 128) * (Cout / 128) <= 320) BN = 64;
-    if (blt_debug_get(4) == 64) BN = 64;
-    if (blt_debug_get(4) == 128 && Cout % 128 == 0) BN = 128;
+    a.pw = pl.pw;
+    const int BN = pl.BN, BM = pl.wide ? 256 : 128;
     a.tiles_n = Cout / BN;
-    a.nblocks = cdiv(a.Mq, 128) * a.tiles_n;
+    a.nblocks = cdiv(a.Mq, BM) * a.tiles_n;
+    BLT_REQUIRE(a.Mq < (1L << 31), "conv3x3_pp: too many positions");
     // weights that fit an XCD's L2 beside the patches: keep neighbouring tiles on one XCD; otherwise the round-robin deal, which
     // gives each XCD every 8th tile and hence only (tiles_n | 8) of the weight slices
     a.chunked = ((long)Cout * 9 * Cin * 2 <= (2L << 20)) ? 1 : 0;
     if (blt_debug_get(5)) a.chunked = blt_debug_get(5) == 1;
     const int grid = a.chunked ? 8 * cdiv(a.nblocks, 8) : a.nblocks;
     const int NS = Cin / 64;
+    const size_t stage = ((size_t)BM * (BN + 8) * 2 + 15) / 16 * 16;      // the staged bf16 output tile; the validity table sits behind it
+    a.valid_off = (int)stage;
+    if (pl.wide) {
+        size_t lds = (size_t)(NS > 1 ? 2 : 1) * a.pw * 8192 + 4 * (size_t)BN * 128;
+        if (lds < stage + 1024) lds = stage + 1024;
+        return in_scale ? launch<128, 4, true, 4>(a, grid, lds, s) : launch<128, 4, false, 4>(a, grid, lds, s);
+    }
     // two workgroups per CU need <= 80 KB each: the validity table (512 B) shares the epilogue's space behind the staged tile
     // a grid that gives most CUs a single workgroup: deep weight ring instead of a partner workgroup
     bool deep = a.nblocks <= 320;
+    // (four stages for the 64-channel layers, which would still fit two workgroups per CU, measured SLOWER: 101 vs 85 us — those layers run
+    // three 48 KB workgroups per CU and lose the third)
     if (blt_debug_get(6)) deep = blt_debug_get(6) == 1;
     size_t lds = (size_t)(NS > 1 ? 2 : 1) * a.pw * 4096 + (deep ? 4 : 2) * (size_t)BN * 128;
-    const size_t stage = ((size_t)128 * (BN + 8) * 2 + 15) / 16 * 16;
     if (lds < stage + 512) lds = stage + 512;
-    a.valid_off = (int)stage;
-    BLT_REQUIRE(a.Mq < (1L << 31), "conv3x3_pp: too many positions");
     // the tile overhang of the last workgroup's patch must stay inside the tail guard
     BLT_REQUIRE(a.pw * 32 - (W + 2) <= BLT_PP_GUARD_TAIL, "conv3x3_pp: tail guard too small");
     if (in_scale != nullptr) {

@@ -867,7 +867,7 @@ struct bltvqg_engine {
             return blt_bn_eval_scale(FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"),
                                      1e-5f, cs.scale, cs.shift, cs.Cout, s);
         const int nparts = pooled_stem ? blt_conv_stem_pool_stat_rows(B, c.image_h, c.image_w)
-                           : direct ? blt_conv3x3_pp_stat_rows(B, cs.Ho, cs.Wo)
+                           : direct ? blt_conv3x3_pp_stat_rows_for(B, cs.Ho, cs.Wo, cs.Cin, cs.Cout)
                            : direct_stem ? blt_conv_stem_direct_stat_rows(B, c.image_h, c.image_w) : blt_gemm_stat_rows(g, dt);
         return blt_bn_finalize(stat_sum, stat_sq, nparts, cs.Cout, (long)B * cs.Ho * cs.Wo, FZ(cs.bnname + ".weight"), FZ(cs.bnname + ".bias"), 1e-5f,
                                0.1f, FZ(cs.bnname + ".running_mean"), FZ(cs.bnname + ".running_var"), cs.scale, cs.shift, nullptr,

@@ -100,7 +100,8 @@ int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, 
 
 // ---- padded-pitch 3x3 stride-1 convolution (conv_pp.hip), bf16 only ----------------
 long blt_pp_pixels(int N, int H, int W);                 // N*(H+1)*(W+1) positions (without the guards)
-int blt_conv3x3_pp_stat_rows(int N, int H, int W);       // partial rows written to stat_sum / stat_sq
+int blt_conv3x3_pp_stat_rows(int N, int H, int W);       // upper bound of the partial rows written to stat_sum / stat_sq (any tile plan)
+int blt_conv3x3_pp_stat_rows_for(int N, int H, int W, int Cin, int Cout);      // exactly the rows the launch for this layer writes
 // in_scale / in_shift (both or neither, [Cin] floats): x is the previous convolution's RAW output, its BatchNorm + ReLU is applied to
 // the staged input patch in LDS (pad positions become the zeros the taps expect) — saves the bn_apply_pp pass between two convolutions
 int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int Cout, float* stat_sum, float* stat_sq,

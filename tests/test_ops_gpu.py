@@ -618,14 +618,20 @@ def test_conv3x3_pp_exact_integer_and_stats(geom):
     wp = G.conv_pack_w(w.cuda(), dtype, cin)
     ybuf, ybody, yview = _pp_alloc(N, H, W, cout, dtype, fill=7.0)
     rows = lib.bltvqg_conv3x3_pp_stat_rows(N, H, W)
-    ssum = torch.zeros(rows, cout, device="cuda")
-    ssq = torch.zeros(rows, cout, device="cuda")
-    check(lib.bltvqg_conv3x3_pp(ptr(xbody), ptr(wp), ptr(ybody), N, H, W, cin, cout, ptr(ssum), ptr(ssq), stream_ptr()), "conv3x3_pp")
-    torch.cuda.synchronize()
-    got = yview[:, :H, :W].float().cpu().double()
-    assert torch.equal(got, ref.float().to(dtype).double()), (got - ref).abs().max()
-    assert torch.equal(ssum.double().sum(0).cpu(), ref.reshape(-1, cout).sum(0))
-    assert torch.equal(ssq.double().sum(0).cpu(), (ref.reshape(-1, cout) ** 2).sum(0))
+    for form in ((0, 2) if cout % 128 == 0 else (0,)):      # debug key 19 = 2: the 256-position / 8-wave tile form (off by default)
+        ybody.fill_(7.0)
+        ssum = torch.zeros(rows, cout, device="cuda")
+        ssq = torch.zeros(rows, cout, device="cuda")
+        lib.bltvqg_debug_set(19, form)
+        try:
+            check(lib.bltvqg_conv3x3_pp(ptr(xbody), ptr(wp), ptr(ybody), N, H, W, cin, cout, ptr(ssum), ptr(ssq), stream_ptr()), "conv3x3_pp")
+            torch.cuda.synchronize()
+        finally:
+            lib.bltvqg_debug_set(19, 0)
+        got = yview[:, :H, :W].float().cpu().double()
+        assert torch.equal(got, ref.float().to(dtype).double()), (form, (got - ref).abs().max())
+        assert torch.equal(ssum.double().sum(0).cpu(), ref.reshape(-1, cout).sum(0))
+        assert torch.equal(ssq.double().sum(0).cpu(), (ref.reshape(-1, cout) ** 2).sum(0))
     gf = lib.bltvqg_pp_guard_front()
     assert float(ybuf[:gf].abs().max()) == 0.0 and float(ybuf[gf + ybody.shape[0]:].abs().max()) == 0.0      # guards untouched
     # without statistics (eval-mode BatchNorm path)

@@ -502,128 +502,172 @@ struct StemPoolArgs {
     float *stat_sum, *stat_sq;
 };
 constexpr int STEMP_PATCH_BYTES = 8 * 1024;     // 25 rows x 19 chunks = 475 chunks -> 8 DMA instructions
+constexpr int STEMP_LDS = STEM_W_BYTES + 2 * STEMP_PATCH_BYTES;      // 28 + 16 KB: three workgroups per CU
 
+__device__ __forceinline__ float dpp_row_shl(float x, int n) {      // lane i of a 16-lane row receives lane i + n (n = 1, 2)
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, n == 1 ? __builtin_amdgcn_update_dpp(v, v, 0x101, 0xF, 0xF, false) : __builtin_amdgcn_update_dpp(v, v, 0x102, 0xF, 0xF, false));
+}
+
+// PERSISTENT, register-resident pooling.  History (B = 256, standalone): one workgroup per tile, tile staged in LDS, pooled from LDS:
+// each workgroup lived 7.9 us for 0.5 us of MFMAs; persistent with the staged tile: 267 us (two 67 KB workgroups per CU, every phase
+// serialised).  Now a workgroup keeps the filter in LDS, walks tiles b, b + grid, ... with the NEXT tile's patch in flight, and pools
+// straight from the accumulators:
+//   * the filter fragment is the MFMA's A operand, so a lane holds tile COLUMN l15 and 4 consecutive channels (lg*4 + r) of 5 tile rows;
+//   * wave row 0 computes tile rows 0..4, wave row 1 rows 4..8 (row 9 was never needed; row 4 is computed twice), so both pooled rows of a
+//     wave — windows over rows {0,1,2} and {2,3,4} of its five — are in-lane maxima, and the three columns of a window are two DPP row
+//     shifts: no LDS staging, no second barrier, 44 KB of LDS;
+//   * max / min by the sign of gamma as max(s*x) with s = +-1 (exact), on the bf16-ROUNDED outputs (what the two-pass form stored);
+//   * BatchNorm partial sums stay in registers for the whole walk: two statistics rows per workgroup (1.5 K rows instead of 57 K).
 __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const StemPoolArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l15 = lane & 15, lg = lane >> 4;
-    const int tiles_w = p.Wo / 14, tiles_h = p.Ho >> 3;
-    const int b = blockIdx.x;
-    const int n = b / (tiles_w * tiles_h), rem = b - n * (tiles_w * tiles_h);
-    const int th = rem / tiles_w, tw = rem - th * tiles_w;
-    const int or0 = 8 * th - 1, oc0 = 14 * tw - 1;          // convolution row / column of tile position (0, 0)
-    char* const patch = smem;
-    char* const wl = smem + STEMP_PATCH_BYTES;
+    const int tiles_w = p.Wo / 14, tiles_h = p.Ho >> 3, per_img = tiles_w * tiles_h;
+    const int ntiles = p.N * per_img;
+    char* const wl = smem;
+    char* const patch0 = smem + STEM_W_BYTES;
 
-    // ---- LDS-DMA: patch (instructions 0..7), filter planes (28 instructions); instruction ii = j*4 + wave ----
-    const bf16* ximg = p.X + (size_t)n * p.Hp * p.Wp * 4;
+    // patch of tile `tile` -> buffer `buf` (two DMA instructions per wave); chunks that would start outside the padded image read zeros
+    auto issue_patch = [&](int tile, int buf) {
+        const int n = tile / per_img, rem = tile - n * per_img;
+        const int th = rem / tiles_w, tw = rem - th * tiles_w;
+        const int or0 = 8 * th - 1, oc0 = 14 * tw - 1;
+        const bf16* ximg = p.X + (size_t)n * p.Hp * p.Wp * 4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int ii = j * 4 + wave;
-        const int c = ii * 64 + lane;
-        const int row = c / 19, cc = c - row * 19;
-        int ir = 2 * or0 + row;                              // padded-image row of patch row `row`
-        ir = ir < 0 ? 0 : (ir > p.Hp - 1 ? p.Hp - 1 : ir);   // clamped rows feed only tile positions outside the image (never used)
-        const int ic = 2 * oc0 + 2 * cc;                     // first of the chunk's two pixels
-        const void* src = (c < 25 * 19 && ic >= 0 && ic + 1 < p.Wp) ? (const void*)(ximg + ((size_t)ir * p.Wp + ic) * 4) : (const void*)g_zero16;
-        dma16(src, patch + ii * 1024);
-    }
+        for (int j = 0; j < 2; ++j) {
+            const int ii = j * 4 + wave;
+            const int c = ii * 64 + lane;
+            const int row = c / 19, cc = c - row * 19;
+            int ir = 2 * or0 + row;                              // padded-image row of patch row `row`
+            ir = ir < 0 ? 0 : (ir > p.Hp - 1 ? p.Hp - 1 : ir);   // clamped rows feed only tile positions outside the image (never used)
+            const int ic = 2 * oc0 + 2 * cc;                     // first of the chunk's two pixels
+            const void* src = (c < 25 * 19 && ic >= 0 && ic + 1 < p.Wp) ? (const void*)(ximg + ((size_t)ir * p.Wp + ic) * 4) : (const void*)g_zero16;
+            dma16(src, patch0 + buf * STEMP_PATCH_BYTES + ii * 1024);
+        }
+    };
+
+    // ---- filter planes (28 DMA instructions, once) + the first patch ----
 #pragma unroll
     for (int j = 0; j < 7; ++j) {
         const int ii = j * 4 + wave;
-        const int c = ii * 64 + lane;                    // chunk (r, cout, q): c = (r*64 + cout)*4 + q
-        const int q = c & 3, co = (c >> 2) & 63, r = c >> 8;
+        const int c = ii * 64 + lane;                    // LDS chunk (r, cout, q'): c = (r*64 + cout)*4 + q'
+        // slot (r, cout, q') holds the filter's k-chunk q = (q' - 2*(cout >> 2)) & 3: without the rotation the 16 lanes of a
+        // ds_read_b128 group hit each bank twice (couts 4 apart share a bank)
+        const int qs = c & 3, co = (c >> 2) & 63, r = c >> 8;
+        const int q = (qs - 2 * (co >> 2)) & 3;
         dma16(p.Wt + co * 224 + r * 32 + q * 8, wl + ii * 1024);
     }
-
-    f32x4 acc[5][2];
+    int tile = blockIdx.x;
+    if (tile < ntiles) issue_patch(tile, 0);
+    float st1[2][4], st2[2][4];      // this lane's share (tile column l15) of the statistics of channels wn*32 + j*16 + lg*4 + r
+    float sgn[2][4];                 // +1: the pooled extremum of that channel is the max, -1: the min
 #pragma unroll
-    for (int i = 0; i < 5; ++i)
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+        for (int r = 0; r < 4; ++r) {
+            st1[j][r] = 0.f; st2[j][r] = 0.f;
+            sgn[j][r] = (p.gamma[wn * 32 + j * 16 + lg * 4 + r] >= 0.f) ? 1.f : -1.f;
+        }
+    const int Hq = (p.Ho >> 1) + 1, Wq = (p.Wo >> 1) + 1;             // PP pitch of the pooled tensor
+    const bool own_col = l15 >= 1 && l15 <= 14;
+    const bool writer = (l15 & 1) == 0 && l15 <= 12;                  // holds the window over tile columns l15 .. l15 + 2
+    int buf = 0;
+    bf16* pend_dst = nullptr;
+    s16x4 pend[2][2];
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int n = tile / per_img, rem = tile - n * per_img;
+        const int th = rem / tiles_w, tw = rem - th * tiles_w;
+        const char* patch = patch0 + buf * STEMP_PATCH_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();      // this tile's patch (and the filter) have landed for every wave; everyone is done reading the other buffer
+        if (tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x, buf ^ 1);      // lands under the MFMAs / pooling below
+        // the previous tile's pooled pixels leave HERE, one iteration late: the vmcnt(0) above would otherwise wait for stores that were
+        // issued just before it (loads and stores do not retire in order with each other, so a counted wait cannot skip them)
+        if (pend_dst != nullptr) {
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
-        bf16x8 af[5], bfr[2];
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int lp = 0; lp < 2; ++lp) *reinterpret_cast<s16x4*>(pend_dst + (size_t)lp * Wq * 64 + j * 16) = pend[j][lp];
+            pend_dst = nullptr;
+        }
+        f32x4 acc[5][2];
 #pragma unroll
         for (int i = 0; i < 5; ++i)
-            af[i] = *reinterpret_cast<const bf16x8*>(patch + (2 * (wm * 5 + i) + r) * STEM_PITCH + (l15 + lg) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 7; ++r) {
+            bf16x8 af[5], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+                af[i] = *reinterpret_cast<const bf16x8*>(patch + (2 * (wm * 4 + i) + r) * STEM_PITCH + (l15 + lg) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int co = wn * 32 + j * 16 + l15;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(wl + ((r * 64 + co) * 4 + ((lg + 2 * (co >> 2)) & 3)) * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        // ---- statistics over the positions this wave OWNS: its rows 1..4 (tile rows 1..4 / 5..8); the column mask (tile columns 1..14)
+        //      is a per-lane constant and is applied once, after the walk.  This kernel is VALU-bound (K = 147: 70 MFMAs feed 40 results
+        //      per lane that each need statistics + rounding + pooling), so every select here counts ----
 #pragma unroll
         for (int j = 0; j < 2; ++j)
-            bfr[j] = *reinterpret_cast<const bf16x8*>(wl + ((r * 64 + wn * 32 + j * 16 + l15) * 4 + lg) * 16);
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-
-    // ---- BatchNorm partial statistics over the positions this workgroup OWNS (tile rows 1..8, columns 1..14): per wave row ----
-    if (p.stat_sum != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) {
-                const int orow = wm * 5 + i;
+            for (int i = 1; i < 5; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ocol = lg * 4 + r;
-                    const bool own = orow >= 1 && orow <= 8 && ocol >= 1 && ocol <= 14;
-                    const float v = own ? acc[i][j][r] : 0.f;
-                    s1 += v;
-                    s2 += v * v;
+                    const float v = acc[i][j][r];
+                    st1[j][r] += v;
+                    st2[j][r] += v * v;
                 }
-            }
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-            if (lg == 0) {
-                const size_t o = (size_t)(b * 2 + wm) * 64 + wn * 32 + j * 16 + l15;
-                p.stat_sum[o] = s1;
-                p.stat_sq[o] = s2;
-            }
-        }
-    }
-    // ---- bf16 tile -> LDS (what the unfused path stored and bn_relu_maxpool read back): position (orow, ocol) at (orow*16 + ocol) ----
-    constexpr int CSB = 72;
-    bf16* Cs = reinterpret_cast<bf16*>(smem);
-#pragma unroll
-    for (int i = 0; i < 5; ++i)
+        // ---- 3x3 / 2 pooling: rows in-lane, columns by DPP; the pool's padding is convolution row / column -1 (tile row 0 of the
+        //      first tile row, tile column 0 of the first tile column) ----
+        const bool row0_pad = th == 0 && wm == 0;
+        const bool col_pad = tw == 0 && l15 == 0;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Cs[((wm * 5 + i) * 16 + lg * 4 + r) * CSB + wn * 32 + j * 16 + l15] = (bf16)acc[i][j][r];
-    __syncthreads();
-    // ---- 3x3 / 2 pooling window extrema: 4 x 7 pooled pixels x 8 channel chunks = 224 items ----
-    if (tid < 28 * 8) {
-        const int pix = tid >> 3, ch = (tid & 7) * 8;
-        const int pp = pix / 7, qq = pix - pp * 7;
-        float g[8];
-        Vec8<float>::load(p.gamma + ch, g);
-        float e[8];
-        bool first = true;
+            for (int r = 0; r < 4; ++r) {
+                float v[5];
 #pragma unroll
-        for (int dr = 0; dr < 3; ++dr)
+                for (int i = 0; i < 5; ++i) v[i] = sgn[j][r] * (float)(bf16)acc[i][j][r];
+                if (row0_pad) v[0] = -INFINITY;
+                float m[2] = {fmaxf(fmaxf(v[0], v[1]), v[2]), fmaxf(fmaxf(v[2], v[3]), v[4])};
 #pragma unroll
-            for (int dc = 0; dc < 3; ++dc) {
-                const int orow = 2 * pp + dr, ocol = 2 * qq + dc;
-                if (or0 + orow < 0 || oc0 + ocol < 0) continue;          // the pool's padding (only row / column -1 can be outside)
-                float v[8];
-                Vec8<bf16>::load(Cs + (orow * 16 + ocol) * CSB + ch, v);
-                if (first) {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) e[k] = v[k];
-                    first = false;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) e[k] = (g[k] >= 0.f) ? fmaxf(e[k], v[k]) : fminf(e[k], v[k]);
+                for (int lp = 0; lp < 2; ++lp) {
+                    if (col_pad) m[lp] = -INFINITY;
+                    const float h = fmaxf(fmaxf(m[lp], dpp_row_shl(m[lp], 1)), dpp_row_shl(m[lp], 2));
+                    pend[j][lp][r] = __builtin_bit_cast(short, (bf16)(sgn[j][r] * h));
                 }
             }
-        const int Hq = (p.Ho >> 1) + 1, Wq = (p.Wo >> 1) + 1;             // PP pitch of the pooled tensor
-        bf16* dst = p.Y + (((size_t)n * Hq + 4 * th + pp) * Wq + 7 * tw + qq) * 64 + ch;
-        Vec8<bf16>::store(dst, e);
+        if (writer) pend_dst = p.Y + (((size_t)n * Hq + 4 * th + 2 * wm) * Wq + 7 * tw + (l15 >> 1)) * 64 + wn * 32 + lg * 4;
+    }
+    if (pend_dst != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int lp = 0; lp < 2; ++lp) *reinterpret_cast<s16x4*>(pend_dst + (size_t)lp * Wq * 64 + j * 16) = pend[j][lp];
+    }
+    if (p.stat_sum != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s1 = own_col ? st1[j][r] : 0.f, s2 = own_col ? st2[j][r] : 0.f;
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+                if (l15 == 0) {
+                    const size_t o = (size_t)(blockIdx.x * 2 + wm) * 64 + wn * 32 + j * 16 + lg * 4 + r;
+                    p.stat_sum[o] = s1;
+                    p.stat_sq[o] = s2;
+                }
+            }
     }
 }
 
@@ -633,10 +677,12 @@ bool blt_conv_stem_pool_ok(int dtype, int H, int W, int Hp, int Wp, int Cout) {
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
     return dtype == BLT_BF16 && Cout == 64 && Ho % 8 == 0 && Wo % 14 == 0 && Hp >= H + 6 && Wp >= W + 6 && Wp % 2 == 0;
 }
-int blt_conv_stem_pool_stat_rows(int N, int H, int W) {
+static int stem_pool_grid(int N, int H, int W) {
     const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
-    return 2 * N * (Ho / 8) * (Wo / 14);
+    const long tiles = (long)N * (Ho / 8) * (Wo / 14);
+    return (int)(tiles < 768 ? tiles : 768);      // three 44 KB workgroups per CU
 }
+int blt_conv_stem_pool_stat_rows(int N, int H, int W) { return 2 * stem_pool_grid(N, H, W); }
 int blt_conv_stem_pool(const void* x_padded, const void* w, const float* gamma, void* y_pool_pp, int N, int H, int W, int Hp, int Wp, float* stat_sum,
                        float* stat_sq, hipStream_t s) {
     BLT_REQUIRE(x_padded && w && gamma && y_pool_pp && N > 0 && blt_conv_stem_pool_ok(BLT_BF16, H, W, Hp, Wp, 64), "conv_stem_pool: unsupported geometry");
@@ -646,9 +692,16 @@ int blt_conv_stem_pool(const void* x_padded, const void* w, const float* gamma, 
     StemPoolArgs a;
     a.X = (const bf16*)x_padded; a.Wt = (const bf16*)w; a.gamma = gamma; a.Y = (bf16*)y_pool_pp; a.N = N; a.Hp = Hp; a.Wp = Wp;
     a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
-    const long grid = (long)N * (a.Ho / 8) * (a.Wo / 14);
-    BLT_REQUIRE(grid < (1L << 31), "conv_stem_pool: too many tiles");
-    hipLaunchKernelGGL(conv_stem_pool_kernel, dim3((unsigned)grid), dim3(256), STEMP_PATCH_BYTES + STEM_W_BYTES, s, a);
+    BLT_REQUIRE((long)N * (a.Ho / 8) * (a.Wo / 14) < (1L << 31), "conv_stem_pool: too many tiles");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEMP_LDS) != hipSuccess) {
+            blt_set_error("conv_stem_pool: hipFuncSetAttribute failed");
+            return BLT_ERR_HIP;
+        }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv_stem_pool_kernel, dim3((unsigned)stem_pool_grid(N, H, W)), dim3(256), STEMP_LDS, s, a);
     return blt_check_launch("conv_stem_pool");
 }
 

@@ -423,7 +423,7 @@ def main():
                       "nets: forward gemm_nt2_kernel<Nt2<BM,BN,..>> (gemm_dma_kernel<*,*,plain,*> for M < 256), input gradients through the transposed weight shadow, weight "
                       "gradients gemm_kernel<bf16,*,*,T,T> / wgrad_group_kernel); flops = 2*M*N*K per launch")
         roof_conv = family(conv_ms, conv_n, conv_flops,
-                           "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), conv_stem_direct_kernel (1), "
+                           "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), conv_stem_pool_kernel (1: stem + max-pool, pooled extrema), "
                            "gemm_dma_kernel<*,*,conv,*> (6: stride-2 / 1x1); flops over real pixels, unpadded Cin")
         # HBM bytes per launch from the committed PMC passes (profiles/summarize_pmc.py): collected for the default workload only
         pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")

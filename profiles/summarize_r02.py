@@ -25,7 +25,7 @@ def is_gemm(n):       # the Linear-layer GEMM family (bench.py class 1)
 
 def is_conv(n):
     s = short(n)
-    return s.startswith("conv3x3_pp_kernel") or s.startswith("conv_stem_direct_kernel") or re.match(r"gemm_dma_kernel<\d+, \d+, [12], \d+>", s) is not None
+    return s.startswith("conv3x3_pp_kernel") or s.startswith("conv_stem_direct_kernel") or s.startswith("conv_stem_pool_kernel") or re.match(r"gemm_dma_kernel<\d+, \d+, [12], \d+>", s) is not None
 
 
 def counters(d):
@@ -35,7 +35,7 @@ def counters(d):
     if not fs:
         return out, dur
     seen = set()
-    for r in csv.DictReader(open(fs[0])):
+    for r in csv.DictReader(open(max(fs, key=os.path.getmtime))):
         out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         key = (r.get("Dispatch_Id"), r["Kernel_Name"])
         if key not in seen and "Start_Timestamp" in r:
@@ -47,7 +47,7 @@ def counters(d):
 def main():
     st = glob.glob(os.path.join(SRC, "r02_stats", "*", "*_kernel_stats.csv"))
     if st:
-        shutil.copy(st[0], os.path.join(ROOT, "r02_bench_kernel_stats.csv"))
+        shutil.copy(max(st, key=os.path.getmtime), os.path.join(ROOT, "r02_bench_kernel_stats.csv"))
     F, _ = counters("r02_fetch")
     W, _ = counters("r02_write")
     rows = []

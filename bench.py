@@ -433,6 +433,14 @@ def main():
                 roof["traffic"] = int(tr["gemm_bytes_per_launch"])
             if roof_conv and "conv_bytes_per_launch" in tr:
                 roof_conv["traffic"] = int(tr["conv_bytes_per_launch"])
+            # the committed rocprofv3 --kernel-trace --stats run of this same command (profiles/r02_bench_kernel_stats.csv): under the
+            # profiler the host enqueue is slower, the three streams of the step overlap less and a launch is stretched less by the
+            # other streams' workgroups than in the un-profiled brackets above
+            for r_, key in ((roof, "gemm"), (roof_conv, "conv")):
+                rp = (tr.get(key) or {}).get("rocprof_avg_launch_us")
+                if r_ and rp:
+                    r_["rocprof_avg_launch_us"] = rp
+                    r_["rocprof_frac"] = round(r_["gflop_per_step"] / r_["launches_per_step"] / rp / 1e3 / r_["peak"], 4)
         out = {
             "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",

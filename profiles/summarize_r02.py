@@ -70,6 +70,16 @@ def main():
         wr = sum(r[3] * r[1] for r in sel) / n
         return {"launches_sampled": n, "read_MB_per_launch": round(rd, 2), "write_MB_per_launch": round(wr, 2), "bytes_per_launch": int((rd + wr) * 1e6)}
     g, c = fam(is_gemm), fam(is_conv)
+    # average launch duration of each family in the rocprofv3 --kernel-trace --stats run of the same bench command
+    ks = os.path.join(ROOT, "r02_bench_kernel_stats.csv")
+    if os.path.exists(ks):
+        kr = list(csv.DictReader(open(ks)))
+        for d, pred in ((g, is_gemm), (c, is_conv)):
+            sel = [r for r in kr if pred(r["Name"])]
+            calls = sum(int(r["Calls"]) for r in sel)
+            if d is not None and calls:
+                d["rocprof_avg_launch_us"] = round(sum(int(r["TotalDurationNs"]) for r in sel) / calls / 1e3, 2)
+                d["rocprof_launches"] = calls
     tr = {"note": "HBM bytes per launch, big cfg B=256 bf16: reads = 2 x FETCH_SIZE (gfx950 wide-load correction), writes = WRITE_SIZE; separate --pmc passes "
                   "(profiles/collect_r02.sh)", "gemm": g, "conv": c}
     if g:

@@ -279,9 +279,9 @@ int launch(const ConvPPArgs& a, int grid, size_t lds, hipStream_t s) {
 }  // namespace
 
 long blt_pp_pixels(int N, int H, int W) { return (long)N * (H + 1) * (W + 1); }
-// Tile plan shared by the launch and by the count of statistics rows: `wide` = the 256-position / 8-wave / 4-stage form (layers with
-// Cout % 128 == 0 whose patch slices and ring fit 160 KB; debug key 19 = 2 — OFF by default: measured 90-94 us against 82-88 us for the
-// 128-position form at B = 256), else 128 positions with BN = 128 or 64.
+// Tile plan shared by the launch and by the count of statistics rows: `wide` = the 256-position / 8-wave / 4-stage form — ON for
+// Cout = 64 (see below), OFF by default for Cout % 128 == 0 (debug key 19 = 2 turns it on: measured 90-94 us against 82-88 us for the
+// 128-position form at B = 256) — else 128 positions with BN = 128 or 64.
 struct ConvPPPlan { bool wide; int BN; int pw; };
 static ConvPPPlan conv_pp_plan(int N, int H, int W, int Cin, int Cout) {
     ConvPPPlan pl;
@@ -291,6 +291,12 @@ static ConvPPPlan conv_pp_plan(int N, int H, int W, int Cin, int Cout) {
     const size_t ldsw = (size_t)(NS > 1 ? 2 : 1) * pww * 8192 + 4 * (size_t)128 * 128;
     pl.wide = Cout % 128 == 0 && pww <= 8 && ldsw <= 160 * 1024 && pww * 64 - (W + 2) <= BLT_PP_GUARD_TAIL && blt_debug_get(19) == 2;
     if (pl.wide) { pl.BN = 128; pl.pw = pww; return pl; }
+    // ... ON for the 64-channel layers (256 positions x 64 channels, 80 KB: two 8-wave workgroups per CU instead of three 4-wave ones):
+    // 6 498 tiles of 128 positions are 8.5 rounds of 5.5 us of fill each — half the tiles, half of that; measured 94 -> 82 us
+    // (plain) and 123 -> 103 us (bn1 fused in) at B = 256.  debug key 19 = 1: the 128-position form everywhere.
+    if (Cout == 64 && pww <= 8 && pww * 64 - (W + 2) <= BLT_PP_GUARD_TAIL && blt_debug_get(19) != 1) {
+        pl.wide = true; pl.BN = 64; pl.pw = pww; return pl;
+    }
     pl.pw = cdiv(cdiv(128 + 2 * (W + 1) + 2, 8), 4);
     pl.BN = (Cout % 128 == 0) ? 128 : 64;
     // a grid that would leave most CUs with a single workgroup (7x7x512: 256 tiles of 128 channels) runs twice as many half-width
@@ -339,6 +345,7 @@ int blt_conv3x3_pp(const void* x, const void* w, void* y, int N, int H, int W, i
     if (pl.wide) {
         size_t lds = (size_t)(NS > 1 ? 2 : 1) * a.pw * 8192 + 4 * (size_t)BN * 128;
         if (lds < stage + 1024) lds = stage + 1024;
+        if (BN == 64) return in_scale ? launch<64, 4, true, 4>(a, grid, lds, s) : launch<64, 4, false, 4>(a, grid, lds, s);
         return in_scale ? launch<128, 4, true, 4>(a, grid, lds, s) : launch<128, 4, false, 4>(a, grid, lds, s);
     }
     // two workgroups per CU need <= 80 KB each: the validity table (512 B) shares the epilogue's space behind the staged tile

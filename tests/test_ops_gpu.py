@@ -618,7 +618,9 @@ def test_conv3x3_pp_exact_integer_and_stats(geom):
     wp = G.conv_pack_w(w.cuda(), dtype, cin)
     ybuf, ybody, yview = _pp_alloc(N, H, W, cout, dtype, fill=7.0)
     rows = lib.bltvqg_conv3x3_pp_stat_rows(N, H, W)
-    for form in ((0, 2) if cout % 128 == 0 else (0,)):      # debug key 19 = 2: the 256-position / 8-wave tile form (off by default)
+    # debug key 19: 0 = default plan (256-position tiles for Cout = 64, 128-position ones otherwise), 1 = 128 positions everywhere,
+    # 2 = 256 positions also for Cout % 128 == 0
+    for form in ((0, 2) if cout % 128 == 0 else (0, 1)):
         ybody.fill_(7.0)
         ssum = torch.zeros(rows, cout, device="cuda")
         ssq = torch.zeros(rows, cout, device="cuda")

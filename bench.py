@@ -46,6 +46,8 @@ MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH
 HP = dict(kl_weight=0.5, lr=1e-4, max_norm=5.0)
 
 
+PROFILE_STRIDE = 4      # the profiled step brackets every 4th plain Linear GEMM launch (weighted 4), see engine_profile_enable
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -311,7 +313,7 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
-            eng.profile_enable(3 if i == profile_step else 0)
+            eng.profile_enable((3 | (PROFILE_STRIDE << 8)) if i == profile_step else 0)
             one_step(first + i, phase2, h2d)
         step.finish()                                           # the last (overlapped) optimiser update is part of the timed region
         torch.cuda.synchronize()
@@ -415,8 +417,9 @@ def main():
                     "traffic_unit": "HBM bytes per launch (2 x FETCH_SIZE + WRITE_SIZE, separate rocprofv3 --pmc passes)",
                     "kernel": kernel, "launches_per_step": launches, "gflop_per_step": round(flops / 1e9, 1),
                     "avg_launch_us": round(us, 2), "avg_bracket_us_raw": round(raw_us, 2), "empty_bracket_us": round(null_us, 2),
-                    "profiled_steps": "1 of the %d timed steps (step %d) carries a HIP event pair around every launch of the family, on the "
-                                      "stream of the launch" % (a.steps, prof_step),
+                    "profiled_steps": "1 of the %d timed steps (step %d) carries HIP event pairs on the stream of the launch: around every "
+                                      "convolution and every grouped weight-gradient launch, around every %d-th plain Linear GEMM launch "
+                                      "(counted %d times: a pair is a ~5 us bubble on its stream)" % (a.steps, prof_step, PROFILE_STRIDE, PROFILE_STRIDE),
                     "kernel_time_ms_per_step": round(us * launches * 1e-3, 3)}
         roof = family(gemm_ms, gemm_n, gemm_flops,
                       "every Linear-layer GEMM of the step (attention q|k|v / output projections, FFN, embedding, vocabulary projection, latent "
@@ -440,7 +443,7 @@ def main():
                 rp = (tr.get(key) or {}).get("rocprof_avg_launch_us")
                 if r_ and rp:
                     r_["rocprof_avg_launch_us"] = rp
-                    r_["rocprof_frac"] = round(r_["gflop_per_step"] / r_["launches_per_step"] / rp / 1e3 / r_["peak"], 4)
+                    r_["rocprof_frac"] = round(r_["gflop_per_step"] / r_["launches_per_step"] / rp * 1e3 / r_["peak"], 4)      # GFLOP / us = PFLOP/s
         out = {
             "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",

@@ -197,7 +197,11 @@ struct bltvqg_engine {
         stamp_used[i] = true;
     }
     int prof_mask = 0;
-    struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; double flops = 0.0; };
+    struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; int w = 1; double flops = 0.0; };
+    // class-1 launches that go through gemm() are bracketed every prof_stride-th time and counted prof_stride times (an event pair is a
+    // ~5 us bubble on its stream: 210 pairs would stretch the one profiled step of bench.py by ~2.5 ms); grouped weight-gradient launches
+    // (4 per step, 15 % of the family's flops each) and convolutions are always bracketed
+    int prof_stride = 1, prof_gemm_count = 0;
     std::vector<ProfRec> prof;
     size_t prof_n = 0;
     int prof_begin(int cls, hipStream_t s) {
@@ -208,6 +212,7 @@ struct bltvqg_engine {
             prof.push_back(r);
         }
         prof[prof_n].cls = cls;
+        prof[prof_n].w = 1;
         (void)hipEventRecord(prof[prof_n].a, s);
         return (int)prof_n++;
     }
@@ -218,7 +223,9 @@ struct bltvqg_engine {
     }
     // every Linear-layer GEMM of the engine goes through here (class-1 bracket when enabled)
     int gemm(int dtype, const GemmArgs& g, hipStream_t s) {
-        const int pi = (prof_mask & 2) ? prof_begin(1, s) : -1;
+        const bool sampled = (prof_mask & 2) && (prof_gemm_count++ % prof_stride) == 0;
+        const int pi = sampled ? prof_begin(1, s) : -1;
+        if (pi >= 0) prof[pi].w = prof_stride;
         const int rc = blt_gemm(dtype, g, s);
         prof_end(pi, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);
         return rc;
@@ -1709,8 +1716,10 @@ int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
 uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site) { return (uint32_t)(stack * 1000 + layer * 10 + site); }
 
 int bltvqg_engine_profile_enable(bltvqg_engine* e, int mask) {
-    BLT_REQUIRE(e && mask >= 0 && mask <= 3, "engine_profile_enable: bad args");
-    e->prof_mask = mask;        // pause / resume: the recorded launches accumulate until bltvqg_engine_profile_read* drains them
+    BLT_REQUIRE(e && mask >= 0 && (mask & 0xFF) <= 3 && (mask >> 8) <= 64, "engine_profile_enable: bad args");
+    e->prof_mask = mask & 3;    // pause / resume: the recorded launches accumulate until bltvqg_engine_profile_read* drains them
+    e->prof_stride = (mask >> 8) > 0 ? (mask >> 8) : 1;      // bits 8..: sample every n-th plain Linear GEMM launch (weighted n)
+    e->prof_gemm_count = 0;
     return BLT_OK;
 }
 
@@ -1725,7 +1734,7 @@ int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms
         if (hipEventSynchronize(r.b) != hipSuccess) { blt_set_error("engine_profile_read: event sync failed"); return BLT_ERR_HIP; }
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { blt_set_error("engine_profile_read: elapsed failed"); return BLT_ERR_HIP; }
-        total += ms; flops += r.flops; ++n;
+        total += (double)ms * r.w; flops += r.flops * r.w; n += r.w;
     }
     e->prof_n = keep;      // records of the other class stay queued (the swaps keep every event pair alive in the vector)
     *total_ms_host = total;

@@ -1010,6 +1010,7 @@ struct bltvqg_engine {
             hipStream_t s0 = side[0];
             RC(fork(s, s0, fj[0]));
             RC(cnn_fwd(images, s));
+            stamp(11, s);
             RC(sync_opt(s0));
             if (bn_train) RC(zero_grads_early(s0));
             RC(forward_tokens(ctx, post, tgt, s0, s0));
@@ -1030,7 +1031,7 @@ struct bltvqg_engine {
         if (use_streams) RC(fork(s0, s1, fj[1]));
         // the CNN is the long pole (1.3 ms of the step) and its ~90 launches take the host ~0.3 ms to enqueue: it goes first when the
         // side streams exist, so that the GPU is not left waiting for it behind the (short) encoder stacks' enqueue
-        if (use_streams) RC(cnn_fwd(images, s));
+        if (use_streams) { RC(cnn_fwd(images, s)); stamp(11, s); }      // [11] image feature done (CNN stream, before the encoders are joined)
         RC(stack_fwd(enc, nullptr, nullptr, s1));
         // the reference runs r_encoder in both phases (encoder_transformer.py:23-25)
         RC(stack_fwd(renc, nullptr, nullptr, s0));
@@ -1595,6 +1596,7 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
             return BLT_ERR_HIP;
         }
     for (int i = 0; i < 2; ++i)
+        // (stream priorities were measured — either side stream lowest or highest: +-1 %, the dispatcher does not preempt resident workgroups)
         if (!e->side[i] && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) {
             blt_set_error("engine_bind: stream creation failed");
             return BLT_ERR_HIP;

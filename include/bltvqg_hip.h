@@ -355,7 +355,8 @@ int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t*
 int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host);
 /* Diagnostic (bltvqg_debug_set(12, 1)): milliseconds from the start of the last forward to the phase boundaries of the step on the
  * caller's stream — [1] CNN + encoders joined, [2] decoder starts, [3] decoder done, [4] end of forward, [5] losses, [6] decoder backward
- * starts, [7] decoder backward done, [8] encoder backward starts, [9] done, [10] end of backward; -1 = not recorded. */
+ * starts, [7] decoder backward done, [8] encoder backward starts, [9] done, [10] end of backward, [11] image feature done on the CNN's
+ * stream (before the encoder streams are joined: [11] ~ [1] means the CNN chain is the long pole of the first phase); -1 = not recorded. */
 int bltvqg_engine_phase_stamps(bltvqg_engine* e, float* ms_host12);
 /* gradient buckets for data-parallel overlap: contiguous float ranges of the flat gradient buffer in the order backward
  * completes them; bltvqg_engine_bucket_wait makes `stream` wait until bucket i of the last backward is complete. */

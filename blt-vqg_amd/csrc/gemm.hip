@@ -1126,6 +1126,12 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 // process-wide tuning switches (bltvqg_debug_set): [0] = disable the LDS-DMA ring, [1] = force a tile, [2] = autotune mode,
 // [3] = ring depth of the DMA kernels (0 = by grid size; 128x128: 1 = always 4 stages, 2 = always 2; 64x64: 3 = always 5, 4 = always 3)
 // [8] = 1: round-1 kernels for the Linear GEMMs instead of gemm2.hip's planned-tile kernel (A/B); [9] / [10] = force its BM / BN
+// [4]..[6] conv_pp.hip (force BN, XCD mapping, ring depth); [7] BatchNorm / LayerNorm variants (norm.hip, engine.hip)
+// [11] weight-gradient flush mode (1 = ungrouped launches, n >= 2 = flush every n-1 layers); [12] = 1 phase stamps; [13] weight-gradient
+// tile rows (128 / 256); [14] / [15] = 1 TIMING ABLATIONS ONLY (results wrong): skip the grouped weight-gradient launches / the conv stack
+// [16] = 1 VALU attention kernels instead of the MFMA form; [17] = 1 bn1 as a separate pass (not fused into conv2's patch staging);
+// [18] = 1 stem and max-pool as two launches; [19] conv3x3_pp tile form (1 = 128 positions everywhere, 2 = 256 positions also for
+// Cout % 128 == 0).  Every key defaults to 0 = the shipped path; the A/B keys exist so that tests and measurements can compare forms.
 static int g_debug[24] = {0};
 void blt_debug_set(int key, int value) { if (key >= 0 && key < 24) g_debug[key] = value; }
 int blt_debug_get(int key) { return (key >= 0 && key < 24) ? g_debug[key] : 0; }

@@ -305,8 +305,7 @@ __device__ __forceinline__ void softmax_t(const AttnArgs& a, const MfmaHead& m, 
                 st[jt][it][r] = v;
                 mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = max_across_rows(mx);
         float sum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -316,8 +315,7 @@ __device__ __forceinline__ void softmax_t(const AttnArgs& a, const MfmaHead& m, 
                 st[jt][it][r] = e;
                 sum += e;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = sum_across_rows(sum);
         const float inv = (i < a.Tq) ? 1.f / sum : 0.f;       // padded queries: P = 0
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt)
@@ -475,8 +473,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
                 delta += st[jt][it][r] * dp[jt][it][r];
             }
         }
-        delta += __shfl_xor(delta, 16, 64);
-        delta += __shfl_xor(delta, 32, 64);
+        delta = sum_across_rows(delta);
 #pragma unroll
         for (int jt = 0; jt < 2; ++jt) {
 #pragma unroll

@@ -29,6 +29,34 @@ int blt_check_launch(const char* what);
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---------------------------------------------------------------------------------
+// Cross-row exchange without LDS: gfx950's v_permlane16_swap / v_permlane32_swap swap the odd 16- (32-) lane rows of the first
+// operand with the even rows of the second; with both operands = x the two results are x of "my row pair's even row" and of its
+// odd row in every lane, i.e. lane l gets x[l] and x[l ^ 16] (x[l ^ 32]) in some order.  One VALU instruction instead of a
+// ds_bpermute round trip through the LDS pipe (__shfl_xor) — these sit at the tail of latency-bound kernels.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void xor16_pair(float x, float& a, float& b) {
+    const unsigned v = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]); b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ void xor32_pair(float x, float& a, float& b) {
+    const unsigned v = __builtin_bit_cast(unsigned, x);
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    a = __builtin_bit_cast(float, (unsigned)r[0]); b = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// sum / max over the four lanes l, l^16, l^32, l^48 (the same value in all four afterwards)
+__device__ __forceinline__ float sum_across_rows(float x) {
+    float a, b;
+    xor16_pair(x, a, b); x = a + b;
+    xor32_pair(x, a, b); return a + b;
+}
+__device__ __forceinline__ float max_across_rows(float x) {
+    float a, b;
+    xor16_pair(x, a, b); x = fmaxf(a, b);
+    xor32_pair(x, a, b); return fmaxf(a, b);
+}
+
+// ---------------------------------------------------------------------------------
 // element conversion
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ float to_f32(float x) { return x; }
@@ -67,16 +95,30 @@ template <> struct Vec8<bf16> {
 // ---------------------------------------------------------------------------------
 // wave (64 lanes) and block reductions
 // ---------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// (__shfl_xor is a ds_bpermute: six dependent LDS round trips per reduction.  Within a 16-lane row the reduction is four DPP row
+// rotations — plain VALU operands — and across rows the two permlane swaps above.)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    const int v = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum(float v) {      // all 16 lanes of a row get the row's sum
+    v += dpp_mov<0x128>(v); v += dpp_mov<0x124>(v); v += dpp_mov<0x122>(v); v += dpp_mov<0x121>(v);      // row_ror:8, 4, 2, 1
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row_max(float v) {
+    v = fmaxf(v, dpp_mov<0x128>(v)); v = fmaxf(v, dpp_mov<0x124>(v)); v = fmaxf(v, dpp_mov<0x122>(v)); v = fmaxf(v, dpp_mov<0x121>(v));
     return v;
 }
+// sum over a group of `lanes` (16, 32 or 64) consecutive lanes starting at a multiple of `lanes`
+__device__ __forceinline__ float group_sum(float v, int lanes) {
+    v = row_sum(v);
+    if (lanes >= 32) { float a, b; xor16_pair(v, a, b); v = a + b; }
+    if (lanes >= 64) { float a, b; xor32_pair(v, a, b); v = a + b; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return sum_across_rows(row_sum(v)); }
+__device__ __forceinline__ float wave_max(float v) { return max_across_rows(row_max(v)); }
 // all threads get the block total; `red` is >= 16 floats of LDS; blockDim.x multiple of 64
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);

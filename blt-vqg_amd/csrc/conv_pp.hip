@@ -233,8 +233,7 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_pp_kernel(const ConvPPArgs 
                     s1 += v;
                     s2 += v * v;
                 }
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            s1 = sum_across_rows(s1); s2 = sum_across_rows(s2);
             if (lg == 0) {
                 const size_t o = (size_t)(tile_m * NWM + wm) * p.Cout + n0 + wn * WN + j * 16 + l15;
                 p.stat_sum[o] = s1;
@@ -459,8 +458,7 @@ __global__ __launch_bounds__(256) void conv_stem_direct_kernel(const StemArgs p)
                     s1 += v;
                     s2 += v * v;
                 }
-            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            s1 = sum_across_rows(s1); s2 = sum_across_rows(s2);
             if (lg == 0) {
                 const size_t o = (size_t)(b * 2 + wm) * 64 + wn * 32 + j * 16 + l15;
                 p.stat_sum[o] = s1;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     xh[r][j][e] = xn;
                     d[r][j][e] = dg;
                 }
-            for (int o = lpr >> 1; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+            s1 = group_sum(s1, lpr); s2 = group_sum(s2, lpr);
             const float c1 = s1 / (float)cols, c2 = s2 / (float)cols;
             if (row < rows) {
 #pragma unroll

@@ -446,6 +446,7 @@ def main():
                     r_["rocprof_frac"] = round(r_["gflop_per_step"] / r_["launches_per_step"] / rp * 1e3 / r_["peak"], 4)      # GFLOP / us = PFLOP/s
         out = {
             "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+            "world_size": (dist.get_world_size() if dist is not None else 1),
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic, pinned host batch copied over PCIe every step (one step ahead)" if a.h2d else "synthetic",

@@ -564,8 +564,20 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const StemPoolArgs 
         const int q = (qs - 2 * (co >> 2)) & 3;
         dma16(p.Wt + co * 224 + r * 32 + q * 8, wl + ii * 1024);
     }
-    int tile = blockIdx.x;
-    if (tile < ntiles) issue_patch(tile, 0);
+    // XCD-aware walk: the hardware deals workgroup ids round-robin over the 8 XCDs, each with its own L2.  XCD x takes the CONTIGUOUS
+    // tile range [x * chunk, (x+1) * chunk) and its workgroups walk it side by side, so that the patch halo two neighbouring tiles share
+    // (the 25 x 38-pixel patch covers 16 x 28 owned pixels) is in that XCD's L2 instead of being fetched once per XCD (measured: 188 MB
+    // read per launch against 105 MB of image).  Grids that are not a multiple of 8 keep the plain walk.
+    int tile, tile_end, tile_step;
+    if ((gridDim.x & 7) == 0) {
+        const int chunk = (ntiles + 7) >> 3, xcd = (int)blockIdx.x & 7;
+        tile = xcd * chunk + ((int)blockIdx.x >> 3);
+        tile_end = (xcd + 1) * chunk < ntiles ? (xcd + 1) * chunk : ntiles;
+        tile_step = (int)gridDim.x >> 3;
+    } else {
+        tile = blockIdx.x; tile_end = ntiles; tile_step = gridDim.x;
+    }
+    if (tile < tile_end) issue_patch(tile, 0);
     float st1[2][4], st2[2][4];      // this lane's share (tile column l15) of the statistics of channels wn*32 + j*16 + lg*4 + r
     float sgn[2][4];                 // +1: the pooled extremum of that channel is the max, -1: the min
 #pragma unroll
@@ -581,13 +593,13 @@ __global__ __launch_bounds__(256) void conv_stem_pool_kernel(const StemPoolArgs 
     int buf = 0;
     bf16* pend_dst = nullptr;
     s16x4 pend[2][2];
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    for (; tile < tile_end; tile += tile_step, buf ^= 1) {
         const int n = tile / per_img, rem = tile - n * per_img;
         const int th = rem / tiles_w, tw = rem - th * tiles_w;
         const char* patch = patch0 + buf * STEMP_PATCH_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();      // this tile's patch (and the filter) have landed for every wave; everyone is done reading the other buffer
-        if (tile + (int)gridDim.x < ntiles) issue_patch(tile + gridDim.x, buf ^ 1);      // lands under the MFMAs / pooling below
+        if (tile + tile_step < tile_end) issue_patch(tile + tile_step, buf ^ 1);      // lands under the MFMAs / pooling below
         // the previous tile's pooled pixels leave HERE, one iteration late: the vmcnt(0) above would otherwise wait for stores that were
         // issued just before it (loads and stores do not retire in order with each other, so a counted wait cannot skip them)
         if (pend_dst != nullptr) {

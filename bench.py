@@ -67,7 +67,7 @@ def parse():
     ap.add_argument("--bf16-wire", action="store_true", help="N > 1: gradients cross xGMI as bf16 (half the bytes); default fp32 like Lightning DDP")
     ap.add_argument("--autotune", action="store_true", help="time candidate GEMM/conv kernels per launch in the first warm-up step")
     ap.add_argument("--cpu-batch", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=20)
     return ap.parse_args()
 
 

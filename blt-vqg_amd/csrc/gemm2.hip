@@ -347,16 +347,23 @@ int launch_nt2(const GemmArgs& a, hipStream_t s) {
 // waves (2 per SIMD, wave tile 64 x 32) a K-step took 1.27 us against 0.47 us of LDS-DMA intake (PMC: 40 % of wave cycles in waits).
 // Tile BM x 128 with BM = 256 (wave tile 64 x 32; 48 KB per K-step for twice the MFMA work of a 128 x 128 tile: 25 % less intake per flop
 // and the fixed cost of a K-step — barrier, waits — spread over twice the flops) or 128 (narrow gradients).
-template <int BM_>
+template <int BM_, int BN_ = 128, int NWM_ = 4, int NWN_ = 4, int BK_ = 64>
 struct WgCfgT {
-    static constexpr int BM = BM_, BN = 128, BK = 64, NWM = 4, NWN = 4, NW = NWM * NWN, NT = NW * 64;
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, NWM = NWM_, NWN = NWN_, NW = NWM * NWN, NT = NW * 64;
     static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
-    static constexpr int A_ROW = BM * 2, A_BYTES = BK * A_ROW, B_BYTES = BK * 256, STAGE = A_BYTES + B_BYTES;      // 32 / 48 KB
-    static constexpr int CH_A = BK * (BM / 8) / NT, CH_B = BK * 16 / NT, PER_STAGE = CH_A + CH_B;      // DMA wave-instructions per wave per stage
-    static constexpr int NST = (BM == 256) ? 3 : 4, AHEAD = NST - 1;
+    static constexpr int A_ROW = BM * 2, B_ROW = BN * 2, A_BYTES = BK * A_ROW, B_BYTES = BK * B_ROW, STAGE = A_BYTES + B_BYTES;      // 32 / 48 / 64 KB
+    static constexpr int CH_A = BK * (BM / 8) / NT, CH_B = BK * (BN / 8) / NT, PER_STAGE = CH_A + CH_B;      // DMA wave-instructions per wave per stage
+    static constexpr int NST = (BM == 256 && BN == 256) ? (BK == 32 ? 4 : 2) : (BM == 256) ? 3 : 4, AHEAD = NST - 1;
     static constexpr int LDS = NST * STAGE + 1024;       // + the table's workgroup offsets
-    static_assert(CH_A >= 1 && CH_B >= 1 && (TM == 2 || TM == 4) && TN == 2 && LDS <= 160 * 1024, "wave layout");
+    static_assert(CH_A >= 1 && CH_B >= 1 && ((TM == 2 && TN == 2) || (TM == 4 && TN == 2) || (TM == 4 && TN == 8)) && LDS <= 160 * 1024, "wave layout");
 };
+// The 256 x 256 form (8 waves as 4 x 2, wave tile 64 x 128, four 32 KB stages of 32 tokens): the 256 x 128 form measured 363-405 us for the
+// decoder's set with 331 us of it explained by L2->LDS intake alone (48 KB per K-step per CU at ~70 GB/s; ablation: without the DMA
+// -106 us, without the transposed reads -127 us, without the MFMAs -88 us, empty skeleton 113 us).  A square tile stages 64 KB per 64
+// tokens for TWICE the flops (intake per flop -33 %) and reads 0.75 instead of 1.5 fragments per MFMA — but its 128 accumulator registers
+// per lane allow only 8 waves per CU, and with two waves per SIMD the read -> wait -> MFMA phases of a wave are no longer covered by its
+// neighbours: 361 us, the same.  Kept as a tested option (tile form 512), not selected.
+typedef WgCfgT<256, 256, 4, 2, 32> WgCfgSq;      // 32-token K-steps: four 32 KB stages, three in flight
 typedef WgCfgT<128> WgCfg;
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -404,21 +411,22 @@ __global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem
     // c & 15 <- source chunk (c & 15) ^ f(row)
     // (A rows are BM * 2 bytes: BM / 8 chunks, swizzled inside each 256-byte half)
     int a_row[C::CH_A], b_row[C::CH_B];
-    long a_off[C::CH_A], b_off[C::CH_B];
+    int a_off[C::CH_A], b_off[C::CH_B];          // element offsets inside one 64-token K-step (< 64 * ld + width: far below 2^31)
     constexpr int ACH = C::BM / 8;          // chunks per A row (16 or 32)
 #pragma unroll
     for (int j = 0; j < C::CH_A; ++j) {
         const int c = (j * C::NW + wave) * 64 + lane;
         const int row = c / ACH, slot = c % ACH, gc = (slot & ~15) | ((slot & 15) ^ wg_swz(row));
         a_row[j] = row;
-        a_off[j] = (m0 + gc * 8 < a_cols) ? (long)row * P.lda + m0 + gc * 8 : -1;
+        a_off[j] = (m0 + gc * 8 < a_cols) ? row * P.lda + m0 + gc * 8 : -1;
     }
+    constexpr int BCH = C::BN / 8;          // chunks per B row (16 or 32)
 #pragma unroll
     for (int j = 0; j < C::CH_B; ++j) {
         const int c = (j * C::NW + wave) * 64 + lane;
-        const int row = c >> 4, gc = (c & 15) ^ wg_swz(row);
+        const int row = c / BCH, slot = c % BCH, gc = (slot & ~15) | ((slot & 15) ^ wg_swz(row));
         b_row[j] = row;
-        b_off[j] = (n0 + gc * 8 < b_cols) ? (long)row * P.ldb + n0 + gc * 8 : -1;
+        b_off[j] = (n0 + gc * 8 < b_cols) ? row * P.ldb + n0 + gc * 8 : -1;
     }
     auto issue_one = [&](int d, int kt, int stage) {      // kt relative to kt0; K-steps beyond the slice come from the zero page
         char* a_st = smem + stage * C::STAGE;
@@ -465,50 +473,72 @@ __global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem
             const char* a_st = smem + st_cur * C::STAGE;
             const char* b_st = a_st + C::A_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < C::BK / 32; ++ks) {
                 const int r0 = ks * 32 + lg * 8 + tq;            // token row of the first transposed read (the second: + 4)
                 const int f0 = wg_swz(r0), f1 = wg_swz(r0 + 4);
-                bf16x8 bfr[C::TN], af[C::TM];
-                s16x4 blo[C::TN], bhi[C::TN], alo[C::TM], ahi[C::TM];
+                // B fragments in groups of JG (all of them for TN = 2; two groups of 4 for the square tile, whose 8 + 4 fragments and
+                // 128 accumulator registers would not fit otherwise); the A fragments are read once with the first group
+                constexpr int JG = C::TN > 4 ? 4 : C::TN, NJG = C::TN / JG;
+                bf16x8 af[C::TM];
+                s16x4 alo[C::TM], ahi[C::TM];
 #pragma unroll
-                for (int j = 0; j < C::TN; ++j) {
-                    const int cb = wn * C::WN + j * 16 + tp * 4;           // first of the lane's 4 columns
-                    blo[j] = lds_tr16b(b_st + r0 * 256 + (((cb >> 3) ^ f0) << 4) + (cb & 4) * 2);
-                    bhi[j] = lds_tr16b(b_st + (r0 + 4) * 256 + (((cb >> 3) ^ f1) << 4) + (cb & 4) * 2);
-                }
+                for (int jg = 0; jg < NJG; ++jg) {
+                    bf16x8 bfr[JG];
+                    s16x4 blo[JG], bhi[JG];
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i) {
-                    const int cb = wm * C::WM + i * 16 + tp * 4, hb = (cb >> 7) * 256, cl = cb & 127;      // 256-byte half of the row, column inside it
-                    alo[i] = lds_tr16b(a_st + r0 * C::A_ROW + hb + (((cl >> 3) ^ f0) << 4) + (cl & 4) * 2);
-                    ahi[i] = lds_tr16b(a_st + (r0 + 4) * C::A_ROW + hb + (((cl >> 3) ^ f1) << 4) + (cl & 4) * 2);
-                }
-                if constexpr (C::TM == 4) {
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]),
-                                   "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3])
-                                 :: "memory");
-                } else {
-                    static_assert(C::TM == 2 || C::TM == 4, "lds_tr wait lists");
-                    asm volatile("s_waitcnt lgkmcnt(0)"
-                                 : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1])
-                                 :: "memory");
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < JG; ++j) {
+                        const int cb = wn * C::WN + (jg * JG + j) * 16 + tp * 4, hb = (cb >> 7) * 256, cl = cb & 127;      // first of the lane's 4 columns
+                        blo[j] = lds_tr16b(b_st + r0 * C::B_ROW + hb + (((cl >> 3) ^ f0) << 4) + (cl & 4) * 2);
+                        bhi[j] = lds_tr16b(b_st + (r0 + 4) * C::B_ROW + hb + (((cl >> 3) ^ f1) << 4) + (cl & 4) * 2);
+                    }
+                    if (jg == 0) {
 #pragma unroll
-                for (int j = 0; j < C::TN; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7));
+                        for (int i = 0; i < C::TM; ++i) {
+                            const int cb = wm * C::WM + i * 16 + tp * 4, hb = (cb >> 7) * 256, cl = cb & 127;      // 256-byte half of the row, column inside it
+                            alo[i] = lds_tr16b(a_st + r0 * C::A_ROW + hb + (((cl >> 3) ^ f0) << 4) + (cl & 4) * 2);
+                            ahi[i] = lds_tr16b(a_st + (r0 + 4) * C::A_ROW + hb + (((cl >> 3) ^ f1) << 4) + (cl & 4) * 2);
+                        }
+                    }
+                    if constexpr (JG == 4) {
+                        if (jg == 0)
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]), "+v"(bhi[3]),
+                                           "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]), "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3])
+                                         :: "memory");
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]), "+v"(bhi[3])
+                                         :: "memory");
+                    } else if constexpr (C::TM == 4) {
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]),
+                                       "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3])
+                                     :: "memory");
+                    } else {
+                        static_assert(C::TM == 2 || C::TM == 4, "lds_tr wait lists");
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1])
+                                     :: "memory");
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i) af[i] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+                    for (int j = 0; j < JG; ++j) bfr[j] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(blo[j], bhi[j], 0, 1, 2, 3, 4, 5, 6, 7));
+                    if (jg == 0) {
 #pragma unroll
-                for (int i = 0; i < C::TM; ++i) {
+                        for (int i = 0; i < C::TM; ++i) af[i] = __builtin_bit_cast(bf16x8, (s16x8b)__builtin_shufflevector(alo[i], ahi[i], 0, 1, 2, 3, 4, 5, 6, 7));
+                    }
 #pragma unroll
-                    for (int j = 0; j < C::TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-                    if constexpr (decltype(with_bias)::value) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
-                    // K-step kt + AHEAD goes out between the MFMA groups: PER_STAGE DMA wave-instructions over the 2 * TM slots of a K-step
-                    constexpr int SLOTS = 2 * C::TM;
-                    const int slot = ks * C::TM + i;
+                    for (int i = 0; i < C::TM; ++i) {
 #pragma unroll
-                    for (int d = 0; d < C::PER_STAGE; ++d)
-                        if (d * SLOTS / C::PER_STAGE == slot) issue_one(d, kt + C::AHEAD, st_nxt);
+                        for (int j = 0; j < JG; ++j) acc[i][jg * JG + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][jg * JG + j], 0, 0, 0);
+                        if constexpr (decltype(with_bias)::value) { if (jg == 0) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0); }
+                        // K-step kt + AHEAD goes out between the MFMA groups: PER_STAGE DMA wave-instructions over the 2 * TM * NJG slots of a K-step
+                        constexpr int SLOTS = (C::BK / 32) * C::TM * NJG;
+                        const int slot = (ks * NJG + jg) * C::TM + i;
+#pragma unroll
+                        for (int d = 0; d < C::PER_STAGE; ++d)
+                            if (d * SLOTS / C::PER_STAGE == slot) issue_one(d, kt + C::AHEAD, st_nxt);
+                    }
                 }
             }
             st_cur = (st_cur + 1 == C::NST) ? 0 : st_cur + 1;
@@ -612,20 +642,24 @@ bool blt_wgrad_group_ok(int dtype, const GemmArgs& a) {
 // host table -> (problems, wg0, tile rows); returns the number of workgroups.  256-row tiles when they still fill the chip; split-K only
 // when the whole launch is short of tiles.
 int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_problem>& probs, std::vector<int>& wg0, int* bm_out) {
-    long t256 = 0;
-    for (const GemmArgs& a : g) t256 += (long)cdiv(a.M, 256) * cdiv(a.N, 128);
+    // tile form (returned through *bm_out): 128 = 128 x 128, 256 = 256 x 128, 512 = 256 x 256 (square) — the largest that still gives every
+    // CU a tile; debug key 13 forces one
+    long t256 = 0, tsq = 0;
+    for (const GemmArgs& a : g) { t256 += (long)cdiv(a.M, 256) * cdiv(a.N, 128); tsq += (long)cdiv(a.M, 256) * cdiv(a.N, 256); }
     const int forced = blt_debug_get(13);
-    const int bm = forced == 128 || forced == 256 ? forced : (t256 >= 256 ? 256 : 128);
+    (void)tsq;      // the square form is selectable (debug key 13 = 512) but not chosen: measured 361 us vs 363 us for the 256 x 128 form on the decoder's set
+    const int bm = (forced == 128 || forced == 256 || forced == 512) ? forced : (t256 >= 256 ? 256 : 128);
+    const int tm = bm == 128 ? 128 : 256, tn = bm == 512 ? 256 : 128;
     long tiles = 0;
-    for (const GemmArgs& a : g) tiles += (long)cdiv(a.M, bm) * cdiv(a.N, 128);
+    for (const GemmArgs& a : g) tiles += (long)cdiv(a.M, tm) * cdiv(a.N, tn);
     probs.clear(); wg0.clear();
     int wg = 0;
     for (const GemmArgs& a : g) {
         blt_wg_problem p;
         p.A = a.A; p.B = a.B; p.C = (float*)a.C; p.bias = a.a_rowsum;
         p.Nw = a.M; p.Kw = a.N; p.Mtok = a.K; p.lda = a.lda; p.ldb = a.ldb; p.ldc = a.ldc;
-        p.tiles_n = cdiv(a.N, 128);
-        const int t = cdiv(a.M, bm) * p.tiles_n;
+        p.tiles_n = cdiv(a.N, tn);
+        const int t = cdiv(a.M, tm) * p.tiles_n;
         const int nk = cdiv(a.K, 64);
         int s = 1;
         if (tiles < 192) {                 // fewer tiles than CUs in the whole launch: slice K (>= 4 K-steps per slice)
@@ -660,6 +694,7 @@ static int launch_wg(const blt_wg_problem* probs_dev, const int* wg0_dev, int np
     return blt_check_launch("wgrad_group");
 }
 int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, int bm, hipStream_t s) {
-    BLT_REQUIRE(probs_dev && wg0_dev && nprob > 0 && nprob < 250 && nwg > 0 && (bm == 128 || bm == 256), "wgrad_group: bad table");
+    BLT_REQUIRE(probs_dev && wg0_dev && nprob > 0 && nprob < 250 && nwg > 0 && (bm == 128 || bm == 256 || bm == 512), "wgrad_group: bad table");
+    if (bm == 512) return launch_wg<WgCfgSq>(probs_dev, wg0_dev, nprob, nwg, s);
     return bm == 256 ? launch_wg<WgCfgT<256>>(probs_dev, wg0_dev, nprob, nwg, s) : launch_wg<WgCfgT<128>>(probs_dev, wg0_dev, nprob, nwg, s);
 }

@@ -66,6 +66,9 @@ def parse():
     ap.add_argument("--extra-steps", type=int, default=10)
     ap.add_argument("--bf16-wire", action="store_true", help="N > 1: gradients cross xGMI as bf16 (half the bytes); default fp32 like Lightning DDP")
     ap.add_argument("--autotune", action="store_true", help="time candidate GEMM/conv kernels per launch in the first warm-up step")
+    ap.add_argument("--f32-steps", type=int, default=10, help="extra leg: timed steps of the fp32 (reference-precision, exact-fp32 MFMA) engine on the same "
+                                                              "config, reported as `f32` beside the bf16 headline (0 = skip)")
+    ap.add_argument("--no-prefetch", action="store_true", help="run the frozen conv stack inline in forward (round-2 form) instead of one batch ahead")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=20)
     return ap.parse_args()
@@ -153,7 +156,7 @@ def cpu_baseline(cfg, phase2, batch, steps):
             times.append(time.perf_counter() - t0)
         print("[bench] cpu baseline step %d: %.2f s" % (i, time.perf_counter() - t0), file=sys.stderr, flush=True)
     t = sorted(times)[len(times) // 2]
-    return dict(value=round(batch / t, 2), unit="pairs/s", cores=cores, kind="port",
+    return dict(value=round(batch / t, 2), unit="pairs/s", cores=cores, kind="port", s_per_step=round(t, 3), batch=batch,
                 sample="%d timed train steps (median, 1 untimed warm-up) of the CPU oracle: same model config and synthetic inputs at batch %d, "
                        "fp32, phase %d (latent %s), dropout OFF (the GPU leg runs the reference's 0.1/0.1: Philox masks cost the CPU leg nothing "
                        "it would not also skip), forward + losses + backward + clip 5 + Adam" % (steps, batch, 2 if phase2 else 1,
@@ -202,6 +205,20 @@ def loss_vs_oracle(eng, cfg, a, B, phase2, batch, rank):
                     "vs the fp32 CPU oracle on the same inputs" % (" + 0.5*%.2f kld + aux" % HP["kl_weight"] if phase2 else "", a.dtype, B)}
 
 
+WORK_SKIPPING_KEYS = (14, 15)
+
+
+def check_debug_keys(lib):
+    """{key: value} of every non-zero debug key; exits non-zero when a work-skipping ablation is requested or available."""
+    keys = {str(k): int(lib.bltvqg_debug_get(k)) for k in range(24) if int(lib.bltvqg_debug_get(k)) != 0}
+    bad = [k for k in WORK_SKIPPING_KEYS if str(k) in keys]
+    if bad or int(lib.bltvqg_build_has_ablations()):
+        print("bench.py: refusing to time a run that can skip work (debug keys %s set, ablation build: %d); the headline needs the shipped "
+              "library and keys 14 / 15 unset" % (bad, int(lib.bltvqg_build_has_ablations())), file=sys.stderr, flush=True)
+        sys.exit(3)
+    return keys
+
+
 def main():
     a = parse()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -243,12 +260,15 @@ def main():
     from bltvqg_amd.engine import StepEngine, make_config
     from bltvqg_amd.trainer import DataParallelStep, comm_plan, init_reference_style, shard_seed
 
-    # A/B switches of the kernels (bltvqg_debug_set): BLT_DEBUG="key=value,key=value"
+    # A/B switches of the kernels (bltvqg_debug_set): BLT_DEBUG="key=value,key=value".  Every non-zero key is echoed in the JSON line
+    # (`debug_keys`); the work-skipping timing ablations (keys 14 / 15, which exist only in the -DBLT_ABLATE build) are refused here: a
+    # timed region that skips work is not a measurement of this benchmark.
+    from bltvqg_amd import _lib as _l
     if os.environ.get("BLT_DEBUG"):
-        from bltvqg_amd import _lib as _l
         for kv in os.environ["BLT_DEBUG"].split(","):
             k, v = kv.split("=")
             _l.load().bltvqg_debug_set(int(k), int(v))
+    debug_keys = check_debug_keys(_l.load())
     cfg = dict(CONFIGS[a.config])
     B = a.batch or cfg.pop("batch")
     cfg.pop("batch", None)
@@ -267,6 +287,7 @@ def main():
     d = {k: batch[k].to(dev) for k in keys}
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
 
+    use_prefetch = (not a.no_prefetch) and not cfg.get("num_regions")
     # ---- the PCIe-inclusive feed: pinned host batch, copied one step ahead on a copy stream into two device buffers -----------
     h2d_state = {}
 
@@ -299,8 +320,16 @@ def main():
             upload(slot ^ 1)                                   # next step's batch crosses PCIe underneath this step
             torch.cuda.current_stream().wait_event(h2d_state["ready"][slot])
             cur = h2d_state["bufs"][slot]
+        # image mode: the frozen conv stack of the NEXT batch is enqueued one batch ahead (DataParallelStep.run(next_images=...)); every
+        # step still contains exactly one conv stack and one of everything else
+        nxt = None
+        if use_prefetch and not h2d:      # (the PCIe-fed loop keeps the stack inline: its next batch is still crossing PCIe when this step starts)
+            nxt = cur["images"]
+        elif eng.prefetch_pending():      # a loop of the other kind left its look-ahead batch behind: it is this same synthetic batch
+            step.run(None, cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=999, kl_weight=HP["kl_weight"], lr=HP["lr"],
+                     max_norm=HP["max_norm"])
         step.run(cur["images"], cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=1000 + i,
-                 kl_weight=HP["kl_weight"], lr=HP["lr"], max_norm=HP["max_norm"])
+                 kl_weight=HP["kl_weight"], lr=HP["lr"], max_norm=HP["max_norm"], next_images=nxt)
         if h2d:
             h2d_state["free"][i % 2].record()
 
@@ -311,10 +340,13 @@ def main():
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]      # step boundaries on the step's stream (median_ms_per_step)
         t0 = time.perf_counter()
+        marks[0].record()
         for i in range(n):
             eng.profile_enable((3 | (PROFILE_STRIDE << 8)) if i == profile_step else 0)
             one_step(first + i, phase2, h2d)
+            marks[i + 1].record()
         step.finish()                                           # the last (overlapped) optimiser update is part of the timed region
         torch.cuda.synchronize()
         if dist:
@@ -322,6 +354,8 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         eng.profile_enable(0)
+        per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(n))
+        timed_loop.median_ms = per_step[n // 2]
         if dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -348,6 +382,7 @@ def main():
     # would add ~50 % to every step, so they are sampled; the profiled step IS inside the timed region and counted in `value`.
     prof_step = a.steps // 2
     dt = timed_loop(a.steps, a.warmup, phase2, a.h2d, profile_step=prof_step)
+    median_ms = timed_loop.median_ms      # GPU time between consecutive step boundaries on the step's stream (one profiled step among them)
     print("[bench] rank %d: %d timed steps in %.3f s" % (rank, a.steps, dt), file=sys.stderr, flush=True)
     conv_ms, conv_n, conv_flops = eng.profile_read(0)
     gemm_ms, gemm_n, gemm_flops = eng.profile_read(1)
@@ -379,6 +414,46 @@ def main():
             "ms_per_step": round(dt_h / n * 1e3, 3), "pairs_per_s": round(B * world * n / dt_h, 1), "steps": n,
             "what": "same step, batch resident in HBM" if a.h2d else
                     "same step fed from a pinned host batch copied over PCIe every step, one step ahead on a copy stream (never the headline value)"}
+    if dist and not a.no_extras and a.extra_steps > 0:
+        # exposed communication per step (HIP events: end of backward on the step's stream -> end of the last all-reduce on the
+        # communication stream), measured in a loop of its own so that the event pairs are not inside the headline's timed region
+        step.measure_exposed = True
+        for i in range(a.extra_steps):
+            one_step(i, phase2, a.h2d)
+        step.finish()
+        torch.cuda.synchronize()
+        ex = sorted(step.exposed_ms())
+        step.measure_exposed = False
+        extras["exposed_comm_ms_per_step"] = {"median": round(ex[len(ex) // 2], 3), "max": round(ex[-1], 3), "steps": len(ex),
+                                              "what": "HIP events: end of backward (step stream, all engine streams joined) -> end of the last gradient "
+                                                      "all-reduce (communication stream); 0 = the exchange finished under backward"}
+    if world == 1 and a.f32_steps > 0 and not a.no_extras and a.dtype == "bf16":
+        # reference-precision leg: the SAME step on the fp32 engine (fp32 storage, exact-fp32 MFMA) — the engine that meets the 1e-3 parity bar
+        c32 = make_config(B, cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"], cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"],
+                          cfg["vocab_size"], dtype=0, num_regions=cfg.get("num_regions", 0), region_dim=cfg.get("region_dim", 0))
+        e32 = StepEngine(c32, dev)
+        e32.allocate()
+        init_reference_style(e32, seed=0)
+        s32 = DataParallelStep(e32, None, overlap_optimizer=True)
+
+        def step32(i):
+            eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+            s32.run(d["images"], d["answers"], d["posteriors"], d["questions"], eps, phase2, seed=1000 + i, kl_weight=HP["kl_weight"],
+                    lr=HP["lr"], max_norm=HP["max_norm"], next_images=d["images"] if use_prefetch else None)
+        for i in range(3):
+            step32(i)
+        s32.finish()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.f32_steps):
+            step32(3 + i)
+        s32.finish()
+        torch.cuda.synchronize()
+        dt32 = time.perf_counter() - t0
+        extras["f32"] = {"ms_per_step": round(dt32 / a.f32_steps * 1e3, 3), "pairs_per_s": round(B * a.f32_steps / dt32, 1), "steps": a.f32_steps,
+                         "what": "same config, batch and phase on the fp32 engine (fp32 storage, exact-fp32 MFMA v_mfma_f32_16x16x4_f32): the precision that "
+                                 "meets the north-star 1e-3 loss tolerance (tests/test_fullsize_gpu.py)"}
+        del s32, e32
     comm = None
     if dist:
         # the exchange in isolation: each collective of the step's plan alone on the communication stream, median of 5
@@ -428,26 +503,36 @@ def main():
         roof_conv = family(conv_ms, conv_n, conv_flops,
                            "the 20 convolution launches of the ResNet-18 stack: conv3x3_pp_kernel (13, LDS-patch 3x3), conv_stem_pool_kernel (1: stem + max-pool, pooled extrema), "
                            "gemm_dma_kernel<*,*,conv,*> (6: stride-2 / 1x1); flops over real pixels, unpadded Cin")
-        # HBM bytes per launch from the committed PMC passes (profiles/summarize_pmc.py): collected for the default workload only
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+        # HBM bytes per launch and the rocprofv3 launch durations come from the COMMITTED profile passes of this same command (separate
+        # --pmc FETCH_SIZE / WRITE_SIZE runs cannot share a process with the timed loop): static numbers, labelled with their source
+        for prof_name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+            pmc = os.path.join(ROOT, "profiles", prof_name)
+            if os.path.exists(pmc):
+                break
         if a.config == "big" and B == 256 and a.dtype == "bf16" and os.path.exists(pmc):
             tr = json.load(open(pmc))
+            src = "profiles/%s (static: collected by profiles/%s at commit %s, not measured in this run)" % (
+                os.path.basename(pmc), tr.get("collected_by", "collect_r02.sh"), tr.get("commit", "c1b9ef8-or-earlier"))
             if roof and "gemm_bytes_per_launch" in tr:
                 roof["traffic"] = int(tr["gemm_bytes_per_launch"])
+                roof["traffic_source"] = src
             if roof_conv and "conv_bytes_per_launch" in tr:
                 roof_conv["traffic"] = int(tr["conv_bytes_per_launch"])
-            # the committed rocprofv3 --kernel-trace --stats run of this same command (profiles/r02_bench_kernel_stats.csv): under the
-            # profiler the host enqueue is slower, the three streams of the step overlap less and a launch is stretched less by the
-            # other streams' workgroups than in the un-profiled brackets above
+                roof_conv["traffic_source"] = src
+            # the committed rocprofv3 --kernel-trace --stats run of this same command: under the profiler the host enqueue is slower,
+            # the streams of the step overlap less and a launch is stretched less by the other streams' workgroups than in the
+            # un-profiled brackets above
             for r_, key in ((roof, "gemm"), (roof_conv, "conv")):
                 rp = (tr.get(key) or {}).get("rocprof_avg_launch_us")
                 if r_ and rp:
                     r_["rocprof_avg_launch_us"] = rp
                     r_["rocprof_frac"] = round(r_["gflop_per_step"] / r_["launches_per_step"] / rp * 1e3 / r_["peak"], 4)      # GFLOP / us = PFLOP/s
+                    r_["rocprof_source"] = src
         out = {
             "metric": "image-question pairs/sec (train step)", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
             "world_size": (dist.get_world_size() if dist is not None else 1),
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "median_ms_per_step": round(median_ms, 3),
+            "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype,
             "data": "synthetic, pinned host batch copied over PCIe every step (one step ahead)" if a.h2d else "synthetic",
             "config": {"workload": "%s: IQ train step (fwd+loss+bwd+clip+Adam), %s cfg: %d-layer d_model=%d %d-head, per-GPU batch %d, %s, "
@@ -461,6 +546,9 @@ def main():
         }
         if roof and roof_conv:
             out["roofline_conv"] = roof_conv
+        out["debug_keys"] = debug_keys
+        out["conv_stack"] = ("one batch ahead on the engine's conv stream (bltvqg_engine_prefetch_images)" if use_prefetch and not a.h2d
+                             else "inline in forward")
         out.update(extras)
         if comm:
             out["dist"] = comm

@@ -38,6 +38,8 @@ SIGNATURES = {
     "bltvqg_version": (I, []),
     "bltvqg_last_error_string": (S, []),
     "bltvqg_debug_set": (None, [I, I]),
+    "bltvqg_debug_get": (I, [I]),
+    "bltvqg_build_has_ablations": (I, []),
     "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
     "bltvqg_gemm_ex": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, F, U64, U32, P, I, F, P, I, P, I, I, I, I, P]),
     "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
@@ -86,6 +88,7 @@ SIGNATURES = {
     "bltvqg_sumsq": (I, [P, L, P, P]),
     "bltvqg_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, I, P]),
     "bltvqg_dropout_mask": (I, [U64, U32, L, I, I, F, P, P]),
+    "bltvqg_hw_id_probe": (I, [P, I, I, P]),
     "bltvqg_cast": (I, [I, P, I, I, P, I, L, I, P]),
     "bltvqg_image_store_u8": (I, [P, P, L, P]),
     "bltvqg_batch_rows": (I, [P, P, P, P, I, L, P, I, I, I, P, P, P, P, P, P]),
@@ -93,6 +96,12 @@ SIGNATURES = {
     "bltvqg_batch_images_packed": (I, [P, L, I, P, L, P, P, P, I, I, I, ctypes.POINTER(ctypes.c_float), I, P, I, I, I, I, P]),
     "bltvqg_engine_image_input": (I, [P, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                       ctypes.POINTER(ctypes.c_int)]),
+    "bltvqg_engine_prefetch_images": (I, [P, P, P]),
+    "bltvqg_engine_prefetch_pending": (I, [P]),
+    "bltvqg_engine_set_prefetch_split": (I, [P, I]),
+    "bltvqg_engine_set_cu_masks": (I, [P, P, P, P, I, I]),
+    "bltvqg_engine_chain_stream": (I, [P, ctypes.POINTER(ctypes.c_void_p)]),
+    "bltvqg_engine_conv_stream": (I, [P, ctypes.POINTER(ctypes.c_void_p)]),
     "bltvqg_engine_create": (P, [ctypes.POINTER(Config)]),
     "bltvqg_engine_destroy": (None, [P]),
     "bltvqg_engine_num_params": (I, [P, I]),
@@ -104,6 +113,7 @@ SIGNATURES = {
     "bltvqg_engine_bind": (I, [P, P, P, P, P, P, P, L]),
     "bltvqg_engine_invalidate_frozen": (None, [P]),
     "bltvqg_engine_trust_shadows": (I, [P, I]),
+    "bltvqg_engine_invalidate_params": (None, [P]),
     "bltvqg_engine_forward": (I, [P, P, P, P, P, P, I, U64, P]),
     "bltvqg_engine_decode_greedy": (I, [P, P, P, P, I, I, P, P, P, P]),
     "bltvqg_engine_set_bn_train": (I, [P, I]),

@@ -8,6 +8,14 @@ static inline int ilog2i(int x) { int l = 0; while ((1 << l) < x) ++l; return l;
 extern "C" {
 
 void bltvqg_debug_set(int key, int value) { blt_debug_set(key, value); }
+int bltvqg_debug_get(int key) { return blt_debug_get(key); }
+int bltvqg_build_has_ablations(void) {
+#ifdef BLT_ABLATE
+    return 1;
+#else
+    return 0;
+#endif
+}
 
 int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, int ldb, int transB, void* C, int ldc, int M, int N, int K,
                 const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id, const void* maskY, int ldm, float mask_scale,
@@ -28,9 +36,11 @@ int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int 
     g.maskY = maskY; g.ldm = ldm; g.mask_scale = mask_scale; g.C2 = C2; g.ldc2 = ldc2; g.R = R; g.ldr = ldr; g.accumulate = accumulate;
     if (tile_m < 0) { g.no_dma = 0; g.force_tile = 64; return blt_gemm(BLT_BF16, g, (hipStream_t)stream); }      // round-1 kernel (64x64 ring)
     BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g), "gemm_ex: operands do not fit the planned-tile kernel (bf16 NT, lda/ldb %% 8 == 0, M >= 256)");
-    BLT_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && ldc >= N && ((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0,
-                "gemm_ex: bad operands");
-    return blt_gemm_nt2(g, (hipStream_t)stream, tile_m, tile_n);
+    BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "gemm_ex: tile_m / tile_n must both be 0 or both be a compiled tile shape");
+    // through blt_gemm: the same operand validation as every other entry point (pitches >= round8(K), 16-byte aligned epilogue operands,
+    // rowtab needs rowidx, dropout range); a bad call is BLT_ERR_ARG, not an out-of-bounds LDS-DMA read on the device
+    g.nt2_bm = tile_m; g.nt2_bn = tile_n;
+    return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
 }
 
 int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, const void* const* X, const int32_t* ldx, float* const* dW,
@@ -306,6 +316,9 @@ int bltvqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, co
 }
 int bltvqg_dropout_mask(uint64_t seed, uint32_t stream_id, int64_t rows, int cols, int ld_index, float p, uint8_t* out, void* stream) {
     return blt_dropout_mask(seed, stream_id, (long)rows, cols, ld_index, p, out, (hipStream_t)stream);
+}
+int bltvqg_hw_id_probe(int32_t* out, int n_workgroups, int spin_ticks, void* stream) {
+    return blt_hw_id_probe((int*)out, n_workgroups, spin_ticks, (hipStream_t)stream);
 }
 int bltvqg_cast(int dtype_src, const void* src, int ld_src, int dtype_dst, void* dst, int ld_dst, int64_t rows, int cols, void* stream) {
     return blt_cast_rows(dtype_src, src, ld_src, dtype_dst, dst, ld_dst, (long)rows, cols, (hipStream_t)stream);

@@ -569,13 +569,13 @@ int launch_mfma(const AttnArgs& a, bool bwd, hipStream_t s) {
     }
     const size_t lds = 4 * (3 * 32 * PITCH + 2 * 32 * ATT_PP);
     if (lds > 64 * 1024) {
-        static bool set = false;
-        if (!set) {
+        static BltDevFlag set;
+        if (!set.get()) {
             if (hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
                 blt_set_error("attn_bwd: hipFuncSetAttribute failed");
                 return BLT_ERR_HIP;
             }
-            set = true;
+            set.set();
         }
     }
     hipLaunchKernelGGL(attn_bwd_mfma_kernel<D>, dim3(grid), dim3(256), lds, s, a);

@@ -180,3 +180,12 @@ __host__ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint32_t st
     dropout_words(seed, stream, e >> 3, w);
     return dropout_lane(w, (int)(e & 7)) >= thresh;
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE setting: one flag per (kernel instantiation, device), so that a process
+// that drives several GPUs sets it on each of them (one process per GPU is the deployed form; tests and tools may not be)
+struct BltDevFlag {
+    bool done[32] = {};
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 31; }
+    bool get() const { return done[dev()]; }
+    void set() { done[dev()] = true; }
+};

@@ -262,14 +262,14 @@ __global__ __launch_bounds__(NWM * 128) void conv3x3_pp_kernel(const ConvPPArgs 
 
 template <int BN, int NSTB, bool FUSE_IN, int NWM = 2>
 int launch(const ConvPPArgs& a, int grid, size_t lds, hipStream_t s) {
-    static bool attr_set = false;
+    static BltDevFlag attr_set;
     auto kern = conv3x3_pp_kernel<BN, NSTB, FUSE_IN, NWM>;
-    if (!attr_set) {
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
             blt_set_error("conv3x3_pp: hipFuncSetAttribute failed");
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NWM * 128), lds, s, a);
     return blt_check_launch("conv3x3_pp");
@@ -710,13 +710,13 @@ int blt_conv_stem_pool(const void* x_padded, const void* w, const float* gamma, 
     a.X = (const bf16*)x_padded; a.Wt = (const bf16*)w; a.gamma = gamma; a.Y = (bf16*)y_pool_pp; a.N = N; a.Hp = Hp; a.Wp = Wp;
     a.Ho = (H + 6 - 7) / 2 + 1; a.Wo = (W + 6 - 7) / 2 + 1; a.stat_sum = stat_sum; a.stat_sq = stat_sq;
     BLT_REQUIRE((long)N * (a.Ho / 8) * (a.Wo / 14) < (1L << 31), "conv_stem_pool: too many tiles");
-    static bool attr_set = false;
-    if (!attr_set) {
+    static BltDevFlag attr_set;
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)conv_stem_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEMP_LDS) != hipSuccess) {
             blt_set_error("conv_stem_pool: hipFuncSetAttribute failed");
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     hipLaunchKernelGGL(conv_stem_pool_kernel, dim3((unsigned)stem_pool_grid(N, H, W)), dim3(256), STEMP_LDS, s, a);
     return blt_check_launch("conv_stem_pool");

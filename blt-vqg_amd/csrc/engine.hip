@@ -100,7 +100,10 @@ struct bltvqg_engine {
     // Adam bias-correction counters of the always-trained / latent-phase-only regions.  They belong to the OPTIMISER STATE (the
     // moment buffers), not to an engine: engines of different batch shapes that share one set of parameter / moment buffers (the
     // ragged last batch of an epoch) share one counter object too (bltvqg_engine_share_optimizer_state).
-    struct AdamSteps { int main = 0, late = 0; long params_gen = 0; };      // params_gen: bumped by every write to the shared parameters
+    // params_gen: bumped by every write to the shared parameters.  opt_gen / opt_done_ev: the asynchronous optimiser update (below) is a
+    // write to the SHARED buffers, so "an update is in flight" belongs here too: every engine sharing them orders itself behind the
+    // latest update it has not yet waited for (engine B's forward must not run under engine A's in-flight Adam).
+    struct AdamSteps { int main = 0, late = 0; long params_gen = 0; long opt_gen = 0; hipEvent_t opt_done_ev = nullptr; };
     std::shared_ptr<AdamSteps> steps = std::make_shared<AdamSteps>();
     int last_bwd_phase2 = 0;
     // workspace buffers
@@ -119,6 +122,30 @@ struct bltvqg_engine {
     float* stats;               // 8 floats
     void *img, *pool0, *feats;
     float *pooled, *featpre, *feats32, *dfeats32, *dfeatpre32;   // the CNN head (avg-pool -> fc -> BatchNorm1d) stays in fp32
+    // ---- the frozen conv stack one batch ahead (bltvqg_engine_prefetch_images) --------------------------------------------------------
+    // encoder_cnn.py:18-19 freezes the backbone: the conv stack of batch i+1 depends on nothing step i updates.  It runs on a stream of
+    // its own (optionally on a CU partition of its own, bltvqg_engine_set_cu_masks) underneath step i and leaves the pooled [B,512]
+    // feature in the OTHER slot of `pooled_buf`; forward(i+1) waits for that slot's event and starts at the trainable head.  BatchNorm2d
+    // running statistics advance in batch order because the stack of every batch runs on that one in-order stream.
+    float* pooled_buf[2] = {nullptr, nullptr};
+    int pool_cur = 0;            // slot the current step's head (forward and weight gradient) reads
+    int pf_head = 0, pf_n = 0;   // prefetched slots not yet consumed by a forward: pf_head is the next one, pf_n in {0, 1, 2}
+    int prefetch_split = 10;     // leading stages of the conv stack (cnn_convs) a prefetch runs; the forward that consumes it runs the rest
+    int pf_split[2] = {10, 10};
+    bool pool_in_use = false;    // a forward consumed pool_cur and its backward has not been enqueued yet
+    bool cnn_stream_used = false;
+    int last_cnn_slot = 0;       // slot of the last stack enqueued on the conv stream (its event orders an inline stack behind it)
+    hipStream_t cnn_stream = nullptr, chain_stream = nullptr;
+    hipEvent_t cnn_in_ev = nullptr, cnn_done[2] = {nullptr, nullptr};
+    bool have_masks = false;
+    uint32_t cu_masks[3][8] = {};      // [0] chain (caller's stream + side[0]), [1] side[1] (weight gradients, optimiser), [2] conv stack
+    bool cu_mask_on[3] = {false, false, false};
+    int make_stream(hipStream_t* st, int which) {
+        hipError_t rc = (have_masks && cu_mask_on[which]) ? hipExtStreamCreateWithCUMask(st, 8, cu_masks[which])
+                                                          : hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+        if (rc != hipSuccess) { blt_set_error("engine: stream creation failed (%s)", hipGetErrorString(rc)); return BLT_ERR_HIP; }
+        return BLT_OK;
+    }
     float *bn1_mean, *bn1_rstd;
     std::vector<ConvSpec> convs;
     float *stat_sum, *stat_sq;
@@ -136,7 +163,15 @@ struct bltvqg_engine {
     void *g_rec1, *g_net[2][2];                      // [B, *] gradients that are operands of deferred weight-gradient GEMMs (never reused)
     void *g_rin, *g_zc;                              // d(reconstructor input), d(z_classifier input): produced on the branch stream
     float* acc_big2;                                 // split-K accumulator of the z_classifier dgrad (branch stream)
-    hipEvent_t bucket_ev[3] = {nullptr, nullptr, nullptr};
+    // Gradient buckets (data-parallel exchange): contiguous ranges of the flat gradient buffer, listed in the order backward
+    // COMPLETES them.  The weight gradients of a stack are flushed to the side stream in groups of whole layers of >= ~32 MB
+    // (bucket_target_bytes), each flush closes one bucket and records its event right behind its last launch, so that every collective but
+    // the last is enqueued while backward is still running and none is larger than a few layers.
+    struct Bucket { int64_t off = 0, len = 0; int late = 0; hipEvent_t ev = nullptr; };
+    std::vector<Bucket> buckets;                         // completion order
+    std::vector<int> dec_flush, enc_flush, renc_flush;   // per layer l: bucket closed by the flush after layer l's backward, or -1
+    int bk_dec_last = -1, bk_late0 = -1, bk_enc_last = -1, bk_renc_last = -1, bk_tail = -1;
+    static constexpr int64_t BUCKET_TARGET_BYTES = 32ll << 20;
     // the 330 MB gradient memset leaves the critical path: forward() issues it on a side stream (behind the previous optimiser update,
     // the last reader of the gradients) and backward only waits for its event
     hipEvent_t grad_zero_ev = nullptr;
@@ -170,10 +205,12 @@ struct bltvqg_engine {
     // the tail of the all-reduce.  Every other entry point first orders itself behind the pending update (sync_opt).
     hipStream_t opt_stream = nullptr;
     hipEvent_t opt_fork = nullptr, opt_done = nullptr;
-    bool opt_pending = false;
+    long opt_seen = 0;           // the shared opt_gen this engine's caller stream is already ordered behind
+    bool opt_is_pending() const { return opt_seen != steps->opt_gen; }
+    void opt_mark_synced() { opt_seen = steps->opt_gen; }
     int sync_opt(hipStream_t s) {
-        if (!opt_pending) return BLT_OK;
-        if (hipStreamWaitEvent(s, opt_done, 0) != hipSuccess) { blt_set_error("engine: optimiser wait failed"); return BLT_ERR_HIP; }
+        if (!opt_is_pending() || !steps->opt_done_ev) return BLT_OK;
+        if (hipStreamWaitEvent(s, steps->opt_done_ev, 0) != hipSuccess) { blt_set_error("engine: optimiser wait failed"); return BLT_ERR_HIP; }
         return BLT_OK;
     }
     bool use_streams = true;
@@ -230,8 +267,6 @@ struct bltvqg_engine {
         prof_end(pi, s, 2.0 * (double)g.M * (double)g.N * (double)g.K);
         return rc;
     }
-    int64_t bucket_off[3], bucket_len[3];
-    int bucket_late[3];
 
     // ---------------------------------------------------------------------------------------------
     void add_t(const std::string& n, int r, int cdim, int late) {
@@ -271,22 +306,40 @@ struct bltvqg_engine {
         add_t(pre + ".weight", H, 0, late);
         add_t(pre + ".bias", H, 0, late);
     }
-    void add_enc_stack(const std::string& pre, int late) {
+    // closes the bucket [start, tsize) and returns its index in `tmp` (build order; build_params reorders into completion order)
+    std::vector<Bucket> tmp_buckets;
+    int64_t bucket_start = 0;
+    int close_bucket(int late) {
+        Bucket b; b.off = bucket_start; b.len = tsize - bucket_start; b.late = late;
+        bucket_start = tsize;
+        tmp_buckets.push_back(b);
+        return (int)tmp_buckets.size() - 1;
+    }
+    // layers L-1 .. 0 of a stack in backward order: after which layers the collected weight gradients are flushed (>= target bytes pending)
+    void add_enc_stack(const std::string& pre, int late, std::vector<int>& flush_after) {
         add_ln(pre + ".layer_norm", late);
+        flush_after.assign(L, -1);
         for (int l = L - 1; l >= 0; --l) {
             const std::string lp = pre + ".enc." + std::to_string(l) + ".";
             add_mha(lp + "multi_head_attention.", late);
             add_ffn(lp + "positionwise_feed_forward.", late);
             add_ln(lp + "layer_norm_mha", late);
             add_ln(lp + "layer_norm_ffn", late);
+            if (l > 0 && (tsize - bucket_start) * 4 >= BUCKET_TARGET_BYTES) flush_after[l] = close_bucket(late);
         }
     }
 
     void build_params() {
-        // ---- trainable, in the order backward completes them (gradient buckets are prefixes of this order) ----
+        // ---- trainable, in the order backward completes them; buckets are closed at the weight-gradient flush points ----
         add_t("decoder.output.weight", V, H, 0);
         add_t("decoder.output.bias", V, 0, 0);
+        // (the reconstructor's weight gradients are collected before the decoder chain starts: they leave with its first flush)
+        add_t("image_reconstructor.layers.fc0.weight", F, H, 0);
+        add_t("image_reconstructor.layers.fc0.bias", F, 0, 0);
+        add_t("image_reconstructor.layers.fc1.weight", H, F, 0);
+        add_t("image_reconstructor.layers.fc1.bias", H, 0, 0);
         add_ln("decoder.decoder.layer_norm", 0);
+        dec_flush.assign(L, -1);
         for (int l = L - 1; l >= 0; --l) {
             const std::string lp = "decoder.decoder.dec." + std::to_string(l) + ".";
             add_mha(lp + "multi_head_attention_dec.", 0);
@@ -295,13 +348,11 @@ struct bltvqg_engine {
             add_ln(lp + "layer_norm_mha_dec", 0);
             add_ln(lp + "layer_norm_mha_enc", 0);
             add_ln(lp + "layer_norm_ffn", 0);
+            if (l > 0 && (tsize - bucket_start) * 4 >= BUCKET_TARGET_BYTES) dec_flush[l] = close_bucket(0);
         }
-        bucket_off[0] = 0; bucket_len[0] = tsize; bucket_late[0] = 0;
-        add_t("image_reconstructor.layers.fc0.weight", F, H, 0);
-        add_t("image_reconstructor.layers.fc0.bias", F, 0, 0);
-        add_t("image_reconstructor.layers.fc1.weight", H, F, 0);
-        add_t("image_reconstructor.layers.fc1.bias", H, 0, 0);
-        add_enc_stack("answer_encoder.encoder", 0);
+        const int t_dec_last = close_bucket(0);
+        add_enc_stack("answer_encoder.encoder", 0, enc_flush);
+        const int t_enc_last = close_bucket(0);
         add_t("embedding.1.weight", H, E, 0);
         add_t("embedding.1.bias", H, 0, 0);
         add_t("embedding.0.weight", V, E, 0);
@@ -310,7 +361,7 @@ struct bltvqg_engine {
         if (region_attn) add_t("encoder_cnn.region_attn.weight", 1, H, 0);
         add_t("encoder_cnn.bn.weight", H, 0, 0);
         add_t("encoder_cnn.bn.bias", H, 0, 0);
-        bucket_off[1] = bucket_len[0]; bucket_len[1] = tsize - bucket_len[0]; bucket_late[1] = 0;
+        const int t_tail = close_bucket(0);
         late_off = tsize;
         add_t("decoder.z_classifier.weight", V, H, 1);
         add_t("decoder.z_classifier.bias", V, 0, 1);
@@ -326,8 +377,29 @@ struct bltvqg_engine {
             add_t(std::string(nets[n]) + ".6.weight", 2 * Z, 2 * Z, 1);
             add_t(std::string(nets[n]) + ".6.bias", 2 * Z, 0, 1);
         }
-        add_enc_stack("answer_encoder.r_encoder", 1);
-        bucket_off[2] = late_off; bucket_len[2] = tsize - late_off; bucket_late[2] = 1;
+        const int t_late0 = close_bucket(1);
+        add_enc_stack("answer_encoder.r_encoder", 1, renc_flush);
+        const int t_renc_last = close_bucket(1);
+        // completion order: the decoder's groups, the latent-phase heads (final with the decoder's last flush), the two encoder stacks'
+        // in-stack groups (the context encoder's first: 5 tokens per sample against 21), their last groups, the tail (embedding, CNN head)
+        {
+            std::vector<int> order, remap(tmp_buckets.size(), -1);
+            for (int l = L - 1; l >= 0; --l) if (dec_flush[l] >= 0) order.push_back(dec_flush[l]);
+            order.push_back(t_dec_last); order.push_back(t_late0);
+            for (int l = L - 1; l >= 0; --l) {
+                if (enc_flush[l] >= 0) order.push_back(enc_flush[l]);
+                if (renc_flush[l] >= 0) order.push_back(renc_flush[l]);
+            }
+            order.push_back(t_enc_last); order.push_back(t_renc_last); order.push_back(t_tail);
+            for (size_t i = 0; i < order.size(); ++i) { remap[order[i]] = (int)i; buckets.push_back(tmp_buckets[order[i]]); }
+            for (int l = 0; l < L; ++l) {
+                if (dec_flush[l] >= 0) dec_flush[l] = remap[dec_flush[l]];
+                if (enc_flush[l] >= 0) enc_flush[l] = remap[enc_flush[l]];
+                if (renc_flush[l] >= 0) renc_flush[l] = remap[renc_flush[l]];
+            }
+            bk_dec_last = remap[t_dec_last]; bk_late0 = remap[t_late0]; bk_enc_last = remap[t_enc_last]; bk_renc_last = remap[t_renc_last];
+            bk_tail = remap[t_tail];
+        }
 
         // ---- transposed-shadow table: every weight that appears as the B operand of an input-gradient GEMM ----
         auto ends_with = [](const std::string& a, const char* suf) { const size_t n = strlen(suf); return a.size() >= n && a.compare(a.size() - n, n, suf) == 0; };
@@ -446,7 +518,9 @@ struct bltvqg_engine {
             xr = AT(BR * FD); Pr = AT(BR * H); dPr = AT(BR * H);
             ralpha = AF(BR);
         }
-        pooled = AF((int64_t)B * FD);
+        pooled_buf[0] = AF((int64_t)B * FD);
+        pooled_buf[1] = regions ? pooled_buf[0] : AF((int64_t)B * FD);
+        pooled = pooled_buf[pool_cur];
         featpre = AF((int64_t)B * H); feats32 = AF((int64_t)B * H); dfeats32 = AF((int64_t)B * H); dfeatpre32 = AF((int64_t)B * H);
         feats = AT((int64_t)B * H);
         bn1_mean = AF(H); bn1_rstd = AF(H);
@@ -601,8 +675,20 @@ struct bltvqg_engine {
     int flush_idx = 0;
     char* wg_pool = nullptr;
     static constexpr int WG_SLOTS = 24, WG_SLOT_BYTES = 16384;
-    int flush_wgrads(hipStream_t from, hipStream_t to, hipEvent_t ev) {
-        if (pending_wgrads.empty() && pending_ln.empty()) return BLT_OK;
+    // bucket >= 0: this flush makes that gradient bucket final — its event is recorded on `to` right behind the last launch
+    int flush_wgrads(hipStream_t from, hipStream_t to, hipEvent_t ev, int bucket = -1, int bucket2 = -1) {
+        const int rc0 = flush_wgrads_(from, to, ev);
+        if (rc0) return rc0;
+        const int bk[2] = {bucket, bucket2};
+        for (int k = 0; k < 2; ++k)
+            if (bk[k] >= 0 && bk[k] < (int)buckets.size() && buckets[bk[k]].ev && hipEventRecord(buckets[bk[k]].ev, to) != hipSuccess) {
+                blt_set_error("flush_wgrads: bucket event record failed");
+                return BLT_ERR_HIP;
+            }
+        return BLT_OK;
+    }
+    int flush_wgrads_(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+        if (pending_wgrads.empty() && pending_ln.empty()) return fork(from, to, ev);      // (the bucket event must still order behind `from`)
         int rc = fork(from, to, ev);
         bool grouped = dt == BLT_BF16 && !pending_wgrads.empty() && blt_debug_get(11) != 1 && flush_idx < WG_SLOTS && wg_pool != nullptr &&
                        pending_wgrads.size() * sizeof(blt_wg_problem) + (pending_wgrads.size() + 1) * 4 + 64 <= (size_t)WG_SLOT_BYTES;
@@ -627,8 +713,12 @@ struct bltvqg_engine {
             double fl = 0.0;
             for (const GemmArgs& g : pending_wgrads) fl += 2.0 * (double)g.M * (double)g.N * (double)g.K;
             const int pi = (prof_mask & 2) ? prof_begin(1, to) : -1;
-            // debug key 14: timing ablation only (weight gradients are NOT computed) — bounds what the side-stream launches cost the chain
-            if (blt_debug_get(14) != 1) rc = blt_wgrad_group_launch((const blt_wg_problem*)dev, (const int*)(dev + pb_al), (int)t.probs.size(), nwg, bm, to);
+#ifdef BLT_ABLATE
+            // debug key 14 (ablation build only): weight gradients are NOT computed — bounds what the side-stream launches cost the chain
+            if (blt_debug_get(14) == 1) fl = 0.0;
+            else
+#endif
+            rc = blt_wgrad_group_launch((const blt_wg_problem*)dev, (const int*)(dev + pb_al), (int)t.probs.size(), nwg, bm, to);
             prof_end(pi, to, fl);
             ++flush_idx;
         } else {
@@ -903,49 +993,101 @@ struct bltvqg_engine {
             RC(blt_avgpool(BLT_F32, images, pooled, B, c.num_regions, FD, 1, s));
             return cnn_head_fwd(s);
         }
+        // a batch whose conv stack ran ahead (prefetch_images): wait for its pooled feature, start at the trainable head
+        if (pf_n > 0) {
+            BLT_REQUIRE(images == nullptr, "engine_forward: a prefetched batch is pending, pass images = NULL (its images were given to prefetch_images)");
+            const int slot = pf_head;
+            if (hipStreamWaitEvent(s, cnn_done[slot], 0) != hipSuccess) { blt_set_error("engine_forward: prefetch wait failed"); return BLT_ERR_HIP; }
+            pool_cur = slot; pooled = pooled_buf[slot];
+            pf_head ^= 1; --pf_n;
+            pool_in_use = true;
+            // the stages the prefetch left (bltvqg_engine_set_prefetch_split) run here, behind the prefetched ones
+            if (pf_split[slot] < CNN_STAGES) RC(cnn_convs(nullptr, s, pooled, pf_split[slot], CNN_STAGES));
+            RC(sync_opt(s));
+            return cnn_head_fwd(s);
+        }
+        // inline: the conv buffers are shared with the prefetch stream, so order behind whatever it still runs
+        if (cnn_stream_used && hipStreamWaitEvent(s, cnn_done[last_cnn_slot], 0) != hipSuccess) { blt_set_error("engine_forward: conv-stream wait failed"); return BLT_ERR_HIP; }
+        RC(cnn_convs(images, s, pooled));
+        // Head in fp32 (exact-fp32 MFMA on the fp32 master weights): BatchNorm1d removes the common mode of the pooled feature
+        // across the batch, so bf16 rounding of these tiny [B,512]/[B,H] tensors would be amplified into the image feature.
+        RC(sync_opt(s));      // the head (fc + BatchNorm1d) is trainable: behind a pending asynchronous optimiser update
+        return cnn_head_fwd(s);
+    }
+
+    // the frozen part of EncoderCNN.forward (encoder_cnn.py:33 minus the fc) as 10 stages: [0] image pack -> stem + BatchNorm + ReLU +
+    // max-pool, [1..8] the eight BasicBlocks, [9] global average pool into `pooled_out` [B,512] fp32.  Runs stages [from, to).  Touches no
+    // trainable parameter.
+    static constexpr int CNN_STAGES = 10;
+    int cnn_convs(const float* images, hipStream_t s, float* pooled_out, int from = 0, int to = CNN_STAGES) {
         if (frozen_dirty) {
             for (auto& cs : convs)
                 RC(blt_conv_pack_w(dt, FZ(cs.wname), cs.wpacked, cs.Cout, cs.Cin, cs.K, cs.K, cs.CinPad, cs.Cin < 8 ? 8 : cs.K, s));
             frozen_dirty = false;
         }
-        if (blt_debug_get(15) == 1) return cnn_head_fwd(s);      // timing ablation only: the conv stack is skipped, `pooled` keeps the last step's features
-        if (images) RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 4, 3, 3, imgHp, imgWp, s));      // NULL: the caller filled `img`
+#ifdef BLT_ABLATE
+        if (blt_debug_get(15) == 1) return BLT_OK;      // timing ablation only: the conv stack is skipped, `pooled` keeps the last step's features
+#endif
         size_t ci = 0;
         ConvSpec& c1 = convs[ci++];
-        RC(conv_fwd(c1, img, s));
-        if (stem_pooled()) RC(blt_bn_apply_pp(dt, pool0, c1.scale, c1.shift, nullptr, nullptr, nullptr, pool0, B, c1.Ho / 2, c1.Wo / 2, 64, 1, s));
-        else RC(blt_bn_relu_maxpool_pp(dt, c1.out, c1.scale, c1.shift, pool0, B, c1.Ho, c1.Wo, 64, s));
+        if (from <= 0 && to > 0) {
+            if (images) RC(blt_img_pack(dt, images, img, B, 3, c.image_h, c.image_w, 4, 3, 3, imgHp, imgWp, s));      // NULL: the caller filled `img`
+            RC(conv_fwd(c1, img, s));
+            if (stem_pooled()) RC(blt_bn_apply_pp(dt, pool0, c1.scale, c1.shift, nullptr, nullptr, nullptr, pool0, B, c1.Ho / 2, c1.Wo / 2, 64, 1, s));
+            else RC(blt_bn_relu_maxpool_pp(dt, c1.out, c1.scale, c1.shift, pool0, B, c1.Ho, c1.Wo, 64, s));
+        }
         const void* x = pool0;
         int cin = 64;
         const int couts[4] = {64, 128, 256, 512};
         for (int li = 0; li < 4; ++li)
             for (int b = 0; b < 2; ++b) {
+                const int stage = 1 + li * 2 + b;
                 const int cout = couts[li];
                 const int st = (li > 0 && b == 0) ? 2 : 1;
                 ConvSpec& ca = convs[ci++];
                 ConvSpec& cb = convs[ci++];
-                RC(conv_fwd(ca, x, s));
-                // bn1 + ReLU: inside conv2's patch staging when conv2 is the LDS-patch kernel (debug key 17 = 1: the separate pass)
-                const bool fuse_bn1 = conv_is_direct(cb) && blt_debug_get(17) != 1;
-                if (!fuse_bn1) RC(bn_act(ca, nullptr, nullptr, 1, s));
-                RC(conv_fwd(cb, ca.out, s, fuse_bn1 ? &ca : nullptr));
-                const void* res = x;
-                const ConvSpec* res_bn = nullptr;
-                if (st != 1 || cin != cout) {      // downsample branch: its BatchNorm is applied inside the block's final BN + add + ReLU pass
-                    ConvSpec& cd = convs[ci++];
-                    RC(conv_fwd(cd, x, s));
-                    res = cd.out;
-                    res_bn = &cd;
+                ConvSpec* cd = (st != 1 || cin != cout) ? &convs[ci++] : nullptr;
+                if (stage >= from && stage < to) {
+                    RC(conv_fwd(ca, x, s));
+                    // bn1 + ReLU: inside conv2's patch staging when conv2 is the LDS-patch kernel (debug key 17 = 1: the separate pass)
+                    const bool fuse_bn1 = conv_is_direct(cb) && blt_debug_get(17) != 1;
+                    if (!fuse_bn1) RC(bn_act(ca, nullptr, nullptr, 1, s));
+                    RC(conv_fwd(cb, ca.out, s, fuse_bn1 ? &ca : nullptr));
+                    const void* res = x;
+                    if (cd) {      // downsample branch: its BatchNorm is applied inside the block's final BN + add + ReLU pass
+                        RC(conv_fwd(*cd, x, s));
+                        res = cd->out;
+                    }
+                    RC(bn_act(cb, res, cd, 1, s));
                 }
-                RC(bn_act(cb, res, res_bn, 1, s));
                 x = cb.out;
                 cin = cout;
             }
-        // Head in fp32 (exact-fp32 MFMA on the fp32 master weights): BatchNorm1d removes the common mode of the pooled feature
-        // across the batch, so bf16 rounding of these tiny [B,512]/[B,H] tensors would be amplified into the image feature.
-        RC(sync_opt(s));      // the head (fc + BatchNorm1d) is trainable: behind a pending asynchronous optimiser update
-        RC(blt_avgpool_pp(dt, x, pooled, B, convs.back().Ho, convs.back().Wo, 512, 1, s));
-        return cnn_head_fwd(s);
+        if (to >= CNN_STAGES && from < CNN_STAGES) return blt_avgpool_pp(dt, x, pooled_out, B, convs.back().Ho, convs.back().Wo, 512, 1, s);
+        return BLT_OK;
+    }
+
+    // Enqueues the conv stack of the NEXT batch on the engine's conv stream, ordered behind everything enqueued on `sin` so far (the
+    // producer of `images`; and, when the slot it fills is the one the previous step read, that step's backward).
+    int prefetch_images(const float* images, hipStream_t sin) {
+        BLT_REQUIRE(bound && !regions, "engine_prefetch_images: engine not bound / region mode has no conv stack");
+        BLT_REQUIRE(bn_train, "engine_prefetch_images: train-mode BatchNorm only (eval engines run the stack inline)");
+        BLT_REQUIRE(pf_n < 2, "engine_prefetch_images: two prefetched batches are already pending");
+        // a PARTIAL stack leaves its intermediate activation in the (single-buffered) conv workspace until the forward that finishes it
+        BLT_REQUIRE(pf_n == 0 || (prefetch_split >= CNN_STAGES && pf_split[pf_head] >= CNN_STAGES),
+                    "engine_prefetch_images: with a partial prefetch (set_prefetch_split) only one batch may be pending");
+        // the slot to fill: behind the pending one if there is one, else the one the current step does not read
+        const int slot = pf_n > 0 ? (pf_head ^ 1) : (pool_cur ^ 1);
+        BLT_REQUIRE(!(slot == pool_cur && pool_in_use), "engine_prefetch_images: the slot to fill is still read by the current step: enqueue its backward first");
+        if (!cnn_stream) RC(make_stream(&cnn_stream, 2));
+        RC(fork(sin, cnn_stream, cnn_in_ev));
+        RC(cnn_convs(images, cnn_stream, pooled_buf[slot], 0, prefetch_split));
+        pf_split[slot] = prefetch_split;
+        if (hipEventRecord(cnn_done[slot], cnn_stream) != hipSuccess) { blt_set_error("engine_prefetch_images: event record failed"); return BLT_ERR_HIP; }
+        if (pf_n == 0) pf_head = slot;
+        ++pf_n;
+        cnn_stream_used = true; last_cnn_slot = slot;
+        return BLT_OK;
     }
 
     int cnn_head_fwd(hipStream_t s) {
@@ -1001,8 +1143,8 @@ struct bltvqg_engine {
         phase2 = p2; seed = seed_; fwd_done = false;
         stamp(0, s);
         // with an optimiser update still in flight only the streams that read trainable parameters wait for it (below)
-        const bool overlap_opt = opt_pending && use_streams;
-        if (opt_pending && !overlap_opt) { RC(sync_opt(s)); opt_pending = false; }
+        const bool overlap_opt = opt_is_pending() && use_streams;
+        if (opt_is_pending() && !overlap_opt) { RC(sync_opt(s)); opt_mark_synced(); }
         // loss statistics [0..3]; [4] (gradient norm) belongs to the optimiser, which may still be reading it
         if (hipMemsetAsync(stats - 1, 0, 5 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
         if (overlap_opt) {
@@ -1019,7 +1161,7 @@ struct bltvqg_engine {
             RC(stack_fwd(renc, nullptr, nullptr, s0));
             RC(fork(s0, s, fj[2]));
             RC(fork(side[1], s, fj[3]));
-            opt_pending = false;          // s is now ordered behind the update
+            opt_mark_synced();            // s is now ordered behind the update
             return forward_tail(eps, s);
         }
         // weight shadows
@@ -1132,7 +1274,7 @@ struct bltvqg_engine {
         BLT_REQUIRE((images || !regions) && ctx && tokens && top_idx && top_val, "engine_decode_greedy: null pointer");
         BLT_REQUIRE(!p2 || eps, "engine_decode_greedy: eps required when the latent path is on");
         BLT_REQUIRE(c.attention_dropout == 0.f && c.relu_dropout == 0.f, "engine_decode_greedy: create the decode engine with dropout 0");
-        if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
+        if (opt_is_pending()) { RC(sync_opt(s)); opt_mark_synced(); }
         phase2 = p2; seed = 0; fwd_done = false;
         const bool saved_bn = bn_train, saved_streams = use_streams;
         bn_train = train_bn != 0; use_streams = false; causal_mode = 2;
@@ -1201,7 +1343,7 @@ struct bltvqg_engine {
     // `dx` holds d(stack output before the final LayerNorm) on entry and d(stack input) on exit; the gradients in between live in the
     // layers' own buffers (Layer::dx1..3)
     float relu_ks() const { return (c.relu_dropout > 0.f) ? 1.f / (1.f - c.relu_dropout) : 1.f; }
-    int stack_bwd(Stack& st, void* dx, const void* enc_out, const int* src_ids, hipStream_t s) {
+    int stack_bwd(Stack& st, void* dx, const void* enc_out, const int* src_ids, hipStream_t s, const std::vector<int>* flush_plan = nullptr) {
         const int M = st.M, S = st.S;
         void *gA = sA[st.scr], *gB = sB[st.scr], *gC = sC[st.scr];
         const void* cur = dx;
@@ -1258,10 +1400,10 @@ struct bltvqg_engine {
             void* ngY = (l > 0) ? st.layers[l - 1].gY : nullptr;
             RC(ln_bwd(gB, x, ln1, y.m1, y.r1, cur, out, M, s, nmask, relu_ks(), ngY));
             cur = out;
-            // debug key 11 = N >= 2: hand the collected weight gradients to the side stream every N layers instead of once per stack, so
-            // that they run under the rest of THIS chain rather than under the next one (A/B switch)
-            const int every = blt_debug_get(11);
-            if (defer_wgrads && every >= 2 && l > 0 && ((L - l) % (every - 1)) == 0) RC(flush_wgrads(s, side[1], fj[6]));
+            // in-stack flush points (build_params: groups of whole layers of >= ~32 MB of parameters): the collected weight gradients go
+            // to the weight-gradient stream now, run under the rest of THIS chain and close a gradient bucket, whose all-reduce (N > 1)
+            // can start while backward is still running.  debug key 11 = 1: off (one flush per stack, the round-2 form: A/B switch)
+            if (defer_wgrads && flush_plan && (*flush_plan)[l] >= 0 && blt_debug_get(11) != 1) RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
         }
         return BLT_OK;
     }
@@ -1323,7 +1465,7 @@ struct bltvqg_engine {
                       dec.layers[L - 1].gY));
         }
         stamp(6, s);           // vocabulary input gradient + final LayerNorm backward done
-        RC(stack_bwd(dec, dxT, enc.out, ctx32, s));
+        RC(stack_bwd(dec, dxT, enc.out, ctx32, s, &dec_flush));
         stamp(7, s);
         if (sbr != s && hipStreamWaitEvent(s, fj[12], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
         // target_embedding[:,0] += image_features (+ z); r_in = encoder row 0 (+ z); zc_in = z + image_features
@@ -1346,8 +1488,7 @@ struct bltvqg_engine {
         // section: its dozen [B, *]-sized launches sit on the critical path between the decoder chain and the two encoder chains, and
         // launched beside the grouped kernel they waited for its 40 us workgroups to free a CU one by one (0.55 ms instead of 0.1).  The
         // latent nets' own weight gradients ride in the same launch; bucket 0 (decoder.*) is complete when side[1] gets past it.
-        RC(flush_wgrads(s, side[1], fj[6]));
-        if (bucket_ev[0]) (void)hipEventRecord(bucket_ev[0], use_streams ? side[1] : s);
+        RC(flush_wgrads(s, use_streams ? side[1] : s, fj[6], bk_dec_last, phase2 ? bk_late0 : -1));
         // d(image feature) is final here, long before the encoder chains are: the CNN head's backward (BatchNorm1d -> fc) goes to the
         // weight-gradient stream now instead of closing the chain
         if (use_streams) { RC(fork(s, side[1], fj[13])); RC(cnn_head_bwd(side[1])); }
@@ -1362,11 +1503,11 @@ struct bltvqg_engine {
             const void* xL = renc.layers[L - 1].x2;
             RC(ln_bwd(d_renc, xL, "answer_encoder.r_encoder.layer_norm", renc.mF, renc.rF, nullptr, dxP, Mp, s0, renc.layers[L - 1].y2, relu_ks(),
                       renc.layers[L - 1].gY));
-            RC(stack_bwd(renc, dxP, nullptr, nullptr, s0));
+            RC(stack_bwd(renc, dxP, nullptr, nullptr, s0, &renc_flush));
             // the main stream will join s0 at THIS point (it needs the chain's result for the embedding backward); the posterior
             // encoder's weight gradients then run on s0 behind it, beside the context encoder's on side[1], and are joined at the very end
             if (s0 != s && hipEventRecord(fj[5], s0) != hipSuccess) { blt_set_error("backward: event record failed"); return BLT_ERR_HIP; }
-            RC(flush_wgrads(s0, s0 != s ? s0 : side[1], fj[7]));
+            RC(flush_wgrads(s0, s0 != s ? s0 : side[1], fj[7], bk_renc_last));
             Memb = Mtot;
         }
         // ---- context encoder (main stream) ----
@@ -1376,9 +1517,9 @@ struct bltvqg_engine {
                       enc.layers[L - 1].gY));
         }
         stamp(8, s);           // latent backward done, context-encoder backward starts (posterior encoder runs beside it)
-        RC(stack_bwd(enc, dX_all, nullptr, nullptr, s));
+        RC(stack_bwd(enc, dX_all, nullptr, nullptr, s, &enc_flush));
         stamp(9, s);
-        RC(flush_wgrads(s, side[1], fj[8]));
+        RC(flush_wgrads(s, use_streams ? side[1] : s, fj[8], bk_enc_last));
         defer_wgrads = false;
         if (s0 != s && hipStreamWaitEvent(s, fj[5], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
         // ---- shared embedding (rows of the streams that received gradient): weight + bias gradient to the side stream, the gradient of
@@ -1401,8 +1542,9 @@ struct bltvqg_engine {
             RC(fork(side[1], s, fj[9]));
             if (s0 != s) RC(fork(s0, s, fj[10]));
         }
-        if (bucket_ev[1]) (void)hipEventRecord(bucket_ev[1], s);
-        if (bucket_ev[2]) (void)hipEventRecord(bucket_ev[2], s);
+        // the tail bucket (embedding, CNN head) is final here; without side streams nothing was flushed in between: every bucket is
+        for (size_t k = 0; k < buckets.size(); ++k)
+            if (buckets[k].ev && ((int)k == bk_tail || !use_streams)) (void)hipEventRecord(buckets[k].ev, s);
         last_bwd_phase2 = phase2;
         stamp(10, s);          // every stream joined: end of backward
         return BLT_OK;
@@ -1419,7 +1561,7 @@ struct bltvqg_engine {
 
     int loss_backward(float kl_weight, hipStream_t s) {
         BLT_REQUIRE(bound && fwd_done, "engine_loss_backward: forward has not run");
-        if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
+        if (opt_is_pending()) { RC(sync_opt(s)); opt_mark_synced(); }
         RC(zero_grads(s));
         // train_iq.py:81-103.  The token cross-entropy (41 MB of logits) leads the decoder chain; the image-reconstruction MSE and the
         // bag-of-words CE only feed the branch stream's work (backward_core) and run there, beside it.
@@ -1433,13 +1575,14 @@ struct bltvqg_engine {
         }
         RC(blt_ce_fwd_bwd(dt, logits, ldV, tgt32, Mt, V, counters, 1.f, stats + 0, 1, s));
         stamp(5, s);           // loss kernels enqueued
+        pool_in_use = false;   // (the head's weight gradient, the last reader of the pooled slot, is enqueued by backward_core and joined into s)
         return backward_core(kld_g, s);
     }
 
     int backward_external(const float* d_output, const float* d_zlogit, float d_kld, const float* d_feats_in, const float* d_recon_in,
                           hipStream_t s) {
         BLT_REQUIRE(bound && fwd_done, "engine_backward_external: forward has not run");
-        if (opt_pending) { RC(sync_opt(s)); opt_pending = false; }
+        if (opt_is_pending()) { RC(sync_opt(s)); opt_mark_synced(); }
         RC(zero_grads(s));
         if (d_output) RC(blt_cast_rows(BLT_F32, d_output, V, dt, logits, ldV, Mt, V, s));
         else if (hipMemsetAsync(logits, 0, (size_t)Mt * ldV * es, s) != hipSuccess) return BLT_ERR_HIP;
@@ -1451,13 +1594,14 @@ struct bltvqg_engine {
             if (d_zlogit) RC(blt_cast_rows(BLT_F32, d_zlogit, V, dt, dzl, ldV, B, V, s));
             else if (hipMemsetAsync(dzl, 0, (size_t)B * ldV * es, s) != hipSuccess) return BLT_ERR_HIP;
         }
+        pool_in_use = false;
         return backward_core(d_kld, s);
     }
 
     // async_: run on the engine's optimiser stream behind `s_in` (see opt_stream); the next forward orders itself behind the update
     int optimizer_step(float lr, float max_norm, float b1, float b2, float eps, hipStream_t s_in, bool async_ = false) {
         BLT_REQUIRE(bound, "engine_optimizer_step: engine not bound");
-        if (opt_pending) { RC(sync_opt(s_in)); opt_pending = false; }
+        if (opt_is_pending()) { RC(sync_opt(s_in)); opt_mark_synced(); }
         hipStream_t s = s_in;
         if (async_) {
             RC(fork(s_in, opt_stream, opt_fork));
@@ -1467,7 +1611,8 @@ struct bltvqg_engine {
         if (rc_) return rc_;
         if (async_) {
             if (hipEventRecord(opt_done, opt_stream) != hipSuccess) { blt_set_error("engine_optimizer_step: event record failed"); return BLT_ERR_HIP; }
-            opt_pending = true;
+            ++steps->opt_gen;                 // every engine sharing these buffers (this one included) now has an update to wait for
+            steps->opt_done_ev = opt_done;
         }
         return BLT_OK;
     }
@@ -1520,12 +1665,22 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
 
 void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (!e) return;
-    for (int i = 0; i < 3; ++i) if (e->bucket_ev[i]) (void)hipEventDestroy(e->bucket_ev[i]);
+    for (auto& b : e->buckets) if (b.ev) (void)hipEventDestroy(b.ev);
     if (e->grad_zero_ev) (void)hipEventDestroy(e->grad_zero_ev);
     for (int i = 0; i < 16; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
     for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
+    if (e->cnn_stream) (void)hipStreamDestroy(e->cnn_stream);
+    if (e->chain_stream) (void)hipStreamDestroy(e->chain_stream);
+    if (e->cnn_in_ev) (void)hipEventDestroy(e->cnn_in_ev);
+    for (int i = 0; i < 2; ++i) if (e->cnn_done[i]) (void)hipEventDestroy(e->cnn_done[i]);
     if (e->opt_fork) (void)hipEventDestroy(e->opt_fork);
-    if (e->opt_done) (void)hipEventDestroy(e->opt_done);
+    if (e->opt_done) {
+        if (e->steps->opt_done_ev == e->opt_done) {      // an update of this engine may still be in flight for the engines sharing its state
+            (void)hipEventSynchronize(e->opt_done);
+            e->steps->opt_done_ev = nullptr;
+        }
+        (void)hipEventDestroy(e->opt_done);
+    }
     for (size_t i = 0; i < e->prof.size(); ++i) { (void)hipEventDestroy(e->prof[i].a); (void)hipEventDestroy(e->prof[i].b); }
     delete e;
 }
@@ -1585,8 +1740,8 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
         blt_set_error("engine_bind: event creation failed");
         return BLT_ERR_HIP;
     }
-    for (int i = 0; i < 3; ++i)
-        if (!e->bucket_ev[i] && hipEventCreateWithFlags(&e->bucket_ev[i], hipEventDisableTiming) != hipSuccess) {
+    for (auto& b : e->buckets)
+        if (!b.ev && hipEventCreateWithFlags(&b.ev, hipEventDisableTiming) != hipSuccess) {
             blt_set_error("engine_bind: event creation failed");
             return BLT_ERR_HIP;
         }
@@ -1597,17 +1752,21 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
         }
     for (int i = 0; i < 2; ++i)
         // (stream priorities were measured — either side stream lowest or highest: +-1 %, the dispatcher does not preempt resident workgroups)
-        if (!e->side[i] && hipStreamCreateWithFlags(&e->side[i], hipStreamNonBlocking) != hipSuccess) {
-            blt_set_error("engine_bind: stream creation failed");
+        if (!e->side[i]) { const int rc_ = e->make_stream(&e->side[i], i); if (rc_) return rc_; }
+    e->opt_stream = e->side[1];
+    if (!e->cnn_in_ev && hipEventCreateWithFlags(&e->cnn_in_ev, hipEventDisableTiming) != hipSuccess) { blt_set_error("engine_bind: event creation failed"); return BLT_ERR_HIP; }
+    for (int i = 0; i < 2; ++i)
+        if (!e->cnn_done[i] && hipEventCreateWithFlags(&e->cnn_done[i], hipEventDisableTiming) != hipSuccess) {
+            blt_set_error("engine_bind: event creation failed");
             return BLT_ERR_HIP;
         }
-    e->opt_stream = e->side[1];
+    e->pf_n = 0; e->pool_in_use = false;
     if ((!e->opt_fork && hipEventCreateWithFlags(&e->opt_fork, hipEventDisableTiming) != hipSuccess) ||
         (!e->opt_done && hipEventCreateWithFlags(&e->opt_done, hipEventDisableTiming) != hipSuccess)) {
         blt_set_error("engine_bind: event creation failed");
         return BLT_ERR_HIP;
     }
-    e->bound = true; e->frozen_dirty = true; e->fwd_done = false; e->opt_pending = false;
+    e->bound = true; e->frozen_dirty = true; e->fwd_done = false; e->opt_mark_synced();
     return BLT_OK;
 }
 
@@ -1615,6 +1774,9 @@ void bltvqg_engine_invalidate_frozen(bltvqg_engine* e) {
     if (!e) return;
     e->frozen_dirty = true;
     ++e->steps->params_gen;        // parameters were (re)written from outside: every engine sharing them rebuilds its weight shadows
+}
+void bltvqg_engine_invalidate_params(bltvqg_engine* e) {
+    if (e) ++e->steps->params_gen;      // trainable parameters may have been written from outside (a torch optimiser): no shadow is current
 }
 int bltvqg_engine_trust_shadows(bltvqg_engine* e, int on) {
     BLT_REQUIRE(e, "engine_trust_shadows: null engine");
@@ -1626,6 +1788,62 @@ int bltvqg_engine_forward(bltvqg_engine* e, const float* images, const int64_t* 
                           const float* eps, int phase2, uint64_t seed, void* stream) {
     BLT_REQUIRE(e, "engine_forward: null engine");
     return e->forward(images, context, posterior, target, eps, phase2, seed, (hipStream_t)stream);
+}
+
+int bltvqg_engine_prefetch_images(bltvqg_engine* e, const float* images, void* stream) {
+    BLT_REQUIRE(e, "engine_prefetch_images: null engine");
+    return e->prefetch_images(images, (hipStream_t)stream);
+}
+int bltvqg_engine_prefetch_pending(const bltvqg_engine* e) { return e ? e->pf_n : 0; }
+int bltvqg_engine_set_prefetch_split(bltvqg_engine* e, int stages) {
+    BLT_REQUIRE(e && stages >= 1 && stages <= bltvqg_engine::CNN_STAGES, "engine_set_prefetch_split: stages must be 1..10");
+    BLT_REQUIRE(e->pf_n == 0, "engine_set_prefetch_split: a prefetched batch is pending");
+    e->prefetch_split = stages;
+    return BLT_OK;
+}
+
+int bltvqg_engine_set_cu_masks(bltvqg_engine* e, const uint32_t* chain_mask_host, const uint32_t* side_mask_host, const uint32_t* conv_mask_host,
+                               int words, int chain_cus) {
+    BLT_REQUIRE(e && words >= 1 && words <= 8 && chain_cus >= 0 && chain_cus <= 1024, "engine_set_cu_masks: bad args");
+    BLT_REQUIRE(e->pf_n == 0 && !e->opt_is_pending(), "engine_set_cu_masks: a prefetched batch or an optimiser update is pending");
+    const uint32_t* src[3] = {chain_mask_host, side_mask_host, conv_mask_host};
+    e->have_masks = false;
+    for (int k = 0; k < 3; ++k) {
+        e->cu_mask_on[k] = src[k] != nullptr;
+        for (int w = 0; w < 8; ++w) e->cu_masks[k][w] = (src[k] && w < words) ? src[k][w] : 0u;
+        if (src[k]) {
+            uint32_t any = 0;
+            for (int w = 0; w < words; ++w) any |= src[k][w];
+            BLT_REQUIRE(any != 0, "engine_set_cu_masks: empty mask %d", k);
+            e->have_masks = true;
+        }
+    }
+    // every stream the engine owns is recreated under its mask (the caller has synchronised: nothing of this engine is in flight)
+    if (hipDeviceSynchronize() != hipSuccess) { blt_set_error("engine_set_cu_masks: synchronize failed"); return BLT_ERR_HIP; }
+    for (int i = 0; i < 2; ++i) if (e->side[i]) { (void)hipStreamDestroy(e->side[i]); e->side[i] = nullptr; }
+    if (e->cnn_stream) { (void)hipStreamDestroy(e->cnn_stream); e->cnn_stream = nullptr; }
+    if (e->chain_stream) { (void)hipStreamDestroy(e->chain_stream); e->chain_stream = nullptr; }
+    if (e->bound) {
+        { const int rc_ = e->make_stream(&e->side[0], 0); if (rc_) return rc_; }
+        { const int rc_ = e->make_stream(&e->side[1], 1); if (rc_) return rc_; }
+        e->opt_stream = e->side[1];
+    }
+    e->cnn_stream_used = false;
+    blt_set_plan_cus(chain_cus > 0 ? chain_cus : 0);
+    return BLT_OK;
+}
+int bltvqg_engine_chain_stream(bltvqg_engine* e, void** stream) {
+    BLT_REQUIRE(e && stream, "engine_chain_stream: null argument");
+    if (!e->chain_stream) { const int rc_ = e->make_stream(&e->chain_stream, 0); if (rc_) return rc_; }
+    *stream = (void*)e->chain_stream;
+    return BLT_OK;
+}
+
+int bltvqg_engine_conv_stream(bltvqg_engine* e, void** stream) {
+    BLT_REQUIRE(e && stream, "engine_conv_stream: null argument");
+    if (!e->cnn_stream) { const int rc_ = e->make_stream(&e->cnn_stream, 2); if (rc_) return rc_; }
+    *stream = (void*)e->cnn_stream;
+    return BLT_OK;
 }
 
 int bltvqg_engine_image_input(bltvqg_engine* e, void** ptr, int* Hp, int* Wp, int* dtype) {
@@ -1681,20 +1899,22 @@ int bltvqg_engine_set_adam_steps(bltvqg_engine* e, int32_t steps_main, int32_t s
 int bltvqg_engine_share_optimizer_state(bltvqg_engine* e, bltvqg_engine* primary) {
     BLT_REQUIRE(e && primary && e->tsize == primary->tsize, "engine_share_optimizer_state: engines of different models");
     e->steps = primary->steps;
+    e->opt_seen = -1;      // unknown: wait for whatever update of the primary may be in flight before touching the shared buffers
+    if (e->steps->opt_gen == -1) e->opt_seen = -2;
     return BLT_OK;
 }
 int bltvqg_engine_optimizer_wait(bltvqg_engine* e, void* stream) {
     BLT_REQUIRE(e, "engine_optimizer_wait: null engine");
-    if (!e->opt_pending) return BLT_OK;
+    if (!e->opt_is_pending()) return BLT_OK;
     const int rc = e->sync_opt((hipStream_t)stream);
-    e->opt_pending = false;
+    e->opt_mark_synced();
     return rc;
 }
 
 int bltvqg_engine_read(bltvqg_engine* e, int what, float* dst, void* stream) {
     BLT_REQUIRE(e && e->bound && dst, "engine_read: bad args");
     hipStream_t s = (hipStream_t)stream;
-    if (e->opt_pending) { const int rc_ = e->sync_opt(s); if (rc_) return rc_; }     // stats[4] / parameters of a pending update
+    if (e->opt_is_pending()) { const int rc_ = e->sync_opt(s); if (rc_) return rc_; }     // stats[4] / parameters of a pending update
     switch (what) {
         case 0: return blt_cast_rows(e->dt, e->logits, e->ldV, BLT_F32, dst, e->V, e->Mt, e->V, s);
         case 1: return blt_cast_rows(e->dt, e->zlogit, e->ldV, BLT_F32, dst, e->V, e->B, e->V, s);
@@ -1762,17 +1982,17 @@ int bltvqg_engine_phase_stamps(bltvqg_engine* e, float* ms_host12) {
     return BLT_OK;
 }
 
-int bltvqg_engine_num_buckets(const bltvqg_engine* e) { return e ? 3 : 0; }
+int bltvqg_engine_num_buckets(const bltvqg_engine* e) { return e ? (int)e->buckets.size() : 0; }
 int bltvqg_engine_bucket_info(const bltvqg_engine* e, int i, int64_t* offset, int64_t* numel, int32_t* late) {
-    BLT_REQUIRE(e && i >= 0 && i < 3, "engine_bucket_info: bad args");
-    if (offset) *offset = e->bucket_off[i];
-    if (numel) *numel = e->bucket_len[i];
-    if (late) *late = e->bucket_late[i];
+    BLT_REQUIRE(e && i >= 0 && i < (int)e->buckets.size(), "engine_bucket_info: bad args");
+    if (offset) *offset = e->buckets[i].off;
+    if (numel) *numel = e->buckets[i].len;
+    if (late) *late = e->buckets[i].late;
     return BLT_OK;
 }
 int bltvqg_engine_bucket_wait(bltvqg_engine* e, int i, void* stream) {
-    BLT_REQUIRE(e && i >= 0 && i < 3 && e->bucket_ev[i], "engine_bucket_wait: bad args");
-    return hipStreamWaitEvent((hipStream_t)stream, e->bucket_ev[i], 0) == hipSuccess ? BLT_OK : BLT_ERR_HIP;
+    BLT_REQUIRE(e && i >= 0 && i < (int)e->buckets.size() && e->buckets[i].ev, "engine_bucket_wait: bad args");
+    return hipStreamWaitEvent((hipStream_t)stream, e->buckets[i].ev, 0) == hipSuccess ? BLT_OK : BLT_ERR_HIP;
 }
 
 }  // extern "C"

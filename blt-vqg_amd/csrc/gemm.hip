@@ -1036,13 +1036,13 @@ __global__ __launch_bounds__(256) void gemm_dma_lnA_kernel(const GemmArgs p) {
 
 int launch_dma_lnA(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = 4 * (64 * 128 + 64 * 128) + 2 * 256 * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static BltDevFlag attr_set;
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)gemm_dma_lnA_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             blt_set_error("gemm: hipFuncSetAttribute(%d) failed", LDS);
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     const long tiles = (long)cdiv(a.M, 64) * cdiv(a.N, 64);
     hipLaunchKernelGGL(gemm_dma_lnA_kernel, dim3((unsigned)tiles), dim3(256), LDS, stream, a);
@@ -1051,13 +1051,13 @@ int launch_dma_lnA(const GemmArgs& a, hipStream_t stream) {
 
 int launch_dma_ln(const GemmArgs& a, hipStream_t stream) {
     constexpr int LDS = 3 * (32 * 128 + 256 * 128);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static BltDevFlag attr_set;
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)gemm_dma_ln_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
             blt_set_error("gemm: hipFuncSetAttribute(%d) failed", LDS);
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     hipLaunchKernelGGL(gemm_dma_ln_kernel, dim3(cdiv(a.M, 32)), dim3(256), LDS, stream, a);
     return blt_check_launch("gemm_dma_ln");
@@ -1066,14 +1066,14 @@ int launch_dma_ln(const GemmArgs& a, hipStream_t stream) {
 template <int BM, int BN, int LOADER, int NST>
 int launch_dma(const GemmArgs& a, hipStream_t stream) {
     typedef DmaCfg<BM, BN, LOADER, NST> C;
-    static bool attr_set = false;
+    static BltDevFlag attr_set;
     auto kern = gemm_dma_kernel<BM, BN, LOADER, NST>;
-    if (!attr_set) {
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
             blt_set_error("gemm: hipFuncSetAttribute(%d) failed", C::LDS_BYTES);
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, 1), dim3(256), C::LDS_BYTES, stream, a);
@@ -1090,14 +1090,14 @@ int dispatch_dma(const GemmArgs& a, hipStream_t s) {
 template <typename T, int BM, int BN, bool TA, bool TB, int LOADER>
 int launch(const GemmArgs& a, int splits, hipStream_t stream) {
     typedef Cfg<T, BM, BN, TA, TB, LOADER> C;
-    static bool attr_set = false;
+    static BltDevFlag attr_set;
     auto kern = gemm_kernel<T, BM, BN, TA, TB, LOADER>;
-    if (!attr_set) {
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess) {
             blt_set_error("gemm: hipFuncSetAttribute(%d) failed", C::LDS_BYTES);
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     const long tiles = (long)cdiv(a.M, BM) * cdiv(a.N, BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles, (unsigned)splits), dim3(256), C::LDS_BYTES, stream, a);
@@ -1292,7 +1292,7 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
         return launch_dma_ln(a, stream);
     }
     if (!g_debug[8] && !a.force_tile && !a.no_dma && blt_gemm_nt2_ok(dtype, a))
-        return blt_gemm_nt2(a, stream, g_debug[9], g_debug[10]);
+        return blt_gemm_nt2(a, stream, a.nt2_bm ? a.nt2_bm : g_debug[9], a.nt2_bm ? a.nt2_bn : g_debug[10]);
     const int splits = blt_gemm_splits(a, dtype);
     if (g_debug[2] && splits == 1 && !a.accumulate && !a.force_tile && g_tuned.find(tune_key(a, dtype)) == g_tuned.end()) {
         int rc = autotune(dtype, a, stream);

@@ -321,14 +321,14 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
 
 template <typename C>
 int launch_nt2(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    static BltDevFlag attr_set;
     auto kern = gemm_nt2_kernel<C>;
-    if (!attr_set) {
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
             blt_set_error("gemm_nt2: hipFuncSetAttribute(%d) failed", C::LDS);
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     const long tiles = (long)cdiv(a.M, C::BM) * cdiv(a.N, C::BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(C::NT), C::LDS, s, a);
@@ -586,6 +586,9 @@ const TileOpt kTiles[] = {
     NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(160, 192, 2, 4), NT2(160, 256, 2, 4),
     NT2(192, 64, 4, 2),  NT2(192, 128, 2, 4), NT2(192, 192, 2, 4), NT2(192, 256, 2, 4),
     NT2(128, 256, 2, 4), NT2(256, 128, 4, 2), NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
+    // one-round tile of the 2048-column problems when the chain runs on a 192-CU partition (engine_set_cu_masks): 23 x 8 / 24 x 8 workgroups
+    // (239 VGPRs; 256 x 256 spills)
+    NT2(224, 256, 2, 4),
 };
 #undef NT2
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
@@ -594,15 +597,20 @@ constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 // Cost model of one launch (microseconds, relative): rounds of <= 256 one-per-CU workgroups x (K-steps x max(intake, MFMA) + a fixed
 // prologue / epilogue); intake = (BM + BN) * 128 B per K-step at ~70 GB/s per CU, MFMA = BM * BN * 64 * 2 flop at 9.8 TFLOP/s per CU.
+static int g_plan_cus = 256;
+void blt_set_plan_cus(int n) { g_plan_cus = (n > 0 && n <= 256) ? n : 256; }
+int blt_plan_cus() { return g_plan_cus; }
+
 int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn) {
     int best = -1;
     double best_cost = 1e30;
     const int nk = cdiv(K, 64);
+    const int cus = g_plan_cus;
     for (int i = 0; i < kNumTiles; ++i) {
         const TileOpt& t = kTiles[i];
         if (force_bm && (t.bm != force_bm || t.bn != force_bn)) continue;
         const long tiles = (long)cdiv(M, t.bm) * cdiv(N, t.bn);
-        const long rounds = (tiles + 255) / 256;
+        const long rounds = (tiles + cus - 1) / cus;
         const double intake = (t.bm + t.bn) * 128.0 / 70e3;                   // us per K-step
         const double mfma = (double)t.bm * t.bn * 128.0 / 9.8e6;               // us per K-step
         const double epi = 1.0 + (double)t.bm * t.bn / 40960.0 * 1.0;         // slab passes
@@ -612,7 +620,7 @@ int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn) {
     }
     // measured corrections of the model (scratch/mb_rep.py, un-profiled back-to-back launches on MI355X): at N ~ 1536 the 128 x 256
     // tile (240-252 workgroups, 64 x 64 per wave) beats the 160/192-row tiles the model prefers by 10-15 %
-    if (!force_bm && M >= 4096 && N > 1024 && N < 2048)
+    if (!force_bm && cus == 256 && M >= 4096 && N > 1024 && N < 2048)
         for (int i = 0; i < kNumTiles; ++i)
             if (kTiles[i].bm == 128 && kTiles[i].bn == 256) return i;
     return best;
@@ -681,14 +689,14 @@ int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_prob
 }
 template <typename C>
 static int launch_wg(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, hipStream_t s) {
-    static bool attr_set = false;
+    static BltDevFlag attr_set;
     auto kern = wgrad_group_kernel<C>;
-    if (!attr_set) {
+    if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
             blt_set_error("wgrad_group: hipFuncSetAttribute(%d) failed", C::LDS);
             return BLT_ERR_HIP;
         }
-        attr_set = true;
+        attr_set.set();
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(C::NT), C::LDS, s, probs_dev, wg0_dev, nprob);
     return blt_check_launch("wgrad_group");

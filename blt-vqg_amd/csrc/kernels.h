@@ -77,6 +77,7 @@ struct GemmArgs {
     float* ln_mean = nullptr;
     float* ln_rstd = nullptr;
     float ln_eps = 1e-5f;
+    int nt2_bm = 0, nt2_bn = 0;      // force a tile shape of the planned-tile kernel (bltvqg_gemm_ex)
 };
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
@@ -88,6 +89,10 @@ int blt_gemm_splits(const GemmArgs& a, int dtype);
 bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a);
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm = 0, int force_bn = 0);
 void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn);
+// CUs the launch planners size a "round" for: 256 (the chip) unless the dependent chain runs on a CU partition (engine_set_cu_masks)
+int blt_hw_id_probe(int* out, int n_wg, int spin_ticks, hipStream_t s);      // misc.hip
+void blt_set_plan_cus(int n);      // 0 = the whole chip
+int blt_plan_cus();
 // gemm2.hip: grouped weight gradients (one launch for a table of dW = dY^T X problems; GemmArgs in the transA/transB weight-gradient
 // form: A = dY [rows, lda], B = X [rows, ldb], C = dW fp32 [M = out features, ldc], K = rows, a_rowsum = bias gradient or null)
 struct blt_wg_problem {

@@ -1060,3 +1060,24 @@ int blt_region_attn_bwd(int dtype, const void* P, const float* w, const float* a
     else hipLaunchKernelGGL(region_attn_bwd_kernel<bf16>, dim3(B), dim3(256), 0, s, (const bf16*)P, w, alpha, dout, (bf16*)dP, dw, R, H);
     return blt_check_launch("region_attn_bwd");
 }
+
+// ---- hardware-id probe: which XCD / CU a stream's workgroups land on (tests of the CU partition, bltvqg_engine_set_cu_masks) ----
+namespace {
+__global__ void __launch_bounds__(64) hw_id_probe_kernel(int* __restrict__ out, int spin) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    // keep the workgroup resident for a while so that a launch of many workgroups spreads over every CU the stream may use
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (long long)spin) {}
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = (int)hw;
+        out[2 * blockIdx.x + 1] = (int)(xcc & 0xF);
+    }
+}
+}  // namespace
+int blt_hw_id_probe(int* out, int n_wg, int spin_ticks, hipStream_t s) {
+    BLT_REQUIRE(out && n_wg > 0 && n_wg <= 65536 && spin_ticks >= 0 && spin_ticks <= 10000000, "hw_id_probe: bad args");
+    hipLaunchKernelGGL(hw_id_probe_kernel, dim3((unsigned)n_wg), dim3(64), 0, s, out, spin_ticks);
+    return blt_check_launch("hw_id_probe");
+}

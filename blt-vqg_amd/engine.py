@@ -145,6 +145,57 @@ class StepEngine(object):
         check(self.lib.bltvqg_engine_forward(self.h, ptr(images), ptr(context), ptr(posterior), ptr(target), ptr(eps),
                                              1 if phase2 else 0, int(seed), stream_ptr()), "engine_forward")
 
+    def prefetch_images(self, images):
+        """Enqueue the frozen conv stack of the NEXT batch on the engine's conv stream (bltvqg_engine_prefetch_images); the next
+        forward() must then be called with images=None.  `images` None: the caller filled image_input() itself."""
+        c = self.cfg
+        if images is not None:
+            assert images.is_cuda and images.dtype == torch.float32 and images.is_contiguous()
+            assert tuple(images.shape) == (c.batch, 3, c.image_h, c.image_w), tuple(images.shape)
+        check(self.lib.bltvqg_engine_prefetch_images(self.h, ptr(images), stream_ptr()), "engine_prefetch_images")
+
+    def set_prefetch_split(self, stages):
+        """Leading stages (1..10) of the conv stack a prefetch runs ahead; 10 = all (bltvqg_engine_set_prefetch_split)."""
+        check(self.lib.bltvqg_engine_set_prefetch_split(self.h, int(stages)), "engine_set_prefetch_split")
+        self.prefetch_split = int(stages)
+
+    def prefetch_pending(self):
+        return int(self.lib.bltvqg_engine_prefetch_pending(self.h))
+
+    @staticmethod
+    def cu_mask(cus_per_xcd_lo, cus_per_xcd_hi, n_xcd=8, cus_per_xcd=32):
+        """CU mask words selecting CUs [lo, hi) of every XCD.  Bit i of a HIP CU mask addresses XCD i % n_xcd, CU i // n_xcd
+        (tests/test_partition_gpu.py checks this on the device with the hardware-id probe)."""
+        words = [0] * ((n_xcd * cus_per_xcd + 31) // 32)
+        for cu in range(cus_per_xcd_lo, cus_per_xcd_hi):
+            for x in range(n_xcd):
+                b = cu * n_xcd + x
+                words[b // 32] |= 1 << (b % 32)
+        return words
+
+    def set_cu_masks(self, chain=None, side=None, conv=None, chain_cus=0):
+        """Complementary CU partition of the engine's streams (bltvqg_engine_set_cu_masks): lists of 32-bit mask words or None."""
+        def arr(m):
+            return None if m is None else (ctypes.c_uint32 * 8)(*(list(m) + [0] * (8 - len(m))))
+        torch.cuda.synchronize(self.device)
+        a, b, c_ = arr(chain), arr(side), arr(conv)
+        check(self.lib.bltvqg_engine_set_cu_masks(self.h, a, b, c_, 8, int(chain_cus)), "engine_set_cu_masks")
+        self._chain_stream = None
+
+    def chain_stream(self):
+        """torch stream (engine-owned, under the chain CU mask) to run forward / loss_backward / optimizer_step on."""
+        if getattr(self, "_chain_stream", None) is None:
+            p = ctypes.c_void_p()
+            check(self.lib.bltvqg_engine_chain_stream(self.h, ctypes.byref(p)), "engine_chain_stream")
+            self._chain_stream = torch.cuda.ExternalStream(p.value, device=self.device)
+        return self._chain_stream
+
+    def conv_stream(self):
+        """The engine's prefetch stream as a torch stream (diagnostics only)."""
+        p = ctypes.c_void_p()
+        check(self.lib.bltvqg_engine_conv_stream(self.h, ctypes.byref(p)), "engine_conv_stream")
+        return torch.cuda.ExternalStream(p.value, device=self.device)
+
     def image_input(self):
         """(device pointer, Hp, Wp, dtype) of the engine's zero-bordered NHWC4 stem input (bltvqg_engine_image_input)."""
         p, hp, wp, dt = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -170,6 +221,11 @@ class StepEngine(object):
     def params_changed(self):
         """Call after writing flat_train / flat_frozen from outside the engine (a broadcast, an in-place edit)."""
         self.lib.bltvqg_engine_invalidate_frozen(self.h)
+
+    def params_touched(self):
+        """The trainable parameters may have changed outside the engine's own optimiser (a torch optimiser on the views): every bf16
+        weight shadow is rebuilt from fp32 on the next forward, whatever trust_shadows() says."""
+        self.lib.bltvqg_engine_invalidate_params(self.h)
 
     def set_bn_train(self, train):
         check(self.lib.bltvqg_engine_set_bn_train(self.h, 1 if train else 0), "engine_set_bn_train")

@@ -54,8 +54,12 @@ class _IQFunction(torch.autograd.Function):
         eng = model._engine_for(images, answers, response, target)
         phase2 = bool(model.latent_transformer)
         model._step_seed += 1
+        # autograd path: the nn.Parameters (views of the flat buffer) belong to whoever optimises them — a torch optimiser does not
+        # tell the engine when it writes them, so no bf16 weight shadow written by an earlier FUSED step may be trusted here
+        eng.params_touched()
         eng.forward(images.contiguous().float(), answers.contiguous(), response.contiguous(), target.contiguous(),
                     None if eps is None else eps.contiguous().float(), phase2, model._base_seed + model._step_seed)
+        eng.params_touched()      # ... nor may the shadow this forward just built outlive it: the caller's optimiser writes the parameters next
         # The engine keeps ONE set of saved activations per shape: stamp this forward so that backward can tell whether they are
         # still its own (a second forward of the same shape, or a second backward, would otherwise silently use the wrong ones)
         eng.generation = getattr(eng, "generation", 0) + 1

@@ -157,7 +157,7 @@ class TrainIQ(_Base):
             if not hasattr(self, "_dps"):
                 self._dps = {}
             if id(eng) not in self._dps:
-                self._dps[id(eng)] = DataParallelStep(eng, dist, broadcast=not self._dps)
+                self._dps[id(eng)] = DataParallelStep(eng, dist, broadcast=not self._dps, check_ids_every=100)
             self._dp = self._dps[id(eng)]
         if getattr(self, "_pending_adam", None) is not None:      # optimiser state of a loaded checkpoint (fused path)
             ad, self._pending_adam = self._pending_adam, None

@@ -2,9 +2,10 @@
 
 Data parallelism mirrors what `pl.Trainer(gpus=N)` gives the reference (train_iq.py:372-373: Lightning DDP = one process per
 GPU, gradient mean across ranks, BatchNorm statistics per replica), re-designed for xGMI: the engine writes gradients into ONE
-flat fp32 buffer laid out in backward-completion order, so the exchange is three large all-reduces (decoder | encoder+embedding+
-CNN head | phase-2-only parameters) issued on a side stream as soon as the engine's bucket events fire, overlapping the rest of
-backward; the optimiser step waits for the side stream.
+flat fp32 buffer laid out in backward-completion order and closes a bucket (a group of whole layers, >= ~32 MB) at every
+weight-gradient flush point, so the exchange is one all-reduce per bucket issued on a side stream as soon as the bucket's event
+fires, overlapping the rest of backward; only the last (embedding + CNN head, ~10 MB) is final with the end of backward.  The
+optimiser step waits for the side stream.
 """
 import math
 
@@ -69,23 +70,19 @@ def init_reference_style(eng, seed=0, resnet_state=None):
 
 
 def active_buckets(buckets, phase2):
-    """Gradient buckets that carry gradients in this phase: the phase-2-only bucket is skipped before the switch."""
+    """Gradient buckets that carry gradients in this phase: the phase-2-only buckets are skipped before the switch."""
     return [(i, off, n) for i, (off, n, late) in enumerate(buckets) if phase2 or not late]
 
 
 def comm_plan(buckets, phase2):
-    """The collectives of one step as (bucket ids to wait for, offset, count).  Bucket 0 (decoder) is final early and goes alone, under
-    the encoder backward; the remaining active buckets become final together at the end of backward and are adjacent in the flat
-    buffer, so they travel as ONE collective (each extra one costs a launch and a ring latency on the exposed tail)."""
-    act = active_buckets(buckets, phase2)
-    plan = [([act[0][0]], act[0][1], act[0][2])]
-    rest = act[1:]
-    if rest:
-        contiguous = all(rest[k][1] + rest[k][2] == rest[k + 1][1] for k in range(len(rest) - 1))
-        if contiguous:
-            plan.append(([b[0] for b in rest], rest[0][1], sum(b[2] for b in rest)))
-        else:
-            plan.extend(([b[0]], b[1], b[2]) for b in rest)
+    """The collectives of one step as (bucket ids to wait for, offset, count), in the order backward completes the buckets (the order the
+    engine lists them in).  One collective per bucket: the engine closes a bucket at every weight-gradient flush point — groups of whole
+    layers of >= ~32 MB — and records its event right behind the flush, so every collective but the last (embedding + CNN head, final
+    with the end of backward) is enqueued while backward is still running and none exceeds a few layers (25-32 MB buckets
+    launched as they become final).  Buckets that become final at the same flush AND are adjacent in the flat buffer travel together."""
+    plan = []
+    for i, off, n in active_buckets(buckets, phase2):
+        plan.append(([i], off, n))
     return plan
 
 
@@ -131,7 +128,7 @@ class DataParallelStep(object):
     forward(), loss_backward(), optimizer_step(), optimizer_wait() — tests/test_dp_gloo.py drives this class with a CPU stand-in over
     gloo).  On a CPU device there are no streams: the collectives run inline."""
 
-    def __init__(self, engine, dist=None, overlap_optimizer=False, broadcast=True, bf16_wire=False):
+    def __init__(self, engine, dist=None, overlap_optimizer=False, broadcast=True, bf16_wire=False, check_ids_every=0):
         self.e = engine
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
@@ -145,6 +142,13 @@ class DataParallelStep(object):
         self.wire = None
         if dist is not None and bf16_wire:
             self.wire = torch.empty(max(n for _, _, n in comm_plan(self.buckets, True)), dtype=torch.bfloat16, device=engine.flat_grad.device)
+        self.steps_run = 0
+        self._prefetched_ptr = None
+        # exposed communication: with measure_exposed on, every step records an event pair (end of backward on the step's stream, end of the
+        # last all-reduce on the communication stream); exposed_ms() = how long the optimiser had to wait for the exchange after backward
+        self.measure_exposed = False
+        self._exposed = []
+        self.check_ids_every = int(check_ids_every)      # every n-th step: raise if the batch held token ids outside the vocabulary
         if dist is not None and broadcast:
             # one-time parameter broadcast from rank 0 (DDP does the same at construction); engines of other batch shapes share these
             # buffers and must not repeat it
@@ -152,9 +156,6 @@ class DataParallelStep(object):
             dist.broadcast(engine.flat_frozen, 0)
             if hasattr(engine, "params_changed"):
                 engine.params_changed()
-        # this driver updates the parameters only through the engine's own optimiser: the update may keep the bf16 weight shadows current
-        if hasattr(engine, "trust_shadows"):
-            engine.trust_shadows(True)
 
     def _on_comm(self):
         import contextlib
@@ -170,12 +171,37 @@ class DataParallelStep(object):
         if not self.overlap_optimizer and self.comm is not None:
             torch.cuda.current_stream(e.device).wait_stream(self.comm)
 
-    def run(self, images, context, posterior, target, eps, phase2, seed, kl_weight, lr, max_norm=5.0):
+    def run(self, images, context, posterior, target, eps, phase2, seed, kl_weight, lr, max_norm=5.0, next_images=None):
+        """One training step.  `next_images` (image mode, optional): the NEXT step's image batch — its frozen conv stack is enqueued on the
+        engine's conv stream now (StepEngine.prefetch_images; models/encoder_cnn.py:18-19 freezes the backbone, so it depends on nothing
+        this step updates); the next run() then starts at the trainable head and must be given that same tensor (or images=None)."""
         e = self.e
-        e.forward(images, context, posterior, target, eps, phase2, rank_dropout_seed(seed, self.rank))
+        # this driver updates the parameters only through the engine's own optimiser, so the update may keep the bf16 weight shadows
+        # current; the promise is (re)made per step, and the autograd path (models.IQ.forward) withdraws it with params_touched()
+        if hasattr(e, "trust_shadows"):
+            e.trust_shadows(True)
+        pending = e.prefetch_pending() if hasattr(e, "prefetch_pending") else 0
+        if pending and images is not None and images.data_ptr() != self._prefetched_ptr:
+            raise RuntimeError("DataParallelStep.run: the engine holds the prefetched conv stack of another image batch than the one passed "
+                               "(pass the tensor that was given as next_images to the previous run, or images=None)")
+        if next_images is not None:
+            if pending == 0 and images is not None:      # cold start: this step's own stack goes through the same path
+                e.prefetch_images(images)
+                pending = 1
+            e.prefetch_images(next_images)
+            self._prefetched_ptr = next_images.data_ptr()
+        e.forward(None if pending else images, context, posterior, target, eps, phase2, rank_dropout_seed(seed, self.rank))
         e.loss_backward(kl_weight)
+        ev_a = None
+        if self.measure_exposed and self.comm is not None:      # end of backward on the step's stream (every engine stream is joined)
+            ev_a = torch.cuda.Event(enable_timing=True)
+            ev_a.record()
         if self.dist is not None:
             self.reduce_gradients(phase2)
+        if ev_a is not None:                                     # ... against the end of the last collective on the communication stream
+            ev_b = torch.cuda.Event(enable_timing=True)
+            ev_b.record(self.comm)
+            self._exposed.append((ev_a, ev_b))
         if self.dist is not None and self.overlap_optimizer:
             # the update is forked from the COMMUNICATION stream (behind the all-reduces); the main stream never waits for them, the
             # next forward's parameter consumers wait for the update
@@ -183,6 +209,21 @@ class DataParallelStep(object):
                 e.optimizer_step(lr, max_norm, overlap=True)
         else:
             e.optimizer_step(lr, max_norm, overlap=self.overlap_optimizer)
+        # token ids outside the vocabulary are counted on the device (they were treated as <pad>); reading the counter is a host sync, so
+        # the fused loop looks at it on a cadence instead of every step (the reference's embedding lookup raises at once)
+        self.steps_run += 1
+        if self.check_ids_every and self.steps_run % self.check_ids_every == 0 and hasattr(e, "stats"):
+            e.stats(check_ids=True)
+
+    def exposed_ms(self):
+        """Per measured step: milliseconds between the end of backward and the end of the last gradient all-reduce (0 when the exchange
+        finished first); synchronises.  Clears the record."""
+        out = []
+        for a, b in self._exposed:
+            b.synchronize()
+            out.append(max(0.0, a.elapsed_time(b)))
+        self._exposed = []
+        return out
 
     def finish(self):
         self.e.optimizer_wait()

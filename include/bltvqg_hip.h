@@ -38,6 +38,11 @@ int bltvqg_version(void);
 const char* bltvqg_last_error_string(void);
 /* tuning switches for A/B benchmarks: key 0 = disable the LDS-DMA GEMM ring (value 1), key 1 = force a GEMM tile (64/128/12864) */
 void bltvqg_debug_set(int key, int value);
+int bltvqg_debug_get(int key);      /* keys 0..23; bench.py echoes every non-zero key in its JSON line */
+/* 1 only in the ablation build (make -C blt-vqg_amd/csrc ablate -> libbltvqg_hip_ablate.so, -DBLT_ABLATE): there debug keys 14 (skip the
+ * grouped weight-gradient launches) and 15 (skip the conv stack) exist as TIMING ablations with wrong results.  The shipped library has
+ * no switch that skips work. */
+int bltvqg_build_has_ablations(void);
 
 /* ---------------- operator-level entry points ---------------- */
 
@@ -206,6 +211,9 @@ int bltvqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, co
 /* keep-mask (1 = keep) the kernels use for dropout site `stream_id`: element (r, c) has index r*ld_index + c */
 int bltvqg_dropout_mask(uint64_t seed, uint32_t stream_id, int64_t rows, int cols, int ld_index, float p, uint8_t* out,
                         void* stream);
+/* Diagnostic: n_workgroups one-wave workgroups each write {HW_REG_HW_ID, XCC id} to out[2 * workgroup] after spinning spin_ticks of the
+ * 100 MHz wall clock (so that they spread over every CU the stream may use): which CUs a (CU-masked) stream's work lands on. */
+int bltvqg_hw_id_probe(int32_t* out, int n_workgroups, int spin_ticks, void* stream);
 int bltvqg_cast(int dtype_src, const void* src, int ld_src, int dtype_dst, void* dst, int ld_dst, int64_t rows, int cols,
                 void* stream);
 
@@ -291,11 +299,43 @@ void bltvqg_engine_invalidate_frozen(bltvqg_engine* e);
  * bltvqg_engine_optimizer_step[_async] (and reports every other write with bltvqg_engine_invalidate_frozen) sets on = 1: the update
  * then writes the shadow in the same pass and forward only derives the transposed copies (saves a 0.5 GB pass per step). */
 int bltvqg_engine_trust_shadows(bltvqg_engine* e, int on);
+/* The TRAINABLE parameters may have been written from outside the engine (a torch optimiser stepping the nn.Parameter views, an in-place
+ * edit): no bf16 shadow of any engine sharing them is current any more.  Cheaper than bltvqg_engine_invalidate_frozen (the frozen conv
+ * weights are not repacked); the autograd path (models.IQ.forward) calls it before every forward. */
+void bltvqg_engine_invalidate_params(bltvqg_engine* e);
 
 /* The engine's stem input: zero-bordered NHWC4 [batch, *Hp, *Wp, 4] of *dtype inside the bound workspace, image at (3,3).  A caller
  * that fills it itself (bltvqg_batch_images_packed) passes images = NULL to bltvqg_engine_forward / decode_greedy, which then skip
  * bltvqg_img_pack.  Image mode only. */
 int bltvqg_engine_image_input(bltvqg_engine* e, void** ptr, int* Hp, int* Wp, int* dtype);
+
+/* The frozen conv stack one batch ahead.  models/encoder_cnn.py:18-19 freezes the ResNet-18 backbone, so the 20 convolutions (+ train-mode
+ * BatchNorm2d, average pool) of batch i+1 depend on nothing step i updates: this call enqueues them on the engine's own conv stream, ordered
+ * behind everything enqueued on `stream` so far (the producer of `images`), and the NEXT bltvqg_engine_forward — called with images = NULL —
+ * waits for the pooled feature and starts at the trainable head (fc + BatchNorm1d).  images fp32 NCHW [B,3,h,w], or NULL when the caller
+ * filled the stem input itself (bltvqg_engine_image_input).  Results are bit-identical to the inline forward: same kernels, same order of
+ * BatchNorm2d running-statistics updates (one in-order stream).  At most two batches may be pending; the second one may only be enqueued
+ * after the backward of the step that consumed the previous batch (the pooled feature is double-buffered).  Image mode, train-mode
+ * BatchNorm only.  bltvqg_engine_prefetch_pending: number of prefetched batches not yet consumed by a forward. */
+int bltvqg_engine_prefetch_images(bltvqg_engine* e, const float* images, void* stream);
+int bltvqg_engine_prefetch_pending(const bltvqg_engine* e);
+/* How much of the conv stack a prefetch runs: the stack is 10 stages — [0] image pack + 7x7/2 stem + BatchNorm + ReLU + max-pool (HBM-bound),
+ * [1..8] the eight BasicBlocks, [9] the average pool; `stages` = 1..10 leading stages go to the conv stream, the forward that consumes the
+ * batch runs the rest inline.  10 (default) = the whole stack.  With stages < 10 only ONE batch may be pending and prefetch_images must be
+ * called AFTER the forward of the current step (the partial result lives in the single-buffered conv workspace). */
+int bltvqg_engine_set_prefetch_split(bltvqg_engine* e, int stages);
+/* CU partition (MI355X: 256 CUs in 8 XCDs).  A prefetched conv stack and the dependent chain of the step want different things from a CU
+ * (convolution workgroups hold 2 x 80 KB of LDS for ~25 us each, the chain's launches are short and queue behind them when they share
+ * CUs), so the engine can create its streams under COMPLEMENTARY CU masks (hipExtStreamCreateWithCUMask; words x 32 bits, HOST arrays,
+ * NULL = unmasked): chain_mask for side stream 0 and the stream bltvqg_engine_chain_stream hands out (run forward / loss_backward on
+ * it), side_mask for side stream 1 (deferred weight gradients, asynchronous optimiser), conv_mask for the prefetch stream.  chain_cus =
+ * number of CUs the chain mask leaves (the launch planners size one round of workgroups for it; 0 = the whole chip).  Call while
+ * nothing of this engine is in flight (synchronises the device); the planner setting is process-wide (one process per GPU). */
+int bltvqg_engine_set_cu_masks(bltvqg_engine* e, const uint32_t* chain_mask_host, const uint32_t* side_mask_host, const uint32_t* conv_mask_host,
+                               int words, int chain_cus);
+int bltvqg_engine_chain_stream(bltvqg_engine* e, void** stream);
+/* the engine's prefetch (conv) stream, for diagnostics: which CUs its work lands on (bltvqg_hw_id_probe) */
+int bltvqg_engine_conv_stream(bltvqg_engine* e, void** stream);
 
 /* IQ.forward (iq.py:82-114).  images fp32 NCHW [B,3,h,w]; token tensors int64 like the reference batch; eps fp32 [B,Z]
  * (may be NULL in phase 1).  train_bn: BatchNorm in train mode (batch statistics + running-stat update), as the reference. */

@@ -284,3 +284,35 @@ def test_iq_forward_reports_out_of_range_ids():
     b["questions"][0, 2] = cfg.vocab_size + 3
     with pytest.raises(_lib.HipError, match="token id"):
         t(b)
+
+
+def test_fused_step_then_torch_optimizer_never_reads_a_stale_weight_shadow():
+    """the fused driver lets the engine's Adam keep the bf16 weight shadows current (trust_shadows); TrainIQ shares that engine
+    with the autograd path, whose parameters a TORCH optimiser updates without telling the engine.  After fused step -> autograd step +
+    torch Adam -> fused forward, the forward must see the torch optimiser's weights (bit-identical to a forced rebuild from fp32)."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    z, cfg, state, batch = load_golden("tiny")
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg, precision="bf16", num_pretraining_steps=0))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")
+    b = {k: v.cuda() for k, v in batch.items()}
+    t.fused_training_step(b)                              # engine Adam: writes the bf16 shadow itself, shadow generation == parameter generation
+    t.last_stats()
+    eng = t._last_engine
+    opt = torch.optim.Adam(t.parameters(), lr=5e-2)       # a step large enough to change every bf16 weight
+    output, z_logit, kld, recon = t(b)
+    loss = t.calculate_losses(output, recon, kld, z_logit, b["questions"])[0]
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+
+    def fused_forward():
+        eng.trust_shadows(True)                           # what DataParallelStep.run promises at the top of every fused step
+        eng.forward(b["images"], b["answers"], b["posteriors"], b["questions"], b["eps"], True, 77)
+        return eng.read(0).clone()
+    got = fused_forward()
+    eng.params_changed()                                  # forced rebuild of every shadow from the fp32 parameters
+    want = fused_forward()
+    assert torch.equal(got, want)
+    assert float((got - output.detach()).abs().max()) > 1e-3      # and the torch step really moved the model

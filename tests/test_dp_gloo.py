@@ -36,8 +36,14 @@ def _worker(rank, world, port, out):
         eng = StepEngine(cfg, "cpu")                       # host-side descriptor only: layout + buckets, no device memory
         buckets = eng.buckets()
         n = eng.train_size
-        assert sum(b[1] for b in buckets) == n and buckets[0][0] == 0 and buckets[2][2] == 1
-        assert buckets[2][0] == eng.late_offset
+        # buckets come in backward-COMPLETION order (decoder groups, latent-phase heads, encoder stacks, tail), not in address order;
+        # together they tile the flat buffer exactly once, the late ones tile the phase-2-only region
+        assert sum(b[1] for b in buckets) == n and buckets[0][0] == 0
+        pos = 0
+        for off, cnt, late in sorted(buckets):
+            assert off == pos and (late == 1) == (off >= eng.late_offset)
+            pos += cnt
+        assert pos == n and buckets[-1][2] == 0 and any(b[2] for b in buckets)
         res = {}
         for phase2 in (False, True):
             g = torch.full((n,), float(rank + 1)) + torch.arange(n, dtype=torch.float32) * 1e-3 * (rank + 1)
@@ -50,11 +56,10 @@ def _worker(rank, world, port, out):
                 assert torch.allclose(g[lo:], want[lo:], rtol=1e-6)
             else:   # untouched before the phase switch
                 assert torch.equal(g[lo:], torch.full((n - lo,), float(rank + 1)) + torch.arange(lo, n, dtype=torch.float32) * 1e-3 * (rank + 1))
-            # the step's actual collectives (DataParallelStep.reduce_gradients): decoder bucket alone, the rest merged into one
+            # the step's actual collectives (DataParallelStep.reduce_gradients): one per active bucket, each waiting on its own event only
             plan = comm_plan(buckets, phase2)
-            assert len(plan) == 2 and plan[0] == ([0], buckets[0][0], buckets[0][1])
-            assert plan[1][0] == ([1, 2] if phase2 else [1]) and plan[1][1] == buckets[1][0]
-            assert plan[1][2] == (buckets[1][1] + buckets[2][1] if phase2 else buckets[1][1])
+            assert [p_[0] for p_ in plan] == [[i] for i, b in enumerate(buckets) if phase2 or not b[2]]
+            assert all((off, cnt) == (buckets[ids[0]][0], buckets[ids[0]][1]) for ids, off, cnt in plan)
             g2 = torch.full((n,), float(rank + 1)) + torch.arange(n, dtype=torch.float32) * 1e-3 * (rank + 1)
             for ids, off, cnt in plan:
                 allreduce_bucket(dist, g2, off, cnt)
@@ -165,9 +170,10 @@ def _dp_worker(rank, world, port, out):
                 if not phase2:
                     assert float(seen[lo:].abs().max()) == 0.0          # the phase-2-only bucket is neither produced nor exchanged
                 singles.append(want)
-                # order inside one step: forward, backward, [wait bucket 0], [wait the rest], optimiser
-                names = [r[0] if r[0] != "wait" else "wait%d" % r[1] for r in e.log[-(5 + (1 if phase2 else 0)):]]
-                assert names == ["forward", "backward", "wait0", "wait1"] + (["wait2"] if phase2 else []) + ["opt"], names
+                # order inside one step: forward, backward, one wait per active bucket in completion order, optimiser
+                act = [i for i, b in enumerate(buckets) if phase2 or not b[2]]
+                names = [r[0] if r[0] != "wait" else "wait%d" % r[1] for r in e.log[-(3 + len(act)):]]
+                assert names == ["forward", "backward"] + ["wait%d" % i for i in act] + ["opt"], names
                 assert [r for r in e.log if r[0] == "opt"][-1][1] == overlap
             dp.finish()
             assert e.log[-1] == ("opt_wait",)
@@ -207,3 +213,28 @@ def test_data_parallel_step_two_ranks_gloo():
     out = mgr.dict()
     mp.spawn(_dp_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: "ok", 1: "ok"}
+
+
+def test_bucket_plan_of_the_benchmark_configuration():
+    """BASELINE configs[2..3] (6-layer d_model 512): the engine closes a gradient bucket at every weight-gradient flush point — groups of
+    whole layers of >= 32 MB — so that the exchange is >= 6 collectives in backward-completion order, none above ~40 MB, all but the last
+    final before backward ends; phase 1 skips the phase-2-only ones."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bltvqg_amd  # noqa: F401
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import comm_plan
+    eng = StepEngine(make_config(256, 512, 2048, 512, 300, 6, 8, 8000, dtype=1), "cpu")
+    buckets = eng.buckets()
+    p1, p2 = comm_plan(buckets, False), comm_plan(buckets, True)
+    assert len(p1) >= 6 and len(p2) >= 9
+    assert all(cnt * 4 <= 41 * 2 ** 20 for _, _, cnt in p2), [cnt * 4 / 2 ** 20 for _, _, cnt in p2]
+    assert all(not buckets[ids[0]][2] for ids, _, _ in p1)
+    names = list(eng.train_info)
+    first = [n for n in names if eng.train_info[n].offset < buckets[0][1]]
+    assert first[0] == "decoder.output.weight" and any(n.startswith("decoder.decoder.dec.5.") for n in first)
+    # the last collective is the small tail (shared embedding + CNN head) that only the end of backward makes final
+    tail = buckets[-1]
+    assert tail[1] * 4 < 12 * 2 ** 20
+    assert eng.train_info["embedding.0.weight"].offset >= tail[0] and eng.train_info["encoder_cnn.bn.bias"].offset < tail[0] + tail[1]

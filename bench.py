@@ -287,7 +287,10 @@ def main():
     d = {k: batch[k].to(dev) for k in keys}
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
 
-    use_prefetch = (not a.no_prefetch) and not cfg.get("num_regions")
+    # The conv stack runs one batch ahead on a stream of its own only when no gradient exchange needs one: the command processor runs at
+    # most four queues truly side by side (scratch/queues_exp.py: a fifth stream's kernels are time-sliced even with GPU_MAX_HW_QUEUES=8),
+    # and the step already uses the caller's stream + two engine streams; N > 1 gives the fourth to the communication stream
+    use_prefetch = (not a.no_prefetch) and not cfg.get("num_regions") and dist is None
     # ---- the PCIe-inclusive feed: pinned host batch, copied one step ahead on a copy stream into two device buffers -----------
     h2d_state = {}
 
@@ -328,6 +331,10 @@ def main():
         elif eng.prefetch_pending():      # a loop of the other kind left its look-ahead batch behind: it is this same synthetic batch
             step.run(None, cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=999, kl_weight=HP["kl_weight"], lr=HP["lr"],
                      max_norm=HP["max_norm"])
+            step.finish()
+            # ... and its conv stream: this loop has a copy stream instead, and a fifth live stream would share a hardware queue with one
+            # of the others (set_cu_masks with no masks recreates the engine's streams and drops the conv stream)
+            eng.set_cu_masks(None, None, None, 0)
         step.run(cur["images"], cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=1000 + i,
                  kl_weight=HP["kl_weight"], lr=HP["lr"], max_norm=HP["max_norm"], next_images=nxt)
         if h2d:

@@ -131,6 +131,7 @@ SIGNATURES = {
     "bltvqg_engine_profile_read": (I, [P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]),
     "bltvqg_engine_profile_read_class": (I, [P, I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]),
     "bltvqg_engine_phase_stamps": (I, [P, ctypes.POINTER(ctypes.c_float)]),
+    "bltvqg_engine_set_bucket_flush": (I, [P, I]),
     "bltvqg_engine_num_buckets": (I, [P]),
     "bltvqg_engine_bucket_info": (I, [P, I, ctypes.POINTER(L), ctypes.POINTER(L), ctypes.POINTER(ctypes.c_int32)]),
     "bltvqg_engine_bucket_wait": (I, [P, I, P]),

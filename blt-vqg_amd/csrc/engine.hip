@@ -172,6 +172,15 @@ struct bltvqg_engine {
     std::vector<int> dec_flush, enc_flush, renc_flush;   // per layer l: bucket closed by the flush after layer l's backward, or -1
     int bk_dec_last = -1, bk_late0 = -1, bk_enc_last = -1, bk_renc_last = -1, bk_tail = -1;
     static constexpr int64_t BUCKET_TARGET_BYTES = 32ll << 20;
+    // In-stack flushes exist for the data-parallel exchange (a bucket's all-reduce can start while backward is still running); on one GPU
+    // they only take CUs from the chain (measured +0.15 ms per step on BASELINE configs[2]), so they are off until the step driver that owns
+    // an exchange turns them on (bltvqg_engine_set_bucket_flush).  Off: one flush per stack, every bucket of the stack final with it.
+    bool group_flush = false;
+    int record_buckets(const std::vector<int>& plan, hipStream_t st) {
+        for (int b : plan)
+            if (b >= 0 && buckets[b].ev && hipEventRecord(buckets[b].ev, st) != hipSuccess) { blt_set_error("engine: bucket event record failed"); return BLT_ERR_HIP; }
+        return BLT_OK;
+    }
     // the 330 MB gradient memset leaves the critical path: forward() issues it on a side stream (behind the previous optimiser update,
     // the last reader of the gradients) and backward only waits for its event
     hipEvent_t grad_zero_ev = nullptr;
@@ -1402,8 +1411,8 @@ struct bltvqg_engine {
             cur = out;
             // in-stack flush points (build_params: groups of whole layers of >= ~32 MB of parameters): the collected weight gradients go
             // to the weight-gradient stream now, run under the rest of THIS chain and close a gradient bucket, whose all-reduce (N > 1)
-            // can start while backward is still running.  debug key 11 = 1: off (one flush per stack, the round-2 form: A/B switch)
-            if (defer_wgrads && flush_plan && (*flush_plan)[l] >= 0 && blt_debug_get(11) != 1) RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
+            // can start while backward is still running.  only while group_flush is on (a data-parallel exchange exists)
+            if (defer_wgrads && group_flush && flush_plan && (*flush_plan)[l] >= 0) RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
         }
         return BLT_OK;
     }
@@ -1489,6 +1498,7 @@ struct bltvqg_engine {
         // launched beside the grouped kernel they waited for its 40 us workgroups to free a CU one by one (0.55 ms instead of 0.1).  The
         // latent nets' own weight gradients ride in the same launch; bucket 0 (decoder.*) is complete when side[1] gets past it.
         RC(flush_wgrads(s, use_streams ? side[1] : s, fj[6], bk_dec_last, phase2 ? bk_late0 : -1));
+        if (!group_flush) RC(record_buckets(dec_flush, use_streams ? side[1] : s));
         // d(image feature) is final here, long before the encoder chains are: the CNN head's backward (BatchNorm1d -> fc) goes to the
         // weight-gradient stream now instead of closing the chain
         if (use_streams) { RC(fork(s, side[1], fj[13])); RC(cnn_head_bwd(side[1])); }
@@ -1508,6 +1518,7 @@ struct bltvqg_engine {
             // encoder's weight gradients then run on s0 behind it, beside the context encoder's on side[1], and are joined at the very end
             if (s0 != s && hipEventRecord(fj[5], s0) != hipSuccess) { blt_set_error("backward: event record failed"); return BLT_ERR_HIP; }
             RC(flush_wgrads(s0, s0 != s ? s0 : side[1], fj[7], bk_renc_last));
+            if (!group_flush) RC(record_buckets(renc_flush, s0 != s ? s0 : side[1]));
             Memb = Mtot;
         }
         // ---- context encoder (main stream) ----
@@ -1520,6 +1531,7 @@ struct bltvqg_engine {
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s, &enc_flush));
         stamp(9, s);
         RC(flush_wgrads(s, use_streams ? side[1] : s, fj[8], bk_enc_last));
+        if (!group_flush) RC(record_buckets(enc_flush, use_streams ? side[1] : s));
         defer_wgrads = false;
         if (s0 != s && hipStreamWaitEvent(s, fj[5], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
         // ---- shared embedding (rows of the streams that received gradient): weight + bias gradient to the side stream, the gradient of
@@ -1982,6 +1994,11 @@ int bltvqg_engine_phase_stamps(bltvqg_engine* e, float* ms_host12) {
     return BLT_OK;
 }
 
+int bltvqg_engine_set_bucket_flush(bltvqg_engine* e, int on) {
+    BLT_REQUIRE(e, "engine_set_bucket_flush: null engine");
+    e->group_flush = on != 0;
+    return BLT_OK;
+}
 int bltvqg_engine_num_buckets(const bltvqg_engine* e) { return e ? (int)e->buckets.size() : 0; }
 int bltvqg_engine_bucket_info(const bltvqg_engine* e, int i, int64_t* offset, int64_t* numel, int32_t* late) {
     BLT_REQUIRE(e && i >= 0 && i < (int)e->buckets.size(), "engine_bucket_info: bad args");

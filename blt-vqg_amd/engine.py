@@ -288,6 +288,10 @@ class StepEngine(object):
         check(self.lib.bltvqg_engine_profile_read_class(self.h, int(cls), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "profile_read")
         return ms.value, n.value, fl.value
 
+    def set_bucket_flush(self, on=True):
+        """In-stack weight-gradient flushes at every gradient-bucket boundary (for the data-parallel exchange; off on one GPU)."""
+        check(self.lib.bltvqg_engine_set_bucket_flush(self.h, 1 if on else 0), "engine_set_bucket_flush")
+
     def buckets(self):
         out = []
         off, n, late = _lib.L(), _lib.L(), ctypes.c_int32()

@@ -138,6 +138,10 @@ class DataParallelStep(object):
         self.overlap_optimizer = overlap_optimizer
         self.comm = torch.cuda.Stream(device=engine.device) if (dist is not None and self.cuda) else None
         self.buckets = engine.buckets()
+        # with an exchange to overlap, the engine flushes weight gradients at every bucket boundary so that each bucket's all-reduce can
+        # start under the rest of backward; on one GPU those extra launches only compete with the chain (+0.15 ms per step measured)
+        if dist is not None and hasattr(engine, "set_bucket_flush"):
+            engine.set_bucket_flush(True)
         # optional bf16 wire format of the gradient exchange (allreduce_bucket): one staging buffer as large as the largest collective
         self.wire = None
         if dist is not None and bf16_wire:

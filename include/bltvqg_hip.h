@@ -398,8 +398,14 @@ int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms
  * starts, [7] decoder backward done, [8] encoder backward starts, [9] done, [10] end of backward, [11] image feature done on the CNN's
  * stream (before the encoder streams are joined: [11] ~ [1] means the CNN chain is the long pole of the first phase); -1 = not recorded. */
 int bltvqg_engine_phase_stamps(bltvqg_engine* e, float* ms_host12);
-/* gradient buckets for data-parallel overlap: contiguous float ranges of the flat gradient buffer in the order backward
- * completes them; bltvqg_engine_bucket_wait makes `stream` wait until bucket i of the last backward is complete. */
+/* Gradient buckets for the data-parallel exchange (reference: pl.Trainer(gpus=N), train_iq.py:372-373 = DDP gradient mean): contiguous
+ * float ranges of the flat gradient buffer, LISTED IN THE ORDER BACKWARD COMPLETES THEM (not in address order; together they tile the
+ * buffer once): decoder layer groups, the latent-phase heads, the two encoder stacks' layer groups, the tail (shared embedding + CNN head).
+ * A bucket is a group of whole layers of >= ~32 MB of parameters.  bltvqg_engine_bucket_wait makes `stream` wait until bucket i of the last
+ * backward is final.  bltvqg_engine_set_bucket_flush(1): the collected weight gradients of a stack are flushed to the weight-gradient
+ * stream at every bucket boundary, so a bucket's event fires (and its all-reduce can start) while backward is still running; 0 (default,
+ * single GPU): one flush per stack, the buckets of a stack become final together. */
+int bltvqg_engine_set_bucket_flush(bltvqg_engine* e, int on);
 int bltvqg_engine_num_buckets(const bltvqg_engine* e);
 int bltvqg_engine_bucket_info(const bltvqg_engine* e, int i, int64_t* offset, int64_t* numel, int32_t* late);
 int bltvqg_engine_bucket_wait(bltvqg_engine* e, int i, void* stream);

@@ -299,12 +299,15 @@ def main():
             return
         h2d_state["host"] = {k: batch[k].contiguous().pin_memory() for k in keys}
         h2d_state["bufs"] = [{k: torch.empty_like(d[k]) for k in keys} for _ in range(2)]
+        # With the conv stack one batch ahead, the next batch's PCIe copy and its conv stack are ONE pipeline on the engine's conv stream
+        # (copy, then the stack, both underneath the current step): no fifth stream.  Without it: a copy stream of its own, stack inline.
         h2d_state["stream"] = torch.cuda.Stream(device=dev)
+        if use_prefetch:      # (switch_feed has consumed every pending batch: the conv stream may change)
+            eng.adopt_conv_stream(h2d_state["stream"])
         h2d_state["ready"] = [torch.cuda.Event(), torch.cuda.Event()]       # buffer filled
         h2d_state["free"] = [torch.cuda.Event(), torch.cuda.Event()]        # buffer consumed by its step
         for ev in h2d_state["free"]:
             ev.record()
-        upload(0)
 
     def upload(slot):
         hs = h2d_state
@@ -313,37 +316,43 @@ def main():
             for k in keys:
                 hs["bufs"][slot][k].copy_(hs["host"][k], non_blocking=True)
             hs["ready"][slot].record(hs["stream"])
+            if use_prefetch:
+                eng.prefetch_images(hs["bufs"][slot]["images"])      # (ordered behind the copy: same stream)
+
+    feed = {"kind": None}
+
+    def switch_feed(kind, phase2, first):
+        """The resident and the PCIe-fed loops each keep their own look-ahead pipeline: changing over consumes what the other left."""
+        if feed["kind"] == kind:
+            return
+        while use_prefetch and eng.prefetch_pending():
+            eps0 = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+            step.run(None, d["answers"], d["posteriors"], d["questions"], eps0, phase2, seed=998, kl_weight=HP["kl_weight"], lr=HP["lr"],
+                     max_norm=HP["max_norm"])
+        feed["kind"] = kind
+        if kind == "h2d":
+            h2d_setup()
+            upload(first % 2)
 
     def one_step(i, phase2, h2d=False):
         eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
-        cur = d
+        switch_feed("h2d" if h2d else "resident", phase2, i)
         if h2d:
-            h2d_setup()
             slot = i % 2
-            upload(slot ^ 1)                                   # next step's batch crosses PCIe underneath this step
+            upload(slot ^ 1)                                   # next step's batch crosses PCIe (and runs its conv stack) underneath this step
             torch.cuda.current_stream().wait_event(h2d_state["ready"][slot])
             cur = h2d_state["bufs"][slot]
+            step.run(None if use_prefetch else cur["images"], cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=1000 + i,
+                     kl_weight=HP["kl_weight"], lr=HP["lr"], max_norm=HP["max_norm"])
+            h2d_state["free"][slot].record()
+            return
         # image mode: the frozen conv stack of the NEXT batch is enqueued one batch ahead (DataParallelStep.run(next_images=...)); every
         # step still contains exactly one conv stack and one of everything else
-        nxt = None
-        if use_prefetch and not h2d:      # (the PCIe-fed loop keeps the stack inline: its next batch is still crossing PCIe when this step starts)
-            nxt = cur["images"]
-        elif eng.prefetch_pending():      # a loop of the other kind left its look-ahead batch behind: it is this same synthetic batch
-            step.run(None, cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=999, kl_weight=HP["kl_weight"], lr=HP["lr"],
-                     max_norm=HP["max_norm"])
-            step.finish()
-            # ... and its conv stream: this loop has a copy stream instead, and a fifth live stream would share a hardware queue with one
-            # of the others (set_cu_masks with no masks recreates the engine's streams and drops the conv stream)
-            eng.set_cu_masks(None, None, None, 0)
-        step.run(cur["images"], cur["answers"], cur["posteriors"], cur["questions"], eps, phase2, seed=1000 + i,
-                 kl_weight=HP["kl_weight"], lr=HP["lr"], max_norm=HP["max_norm"], next_images=nxt)
-        if h2d:
-            h2d_state["free"][i % 2].record()
+        step.run(d["images"], d["answers"], d["posteriors"], d["questions"], eps, phase2, seed=1000 + i,
+                 kl_weight=HP["kl_weight"], lr=HP["lr"], max_norm=HP["max_norm"], next_images=d["images"] if use_prefetch else None)
 
     def timed_loop(n, first, phase2, h2d=False, profile_step=-1):
         """n steps bracketed by barrier + synchronize on both sides; returns the MAX over ranks of the wall time."""
-        if h2d:
-            h2d_setup()
         if dist:
             dist.barrier()
         torch.cuda.synchronize()
@@ -371,8 +380,6 @@ def main():
 
     phase2 = a.phase == 2
     print("[bench] rank %d: engine ready (workspace %.2f GB), warming up" % (rank, eng.workspace_bytes / 1e9), file=sys.stderr, flush=True)
-    if a.h2d:
-        h2d_setup()
     if a.autotune:
         # measure, don't guess: the first warm-up step times every candidate GEMM/conv kernel (tile shape, LDS-DMA ring vs
         # register staging) on the real operands of each distinct launch and caches the fastest (csrc/gemm.hip::autotune)

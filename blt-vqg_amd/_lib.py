@@ -102,6 +102,7 @@ SIGNATURES = {
     "bltvqg_engine_set_cu_masks": (I, [P, P, P, P, I, I]),
     "bltvqg_engine_chain_stream": (I, [P, ctypes.POINTER(ctypes.c_void_p)]),
     "bltvqg_engine_conv_stream": (I, [P, ctypes.POINTER(ctypes.c_void_p)]),
+    "bltvqg_engine_adopt_conv_stream": (I, [P, P]),
     "bltvqg_engine_create": (P, [ctypes.POINTER(Config)]),
     "bltvqg_engine_destroy": (None, [P]),
     "bltvqg_engine_num_params": (I, [P, I]),

@@ -136,6 +136,7 @@ struct bltvqg_engine {
     bool cnn_stream_used = false;
     int last_cnn_slot = 0;       // slot of the last stack enqueued on the conv stream (its event orders an inline stack behind it)
     hipStream_t cnn_stream = nullptr, chain_stream = nullptr;
+    bool cnn_stream_owned = true;      // false: the caller's stream (bltvqg_engine_adopt_conv_stream), never destroyed here
     hipEvent_t cnn_in_ev = nullptr, cnn_done[2] = {nullptr, nullptr};
     bool have_masks = false;
     uint32_t cu_masks[3][8] = {};      // [0] chain (caller's stream + side[0]), [1] side[1] (weight gradients, optimiser), [2] conv stack
@@ -1681,7 +1682,7 @@ void bltvqg_engine_destroy(bltvqg_engine* e) {
     if (e->grad_zero_ev) (void)hipEventDestroy(e->grad_zero_ev);
     for (int i = 0; i < 16; ++i) if (e->fj[i]) (void)hipEventDestroy(e->fj[i]);
     for (int i = 0; i < 2; ++i) if (e->side[i]) (void)hipStreamDestroy(e->side[i]);
-    if (e->cnn_stream) (void)hipStreamDestroy(e->cnn_stream);
+    if (e->cnn_stream && e->cnn_stream_owned) (void)hipStreamDestroy(e->cnn_stream);
     if (e->chain_stream) (void)hipStreamDestroy(e->chain_stream);
     if (e->cnn_in_ev) (void)hipEventDestroy(e->cnn_in_ev);
     for (int i = 0; i < 2; ++i) if (e->cnn_done[i]) (void)hipEventDestroy(e->cnn_done[i]);
@@ -1833,7 +1834,7 @@ int bltvqg_engine_set_cu_masks(bltvqg_engine* e, const uint32_t* chain_mask_host
     // every stream the engine owns is recreated under its mask (the caller has synchronised: nothing of this engine is in flight)
     if (hipDeviceSynchronize() != hipSuccess) { blt_set_error("engine_set_cu_masks: synchronize failed"); return BLT_ERR_HIP; }
     for (int i = 0; i < 2; ++i) if (e->side[i]) { (void)hipStreamDestroy(e->side[i]); e->side[i] = nullptr; }
-    if (e->cnn_stream) { (void)hipStreamDestroy(e->cnn_stream); e->cnn_stream = nullptr; }
+    if (e->cnn_stream && e->cnn_stream_owned) { (void)hipStreamDestroy(e->cnn_stream); e->cnn_stream = nullptr; }
     if (e->chain_stream) { (void)hipStreamDestroy(e->chain_stream); e->chain_stream = nullptr; }
     if (e->bound) {
         { const int rc_ = e->make_stream(&e->side[0], 0); if (rc_) return rc_; }
@@ -1851,6 +1852,14 @@ int bltvqg_engine_chain_stream(bltvqg_engine* e, void** stream) {
     return BLT_OK;
 }
 
+int bltvqg_engine_adopt_conv_stream(bltvqg_engine* e, void* stream) {
+    BLT_REQUIRE(e && stream, "engine_adopt_conv_stream: null argument");
+    BLT_REQUIRE(e->pf_n == 0, "engine_adopt_conv_stream: a prefetched batch is pending");
+    if (e->cnn_stream && e->cnn_stream_owned) { (void)hipStreamSynchronize(e->cnn_stream); (void)hipStreamDestroy(e->cnn_stream); }
+    e->cnn_stream = (hipStream_t)stream;
+    e->cnn_stream_owned = false;
+    return BLT_OK;
+}
 int bltvqg_engine_conv_stream(bltvqg_engine* e, void** stream) {
     BLT_REQUIRE(e && stream, "engine_conv_stream: null argument");
     if (!e->cnn_stream) { const int rc_ = e->make_stream(&e->cnn_stream, 2); if (rc_) return rc_; }

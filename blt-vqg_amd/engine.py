@@ -190,6 +190,11 @@ class StepEngine(object):
             self._chain_stream = torch.cuda.ExternalStream(p.value, device=self.device)
         return self._chain_stream
 
+    def adopt_conv_stream(self, stream):
+        """Prefetched conv stacks run on `stream` (a torch.cuda.Stream the caller keeps alive) instead of an engine-owned stream."""
+        check(self.lib.bltvqg_engine_adopt_conv_stream(self.h, ctypes.c_void_p(stream.cuda_stream)), "engine_adopt_conv_stream")
+        self._adopted_conv_stream = stream      # keep it alive as long as the engine
+
     def conv_stream(self):
         """The engine's prefetch stream as a torch stream (diagnostics only)."""
         p = ctypes.c_void_p()

@@ -336,6 +336,10 @@ int bltvqg_engine_set_cu_masks(bltvqg_engine* e, const uint32_t* chain_mask_host
 int bltvqg_engine_chain_stream(bltvqg_engine* e, void** stream);
 /* the engine's prefetch (conv) stream, for diagnostics: which CUs its work lands on (bltvqg_hw_id_probe) */
 int bltvqg_engine_conv_stream(bltvqg_engine* e, void** stream);
+/* Run the prefetched conv stacks on a stream the CALLER owns (and outlives the engine with) instead of the engine's own: a feeder that
+ * copies the next batch over PCIe enqueues copy and bltvqg_engine_prefetch_images on that one stream — one pipeline underneath the current
+ * step, no extra stream.  Not combined with conv_mask_host (the caller's stream has the caller's CU mask). */
+int bltvqg_engine_adopt_conv_stream(bltvqg_engine* e, void* stream);
 
 /* IQ.forward (iq.py:82-114).  images fp32 NCHW [B,3,h,w]; token tensors int64 like the reference batch; eps fp32 [B,Z]
  * (may be NULL in phase 1).  train_bn: BatchNorm in train mode (batch statistics + running-stat update), as the reference. */

@@ -291,6 +291,12 @@ def main():
     # most four queues truly side by side (scratch/queues_exp.py: a fifth stream's kernels are time-sliced even with GPU_MAX_HW_QUEUES=8),
     # and the step already uses the caller's stream + two engine streams; N > 1 gives the fourth to the communication stream
     use_prefetch = (not a.no_prefetch) and not cfg.get("num_regions") and dist is None
+    conv_s = None
+    if use_prefetch:
+        # ONE stream for everything that runs a batch ahead (the conv stack; in the PCIe-fed loop also the copy in front of it), created
+        # once: a stream that is destroyed does not give its hardware queue back, and a fifth queue is time-sliced against the others
+        conv_s = torch.cuda.Stream(device=dev)
+        eng.adopt_conv_stream(conv_s)
     # ---- the PCIe-inclusive feed: pinned host batch, copied one step ahead on a copy stream into two device buffers -----------
     h2d_state = {}
 
@@ -301,9 +307,7 @@ def main():
         h2d_state["bufs"] = [{k: torch.empty_like(d[k]) for k in keys} for _ in range(2)]
         # With the conv stack one batch ahead, the next batch's PCIe copy and its conv stack are ONE pipeline on the engine's conv stream
         # (copy, then the stack, both underneath the current step): no fifth stream.  Without it: a copy stream of its own, stack inline.
-        h2d_state["stream"] = torch.cuda.Stream(device=dev)
-        if use_prefetch:      # (switch_feed has consumed every pending batch: the conv stream may change)
-            eng.adopt_conv_stream(h2d_state["stream"])
+        h2d_state["stream"] = conv_s if use_prefetch else torch.cuda.Stream(device=dev)
         h2d_state["ready"] = [torch.cuda.Event(), torch.cuda.Event()]       # buffer filled
         h2d_state["free"] = [torch.cuda.Event(), torch.cuda.Event()]        # buffer consumed by its step
         for ev in h2d_state["free"]:

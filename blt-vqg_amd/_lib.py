@@ -30,6 +30,7 @@ class Config(ctypes.Structure):
         ("attention_dropout", ctypes.c_float), ("relu_dropout", ctypes.c_float),
         ("kl_ceiling", ctypes.c_float), ("aux_ceiling", ctypes.c_float), ("image_recon_lambda", ctypes.c_float),
         ("num_regions", ctypes.c_int32), ("region_dim", ctypes.c_int32), ("region_pool", ctypes.c_int32),
+        ("head_dim_true", ctypes.c_int32),
     ]
 
 

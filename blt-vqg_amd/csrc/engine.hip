@@ -71,6 +71,10 @@ struct bltvqg_engine {
     int dt, es;                 // dtype, element size
     int B, H, F, Z, E, L, NH, V, Sa, Sp, T;
     int Ma, Mp, Mt, Mtot, Epad, ldV, dh;
+    // Padded model widths (bltvqg_config::head_dim_true): every H-wide tensor stores each head's head_dim_true real features in a slot of
+    // dh = H / heads columns, the rest are zero pads (zero weights, zero gradients).  dh_true = real head width, H_true = heads * dh_true,
+    // ln_pp / ln_pv = the LayerNorm kernels' pad pattern (0 / 0 when nothing is padded).
+    int dh_true = 0, H_true = 0, ln_pp = 0, ln_pv = 0;
     int imgHp = 0, imgWp = 0;   // zero-bordered NHWC4 input image of the 7x7/2 stem
     float* ln_pool = nullptr;
     size_t ln_pool_floats = 0, ln_pool_used = 0;
@@ -591,6 +595,9 @@ struct bltvqg_engine {
         V = c.vocab_size; Sa = c.len_context; Sp = c.len_posterior; T = c.len_target;
         Ma = B * Sa; Mp = B * Sp; Mt = B * T; Mtot = Ma + Mt + Mp;
         Epad = round_up(E, 32); ldV = round_up(V, 8); dh = H / NH;
+        dh_true = (c.head_dim_true > 0 && c.head_dim_true < dh) ? c.head_dim_true : dh;
+        H_true = NH * dh_true;
+        if (dh_true != dh) { ln_pp = dh; ln_pv = dh_true; }
         {
             const int ho = (c.image_h + 6 - 7) / 2 + 1, wo = (c.image_w + 6 - 7) / 2 + 1;
             imgHp = c.image_h + 6 > 2 * (ho - 1) + 7 ? c.image_h + 6 : 2 * (ho - 1) + 7;
@@ -758,7 +765,7 @@ struct bltvqg_engine {
             pending_ln.push_back(e);
         }
         return blt_layernorm_bwd(dt, dy, x, P(ln + ".weight"), mean, rstd, dres, dx, G(ln + ".weight"), G(ln + ".bias"), M, H, s, maskY, mask_scale,
-                                 out2, part);
+                                 out2, part, ln_pp, ln_pv);
     }
 
     // dX = dY W with a vocabulary-sized contraction (K = V): few output tiles and a long K loop, so the K range is split over
@@ -795,7 +802,7 @@ struct bltvqg_engine {
                  int causal, uint32_t stream_id, hipStream_t s) {
         AttnArgs a;
         a.Q = q; a.ldq = ldq; a.K = k; a.V = v; a.ldk = ldkv; a.ldv = ldkv; a.O = o; a.ldo = H; a.key_ids = key_ids;
-        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh);
+        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh_true);
         a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
         return blt_attn_fwd(dt, a, s);
     }
@@ -803,7 +810,7 @@ struct bltvqg_engine {
                  void* dv, int lddkv, const int* key_ids, int Tq, int Tk, int causal, uint32_t stream_id, hipStream_t s) {
         AttnArgs a;
         a.Q = q; a.ldq = ldq; a.K = k; a.V = v; a.ldk = ldkv; a.ldv = ldkv; a.key_ids = key_ids;
-        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh);
+        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh_true);
         a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
         a.dO = dO; a.lddo = H; a.dQ = dq; a.lddq = lddq; a.dK = dk; a.dV = dv; a.lddk = lddkv; a.lddv = lddkv;
         return blt_attn_bwd(dt, a, s);
@@ -814,7 +821,7 @@ struct bltvqg_engine {
     // on the B=128 step it does not pay: every workgroup then streams the whole weight matrix, and what the 14 saved launches give
     // (~5 us each) the slower GEMMs take back (2.91 vs 2.89 ms with 32-row tiles, 2.96 ms with 64-row tiles) — so it is off unless
     // debug key 7 is 3 (A/B switch); the operator stays exported (bltvqg_linear_layernorm) and tested.
-    bool ln_fused() const { return blt_debug_get(7) == 3 && dt == BLT_BF16 && H <= 256 && H % 8 == 0; }
+    bool ln_fused() const { return blt_debug_get(7) == 3 && dt == BLT_BF16 && H <= 256 && H % 8 == 0 && ln_pp == 0; }
     void set_ln(GemmArgs& g, const std::string& ln, void* out, float* m, float* r) {
         g.ln_gamma = P(ln + ".weight"); g.ln_beta = P(ln + ".bias"); g.ln_out = out; g.ln_mean = m; g.ln_rstd = r; g.ln_eps = 1e-5f;
     }
@@ -825,7 +832,7 @@ struct bltvqg_engine {
     // MFMA chain is as long as LayerNorm launch + GEMM launch were, which says that these kernels are bound by dependent memory round
     // trips, not by the launch itself.  Kept as an exported, tested operator (bltvqg_layernorm_linear); the engine uses it only under
     // debug key 7 = 6 (A/B).
-    bool lnA_on() const { return dt == BLT_BF16 && H <= 256 && H % 8 == 0 && blt_debug_get(7) == 6; }
+    bool lnA_on() const { return dt == BLT_BF16 && H <= 256 && H % 8 == 0 && blt_debug_get(7) == 6 && ln_pp == 0; }
     // GEMM input: the normalised tensor `xn`, or — folded — the raw tensor x plus the LayerNorm that produces xn (written as a by-product)
     void set_lnA(GemmArgs& g, const void* x, const std::string& ln, void* xn, float* m, float* r) {
         g.A = x; g.lnA_gamma = P(ln + ".weight"); g.lnA_beta = P(ln + ".bias"); g.lnA_out = xn; g.lnA_mean = m; g.lnA_rstd = r; g.lnA_eps = 1e-5f;
@@ -845,7 +852,7 @@ struct bltvqg_engine {
         if (ln_fused()) set_ln(g, next.name, next.out, next.m, next.r);
         RC(gemm(dt, g, s));
         if (!ln_fused() && (next_is_final || !lnA_on()))
-            RC(blt_layernorm_fwd(dt, y.x2, P(next.name + ".weight"), P(next.name + ".bias"), next.out, next.m, next.r, M, H, 1e-5f, s));
+            RC(blt_layernorm_fwd(dt, y.x2, P(next.name + ".weight"), P(next.name + ".bias"), next.out, next.m, next.r, M, H, 1e-5f, s, ln_pp, ln_pv));
         return BLT_OK;
     }
 
@@ -870,7 +877,7 @@ struct bltvqg_engine {
         if (!lnA_on()) {   // the first LayerNorm reads the shared embedding's output
             const std::string ln1 = lname(0) + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
             Layer& y0 = st.layers[0];
-            RC(blt_layernorm_fwd(dt, x, P(ln1 + ".weight"), P(ln1 + ".bias"), y0.xn1, y0.m1, y0.r1, M, H, 1e-5f, s));
+            RC(blt_layernorm_fwd(dt, x, P(ln1 + ".weight"), P(ln1 + ".bias"), y0.xn1, y0.m1, y0.r1, M, H, 1e-5f, s, ln_pp, ln_pv));
         }
         for (int l = 0; l < L; ++l) {
             Layer& y = st.layers[l];
@@ -900,7 +907,7 @@ struct bltvqg_engine {
                 g.R = x; g.ldr = H;
                 if (ln_fused()) set_ln(g, ln2, y.xn2, y.m2, y.r2);
                 RC(gemm(dt, g, s));
-                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s));
+                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s, ln_pp, ln_pv));
             }
             if (st.dec) {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
@@ -923,7 +930,7 @@ struct bltvqg_engine {
                 g.R = y.x1; g.ldr = H;
                 if (ln_fused()) set_ln(g, ln3, y.xn3, y.m3, y.r3);
                 RC(gemm(dt, g, s));
-                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s));
+                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s, ln_pp, ln_pv));
                 RC(ffn_fwd(lp + "positionwise_feed_forward.", ln3, y.xn3, y.m3, y.r3, y.x1b, y, M, st.id, l, next, l + 1 == L, s));
             } else {
                 RC(ffn_fwd(lp + "positionwise_feed_forward.", ln2, y.xn2, y.m2, y.r2, y.x1, y, M, st.id, l, next, l + 1 == L, s));
@@ -1580,7 +1587,7 @@ struct bltvqg_engine {
         // bag-of-words CE only feed the branch stream's work (backward_core) and run there, beside it.
         hipStream_t sbr = use_streams ? side[0] : s;
         if (sbr != s) RC(fork(s, sbr, fj[11]));
-        RC(blt_mse_fwd_bwd(dt, feats, recon, (long)B * H, c.image_recon_lambda, stats + 1, d_feats, d_recon, sbr));
+        RC(blt_mse_fwd_bwd(dt, feats, recon, (long)B * H, c.image_recon_lambda, stats + 1, d_feats, d_recon, sbr, (long)B * H_true));
         float kld_g = 0.f;
         if (phase2) {
             RC(blt_bow_ce_fwd_bwd(dt, zlogit, ldV, tgt32, B, T, V, counters, c.aux_ceiling, stats + 3, dzl, sbr));
@@ -1673,6 +1680,10 @@ bltvqg_engine* bltvqg_engine_create(const bltvqg_config* cfg) {
         return nullptr;
     }
     if (c.emb_dim % 4 != 0) { blt_set_error("engine_create: emb_dim must be a multiple of 4"); return nullptr; }
+    if (c.head_dim_true < 0 || c.head_dim_true > c.hidden_dim / c.num_heads || (c.head_dim_true > 0 && (c.num_heads * c.head_dim_true) % 2 != 0)) {
+        blt_set_error("engine_create: head_dim_true must be in [0, hidden_dim / num_heads] with an even true width");
+        return nullptr;
+    }
     return new bltvqg_engine(c);
 }
 
@@ -1730,14 +1741,16 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
     if (hipMemset(workspace, 0, (size_t)e->ws_bytes) != hipSuccess) { blt_set_error("engine_bind: workspace memset failed"); return BLT_ERR_HIP; }
     // sinusoid timing signal, transformer_layers.py:542-558: [sin(pos*w_i) | cos(pos*w_i)], float64 then cast
     {
-        const int H = e->H, nt = H / 2;
+        // (padded widths: the signal is that of the TRUE width, each real feature i stored at its padded column)
+        const int H = e->H, Ht = e->H_true, nt = Ht / 2, dht = e->dh_true, dhp = e->dh;
+        auto col = [&](int i) { return (i / dht) * dhp + (i % dht); };
         std::vector<float> tab((size_t)64 * H, 0.f);
         const double inc = log(1.0e4 / 1.0) / ((double)nt - 1.0);
         for (int pos = 0; pos < 64; ++pos)
             for (int i = 0; i < nt; ++i) {
                 const double st = (double)pos * (1.0 * exp((double)i * -inc));
-                tab[(size_t)pos * H + i] = (float)sin(st);
-                tab[(size_t)pos * H + nt + i] = (float)cos(st);
+                tab[(size_t)pos * H + col(i)] = (float)sin(st);
+                tab[(size_t)pos * H + col(nt + i)] = (float)cos(st);
             }
         if (hipMemcpy(e->timing, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
             blt_set_error("engine_bind: timing table upload failed");

@@ -124,15 +124,19 @@ int blt_conv_stem_direct(const void* x_padded, const void* w, void* y, int N, in
                          hipStream_t s);
 
 // ---- normalisation -----------------------------------------------------------------
+// pad_period / pad_valid (0 / 0 = none): column c is a real feature iff c % pad_period < pad_valid; the other columns are zero pads that
+// carry gamma = beta = 0, do not count in mean / variance and get a zero gradient (the reference's default widths: 4 heads of 75 stored
+// as 4 x 80, models.IQ pads them)
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                      long rows, int cols, float eps, hipStream_t s);
+                      long rows, int cols, float eps, hipStream_t s, int pad_period = 0, int pad_valid = 0);
 // dx = LNbwd(dy) (+ dres if non-null); dgamma/dbeta are ACCUMULATED (+=) with float atomics
 // optional second output out2 = (maskY != 0) ? dx * mask_scale : 0 (the ReLU/dropout backward that consumes dx, fused)
 // partials (optional, blt_layernorm_bwd_grid(rows, cols) * 2 * cols floats): the workgroups' dgamma / dbeta sums are stored there
 // instead of being added to dgamma / dbeta; blt_ln_param_reduce adds them later (one launch for many LayerNorms, off the chain)
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
-                      const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr, float* partials = nullptr);
+                      const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr, float* partials = nullptr, int pad_period = 0,
+                      int pad_valid = 0);
 int blt_layernorm_bwd_grid(long rows, int cols);
 #define BLT_LN_RED_MAX 24
 struct LnRed { const float* part; float* dgamma; float* dbeta; int nblocks; int cols; };
@@ -227,8 +231,9 @@ int blt_ce_fwd_bwd(int dtype, void* logits, int ld, const int* target, long M, i
 int blt_bow_ce_fwd_bwd(int dtype, const void* zlogit, int ld, const int* target, int B, int T, int V, const float* count,
                        float gscale, float* loss_out, void* dz, hipStream_t s);
 // mse = mean((a-b)^2); da = gscale*2(a-b)/n ; db = -da   (train_iq.py:84: gradient flows to both arguments)
+// n_div (0 = n): the divisor of the mean when the n elements include zero pads that nn.MSELoss would not have seen
 int blt_mse_fwd_bwd(int dtype, const void* a, const void* b, long n, float gscale, float* loss_out, void* da, void* db,
-                    hipStream_t s);
+                    hipStream_t s, long n_div = 0);
 // reparameterisation + KL (transformer_layers.py:41-59, 536-540)
 int blt_latent_fwd(int dtype, const void* mlv_p, const void* mlv_q, const float* eps, void* z, float* kld_out, int B,
                    int Z, int ld, hipStream_t s);

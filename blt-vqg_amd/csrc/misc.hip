@@ -468,10 +468,10 @@ __global__ __launch_bounds__(256) void bow_ce_kernel(const T* __restrict__ z, in
 
 template <typename T>
 __global__ __launch_bounds__(256) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, long n, float gscale,
-                                                 float* __restrict__ loss_out, T* __restrict__ da, T* __restrict__ db) {
+                                                 float* __restrict__ loss_out, T* __restrict__ da, T* __restrict__ db, long n_div) {
     __shared__ float red[16];
     float s = 0.f;
-    const float inv = 1.f / (float)n;
+    const float inv = 1.f / (float)n_div;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float d = to_f32(a[i]) - to_f32(b[i]);
         s += d * d;
@@ -965,11 +965,12 @@ int blt_bow_ce_fwd_bwd(int dtype, const void* z, int ld, const int* target, int 
     return blt_check_launch("bow_ce");
 }
 
-int blt_mse_fwd_bwd(int dtype, const void* a, const void* b, long n, float gscale, float* loss_out, void* da, void* db, hipStream_t s) {
+int blt_mse_fwd_bwd(int dtype, const void* a, const void* b, long n, float gscale, float* loss_out, void* da, void* db, hipStream_t s, long n_div) {
+    if (n_div <= 0) n_div = n;
     CHECK_DTYPE(dtype, "mse");
     BLT_REQUIRE(a && b && loss_out && n > 0, "mse: bad args");
-    if (dtype == BLT_F32) hipLaunchKernelGGL(mse_kernel<float>, dim3(ew_grid(n, 1024)), dim3(256), 0, s, (const float*)a, (const float*)b, n, gscale, loss_out, (float*)da, (float*)db);
-    else hipLaunchKernelGGL(mse_kernel<bf16>, dim3(ew_grid(n, 1024)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, n, gscale, loss_out, (bf16*)da, (bf16*)db);
+    if (dtype == BLT_F32) hipLaunchKernelGGL(mse_kernel<float>, dim3(ew_grid(n, 1024)), dim3(256), 0, s, (const float*)a, (const float*)b, n, gscale, loss_out, (float*)da, (float*)db, n_div);
+    else hipLaunchKernelGGL(mse_kernel<bf16>, dim3(ew_grid(n, 1024)), dim3(256), 0, s, (const bf16*)a, (const bf16*)b, n, gscale, loss_out, (bf16*)da, (bf16*)db, n_div);
     return blt_check_launch("mse");
 }
 

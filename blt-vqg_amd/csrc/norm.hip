@@ -14,11 +14,24 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, T* __restrict__ y,
                                                            float* __restrict__ mean, float* __restrict__ rstd, long rows,
-                                                           int cols, float eps) {
+                                                           int cols, float eps, int pad_period, int pad_valid) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nch = cols >> 3;
+    // Padded rows (the reference's default widths, e.g. 4 heads of 75 stored as 4 x 80): column c is a real feature iff
+    // c % pad_period < pad_valid; pad columns hold zeros, carry gamma = beta = 0 and count neither in the mean nor in the variance
+    const float n_true = pad_period ? (float)(cols / pad_period * pad_valid) : (float)cols;
+    unsigned vm[LN_MAX_CHUNKS];
+#pragma unroll
+    for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
+        vm[j] = 0xFFu;
+        if (pad_period) {
+            vm[j] = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vm[j] |= ((((lane + 64 * j) * 8 + e) % pad_period) < pad_valid ? 1u : 0u) << e;
+        }
+    }
     float v[LN_MAX_CHUNKS][8];
     float s = 0.f;
 #pragma unroll
@@ -30,17 +43,17 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
             for (int e = 0; e < 8; ++e) s += v[j][e];
         }
     }
-    const float mu = wave_sum(s) / (float)cols;
+    const float mu = wave_sum(s) / n_true;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
         const int c = lane + 64 * j;
         if (c < nch) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mu; q += d * d; }
+            for (int e = 0; e < 8; ++e) { const float d = ((vm[j] >> e) & 1u) ? v[j][e] - mu : 0.f; q += d * d; }
         }
     }
-    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    const float rs = rsqrtf(wave_sum(q) / n_true + eps);
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
 #pragma unroll
     for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
@@ -70,18 +83,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                            T* dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, long rows, int cols,
                                                            const T* __restrict__ maskY, float mask_scale, T* __restrict__ out2,
-                                                           float* __restrict__ partials) {
+                                                           float* __restrict__ partials, int pad_period, int pad_valid) {
     const int lane = threadIdx.x & 63;
     const int nch = cols >> 3;
     const int lpr = (nch <= 32) ? 32 : 64, rpw = 64 / lpr;
     const int l = lane & (lpr - 1), sub = lane / lpr;
+    const float n_true = pad_period ? (float)(cols / pad_period * pad_valid) : (float)cols;      // see layernorm_fwd_kernel
     float ag[NCH][8], ab[NCH][8], g[NCH][8];
+    unsigned vm[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = l + lpr * j;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { ag[j][e] = 0.f; ab[j][e] = 0.f; g[j][e] = 0.f; }
         if (c < nch) Vec8<float>::load(gamma + c * 8, g[j]);
+        vm[j] = 0xFFu;
+        if (pad_period) {
+            vm[j] = 0u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) vm[j] |= (((c * 8 + e) % pad_period) < pad_valid ? 1u : 0u) << e;
+        }
     }
     const long rstride = (long)gridDim.x * 4 * rpw;
     for (long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub; row0 < rows; row0 += rstride * R) {
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     d[r][j][e] = dg;
                 }
             s1 = group_sum(s1, lpr); s2 = group_sum(s2, lpr);
-            const float c1 = s1 / (float)cols, c2 = s2 / (float)cols;
+            const float c1 = s1 / n_true, c2 = s2 / n_true;
             if (row < rows) {
 #pragma unroll
                 for (int j = 0; j < NCH; ++j) {
@@ -132,7 +153,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                     if (c < nch) {
                         float o[8];
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = rs[r] * (d[r][j][e] - c1 - xh[r][j][e] * c2);
+                        for (int e = 0; e < 8; ++e) o[e] = ((vm[j] >> e) & 1u) ? rs[r] * (d[r][j][e] - c1 - xh[r][j][e] * c2) : 0.f;
                         if (dres != nullptr) {
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] += rr[r][j][e];
@@ -523,14 +544,16 @@ inline int ew_grid(long n) {
     } while (0)
 
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                      long rows, int cols, float eps, hipStream_t s) {
+                      long rows, int cols, float eps, hipStream_t s, int pad_period, int pad_valid) {
+    BLT_REQUIRE((pad_period == 0 && pad_valid == 0) || (pad_period > 0 && pad_valid > 0 && pad_valid <= pad_period && cols % pad_period == 0),
+                "layernorm_fwd: bad pad pattern %d / %d for %d columns", pad_valid, pad_period, cols);
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_fwd: bad dtype");
     BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_fwd: cols=%d must be a multiple of 8 and <= %d", cols, LN_MAX_CHUNKS * 512);
     BLT_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
     const int grid = cdiv(rows, 4);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps),
-               hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps));
+               hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps, pad_period, pad_valid),
+               hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, pad_period, pad_valid));
     return blt_check_launch("layernorm_fwd");
 }
 
@@ -574,8 +597,10 @@ int blt_ln_param_reduce(const LnRedArgs& a, hipStream_t s) {
 
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
-                      const void* maskY, float mask_scale, void* out2, float* partials) {
+                      const void* maskY, float mask_scale, void* out2, float* partials, int pad_period, int pad_valid) {
     BLT_REQUIRE((maskY == nullptr) == (out2 == nullptr), "layernorm_bwd: maskY and out2 go together");
+    BLT_REQUIRE((pad_period == 0 && pad_valid == 0) || (pad_period > 0 && pad_valid > 0 && pad_valid <= pad_period && cols % pad_period == 0),
+                "layernorm_bwd: bad pad pattern %d / %d for %d columns", pad_valid, pad_period, cols);
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_bwd: bad dtype");
     BLT_REQUIRE(rows > 0 && cols > 0 && cols % 8 == 0 && cols <= LN_MAX_CHUNKS * 512, "layernorm_bwd: bad cols=%d", cols);
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
@@ -583,7 +608,7 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     if (grid < 1) grid = 1;
 #define LN_BWD_LAUNCH(T_, NCH_, R_)                                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NCH_, R_>), dim3(grid), dim3(256), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, \
-                       (const T_*)dres, (T_*)dx, dgamma, dbeta, rows, cols, (const T_*)maskY, mask_scale, (T_*)out2, partials)
+                       (const T_*)dres, (T_*)dx, dgamma, dbeta, rows, cols, (const T_*)maskY, mask_scale, (T_*)out2, partials, pad_period, pad_valid)
 #define LN_BWD_BY_COLS(T_)                                                                                                                 \
     do {                                                                                                                                    \
         if (cols <= 512) LN_BWD_LAUNCH(T_, 1, 4);                                                                                           \

@@ -17,7 +17,7 @@ F32, BF16 = _lib.F32, _lib.BF16
 
 def make_config(batch, hidden_dim, pwffn_dim, latent_dim, emb_dim, num_layers, num_heads, vocab_size, len_context=5,
                 len_posterior=21, len_target=20, image_hw=(224, 224), dtype=BF16, attention_dropout=0.1, relu_dropout=0.1,
-                kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1, num_regions=0, region_dim=0, region_pool=0):
+                kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1, num_regions=0, region_dim=0, region_pool=0, head_dim_true=0):
     """num_regions > 0: bottom-up feature mode (BASELINE configs[4]) — `images` is [B, num_regions, region_dim] fp32; region_pool = 0 mean
     over the regions, 1 (or "attention") region-attention pooling."""
     region_pool = {"mean": 0, "attention": 1}.get(region_pool, region_pool)
@@ -26,7 +26,7 @@ def make_config(batch, hidden_dim, pwffn_dim, latent_dim, emb_dim, num_layers, n
                   len_posterior=len_posterior, len_target=len_target, image_h=image_hw[0], image_w=image_hw[1], dtype=dtype,
                   attention_dropout=attention_dropout, relu_dropout=relu_dropout, kl_ceiling=kl_ceiling,
                   aux_ceiling=aux_ceiling, image_recon_lambda=image_recon_lambda, num_regions=num_regions, region_dim=region_dim,
-                  region_pool=int(region_pool))
+                  region_pool=int(region_pool), head_dim_true=int(head_dim_true))
 
 
 class ParamInfo(object):

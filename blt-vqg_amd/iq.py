@@ -12,6 +12,7 @@ import torch.nn as nn
 
 from . import _lib
 from .engine import StepEngine, make_config
+from .padded import PaddedLayout, needs_padding
 from .trainer import init_reference_style
 
 
@@ -56,6 +57,12 @@ class _IQFunction(torch.autograd.Function):
         model._step_seed += 1
         # autograd path: the nn.Parameters (views of the flat buffer) belong to whoever optimises them — a torch optimiser does not
         # tell the engine when it writes them, so no bf16 weight shadow written by an earlier FUSED step may be trusted here
+        if model._pad is not None:      # padded widths: the engine computes on ITS buffers; bring them (or the module) up to date first
+            model.sync_from_engine()
+            model._master = "module"
+            model._scatter_to_engine(eng)
+            if eps is not None and eps.shape[1] != eng.cfg.latent_dim:      # latent noise of the real width; the pad columns get none
+                eps = torch.nn.functional.pad(eps.float(), (0, eng.cfg.latent_dim - eps.shape[1]))
         eng.params_touched()
         eng.forward(images.contiguous().float(), answers.contiguous(), response.contiguous(), target.contiguous(),
                     None if eps is None else eps.contiguous().float(), phase2, model._base_seed + model._step_seed)
@@ -64,9 +71,15 @@ class _IQFunction(torch.autograd.Function):
         # still its own (a second forward of the same shape, or a second backward, would otherwise silently use the wrong ones)
         eng.generation = getattr(eng, "generation", 0) + 1
         ctx.eng, ctx.phase2, ctx.names, ctx.was_training = eng, phase2, model._train_names, bool(model.training)
+        ctx.model = model
         ctx.generation = eng.generation
         output = eng.read(0)
         feats, recon = eng.read(2), eng.read(3)
+        if model._pad is not None:
+            mh = model._pad.maps["H"][0].to(feats.device)
+            feats, recon = feats[:, mh].contiguous(), recon[:, mh].contiguous()      # back to the reference's 300 columns
+            if model.training:
+                model._gather_from_engine(eng, frozen_only=True)                     # BatchNorm running statistics
         stats = eng.read(4)
         if float(stats[6]) > 0:      # one host sync; the reference's loss code syncs five times per step (train_iq.py:98,103)
             raise _lib.HipError("%d token id(s) outside [0, %d) in the batch (vocabulary / dataset mismatch?)"
@@ -91,9 +104,26 @@ class _IQFunction(torch.autograd.Function):
                                "backward are not supported)")
         eng.generation += 1          # consumed: backward_external overwrites the logits with their gradient
         f = lambda t: None if t is None else t.contiguous().float()   # noqa: E731
+        model = ctx.model
+        if model._pad is not None:
+            mh = model._pad.maps["H"][0].to(eng.flat_grad.device)
+
+            def widen(t):      # gradients of the 300-wide feature tensors -> the engine's padded width (zeros at the pads)
+                if t is None:
+                    return None
+                o = torch.zeros(t.shape[0], eng.cfg.hidden_dim, device=t.device, dtype=torch.float32)
+                o[:, mh] = t.float()
+                return o
+            d_feats, d_recon = widen(d_feats), widen(d_recon)
         eng.backward_external(f(d_out), f(d_zl) if ctx.phase2 else None, float(d_kld) if (ctx.phase2 and d_kld is not None) else 0.0,
                               f(d_feats), f(d_recon))
         grads = []
+        if model._pad is not None:
+            flat_g = eng.flat_grad[model._pad_index(eng.flat_grad.device)[0]]
+            for n in ctx.names:
+                info = model._train_info[n]
+                grads.append(flat_g[info.offset:info.offset + info.numel].view(info.shape).clone() if (ctx.phase2 or not info.late) else None)
+            return (None, None, None, None, None, None) + tuple(grads)
         for n in ctx.names:
             info = eng.train_info[n]
             grads.append(eng.grad_view(n).clone() if (ctx.phase2 or not info.late) else None)
@@ -116,15 +146,16 @@ class IQ(nn.Module):
         self.args = args
         if num_att_layers != 2:
             raise ValueError("image_reconstructor is the reference's 2-layer MLP (iq.py:46-48)")
-        # The HIP kernels move activations in 16-byte vectors: every feature width must be a multiple of 8 elements.  The reference
-        # CLI defaults (train_iq.py:315-325: hidden_dim = latent_dim = 300, pwffn_dim = 600) are NOT; say so here instead of failing
-        # inside engine creation (the nearest supported widths are 304 / 304 / 608, or the BASELINE configurations 256 / 512).
-        bad = [(k, getattr(args, k)) for k in ("hidden_dim", "latent_dim", "pwffn_dim") if int(getattr(args, k)) % 8 != 0]
-        if bad or int(args.emb_dim) % 4 != 0 or int(args.hidden_dim) % int(args.num_heads) != 0:
-            raise ValueError("unsupported model widths for the MI355X engine: %s must be multiples of 8, emb_dim (%s) a multiple of 4 and "
-                             "hidden_dim divisible by num_heads (%s); e.g. --hidden_dim 304 --latent_dim 304 --pwffn_dim 608 in place of "
-                             "the reference defaults 300/300/600"
-                             % (", ".join("%s=%s" % kv for kv in bad) or "hidden_dim/latent_dim/pwffn_dim", args.emb_dim, args.num_heads))
+        # The HIP kernels move activations in 16-byte vectors and tile the head width: feature widths that are not multiples of 8 (the
+        # reference CLI defaults, train_iq.py:315-325: hidden_dim = latent_dim = 300, pwffn_dim = 600, 4 heads of 75) run on an engine
+        # with PADDED widths (hidden 320 = 4 heads of 80 columns with 75 real ones, latent 304); the parameters keep the reference's shapes here
+        # and are scattered into the padded layout (padded.py).  state_dict / checkpoints are unchanged.
+        if int(args.emb_dim) % 4 != 0 or int(args.hidden_dim) % int(args.num_heads) != 0 or int(args.hidden_dim) % 2 != 0:
+            raise ValueError("unsupported model widths for the MI355X engine: emb_dim (%s) must be a multiple of 4 and hidden_dim (%s) even and "
+                             "divisible by num_heads (%s)" % (args.emb_dim, args.hidden_dim, args.num_heads))
+        self._pad = (PaddedLayout(args.hidden_dim, args.latent_dim, args.pwffn_dim, args.num_heads)
+                     if needs_padding(int(args.hidden_dim), int(args.latent_dim), int(args.pwffn_dim), int(args.num_heads)) else None)
+        self._master = "module"        # padded mode: who holds the current parameter values, the module's buffers or the engine's
         self._dtype = _lib.F32 if getattr(args, "precision", "bf16") in ("fp32", "f32", 32) else _lib.BF16
         self._engines = {}
         self._primary = None
@@ -135,10 +166,14 @@ class IQ(nn.Module):
         probe = self._make_engine(1, 5, 21, 20, 224, 224, allocate=False)
         self._train_names = list(probe.train_info.keys())
         self._train_info, self._frozen_info = probe.train_info, probe.frozen_info
-        flat_t = torch.zeros(probe.train_size)
-        flat_f = torch.zeros(probe.frozen_size)
+        n_t, n_f = probe.train_size, probe.frozen_size
+        if self._pad is not None:      # reference-shaped parameters in a flat buffer of the module's own + the scatter index into the engine's
+            self._train_info, self._pad_train_index, n_t = self._pad.build(probe.train_info)
+            self._frozen_info, self._pad_frozen_index, n_f = self._pad.build(probe.frozen_info)
+        flat_t = torch.zeros(n_t)
+        flat_f = torch.zeros(n_f)
         self._install(flat_t, flat_f)
-        init_reference_style(SimpleNamespace(train_info=probe.train_info, frozen_info=probe.frozen_info, device=torch.device("cpu"),
+        init_reference_style(SimpleNamespace(train_info=self._train_info, frozen_info=self._frozen_info, device=torch.device("cpu"),
                                              view=self._cpu_view, lib=SimpleNamespace(bltvqg_engine_invalidate_frozen=lambda h: None), h=None),
                              seed=int(getattr(args, "seed", 0)), resnet_state=self._resnet_state(args))
         if getattr(args, "emb_file", None):
@@ -150,13 +185,61 @@ class IQ(nn.Module):
         # module.eval() (Lightning's validation loop): nn.Dropout is the identity
         p_attn = float(getattr(a, "attention_dropout", 0.1)) if training else 0.0
         p_relu = float(getattr(a, "relu_dropout", 0.1)) if training else 0.0
-        cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size, Sa, Sp, T,
+        H, F, Z, dht = self._widths()
+        cfg = make_config(B, H, F, Z, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size, Sa, Sp, T,
                           (h, w), self._dtype, p_attn, p_relu,
                           float(getattr(a, "kl_ceiling", 0.5)), float(getattr(a, "aux_ceiling", 1.0)),
                           float(getattr(a, "image_recon_lambda", 0.1)), int(getattr(a, "num_regions", 0) or 0),
-                          int(getattr(a, "region_dim", 0) or 0), getattr(a, "region_pool", 0) or 0)
+                          int(getattr(a, "region_dim", 0) or 0), getattr(a, "region_pool", 0) or 0, head_dim_true=dht)
         e = StepEngine(cfg, device if allocate else "cpu")
         return e
+
+    def _widths(self):
+        """(hidden, pwffn, latent, head_dim_true) the ENGINE is created with: the padded widths when the model's own are not tileable."""
+        a = self.args
+        if self._pad is None:
+            return int(a.hidden_dim), int(a.pwffn_dim), int(a.latent_dim), 0
+        return self._pad.Hp, self._pad.Fp, self._pad.Zp, self._pad.dh
+
+    # ---- padded mode: the module's flat buffers (reference shapes) <-> the engine's (padded) --------------------------------------
+    def _pad_index(self, dev):
+        if getattr(self, "_pad_index_dev", None) is None or self._pad_index_dev[0].device != dev:
+            self._pad_index_dev = (self._pad_train_index.to(dev), self._pad_frozen_index.to(dev))
+        return self._pad_index_dev
+
+    def _scatter_to_engine(self, eng):
+        """module -> engine: every real element to its padded position; the pads were zeroed at allocation and stay zero."""
+        it, if_ = self._pad_index(eng.flat_train.device)
+        with torch.no_grad():
+            eng.flat_train.index_copy_(0, it, self._flat_train.to(eng.flat_train.device))
+            eng.flat_frozen.index_copy_(0, if_, self._flat_frozen.to(eng.flat_frozen.device))
+        eng.params_changed()
+
+    def _gather_from_engine(self, eng, frozen_only=False):
+        it, if_ = self._pad_index(eng.flat_train.device)
+        with torch.no_grad():
+            if not frozen_only:
+                self._flat_train.copy_(eng.flat_train[it])
+            self._flat_frozen.copy_(eng.flat_frozen[if_])
+
+    def sync_from_engine(self):
+        """Padded mode, after fused steps (the engine's optimiser updates ITS buffers): bring the nn.Parameters up to date."""
+        if self._pad is not None and self._master == "engine" and self._primary is not None:
+            self._primary.optimizer_wait()
+            self._gather_from_engine(self._primary)
+
+    def sync_to_engine(self, for_fused=False):
+        """Padded mode: make the engine's buffers current before it runs on them; for_fused: the engine's optimiser owns them from now on."""
+        if self._pad is None or self._primary is None:
+            return
+        if self._master == "module":
+            self._scatter_to_engine(self._primary)
+        if for_fused:
+            self._master = "engine"
+
+    def state_dict(self, *a, **k):
+        self.sync_from_engine()
+        return super().state_dict(*a, **k)
 
     def _cpu_view(self, name, which=None):
         info = self._train_info.get(name) if which in (None, 0) and name in self._train_info else self._frozen_info[name]
@@ -220,6 +303,7 @@ class IQ(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._master = "module"
         for e in self._engines.values():
             e.lib.bltvqg_engine_invalidate_frozen(e.h)
         return r
@@ -228,8 +312,11 @@ class IQ(nn.Module):
         """True when the parameters still live inside the primary engine's flat buffers (False after .to()/.cuda()/.float())."""
         e = self._primary
         first, last = self._train_names[0], self._train_names[-1]
+        base = self._flat_train if self._pad is not None else e.flat_train      # padded mode: the module's own device buffers
+        if self._pad is not None and self._flat_train.device != e.flat_train.device:
+            return False
         for n in (first, last):
-            if self.get_parameter(n).data_ptr() != e.flat_train.data_ptr() + 4 * e.train_info[n].offset:
+            if self.get_parameter(n).data_ptr() != base.data_ptr() + 4 * self._train_info[n].offset:
                 return False
         return True
 
@@ -266,6 +353,22 @@ class IQ(nn.Module):
 
     def _adopt(self, eng):
         """Copies the current parameter values into the engine's flat device buffers and re-points the module tree at them."""
+        if self._pad is not None:
+            # padded mode: the module keeps flat buffers of its own (reference shapes) on the engine's device; values reach the engine's
+            # padded buffers through the scatter index
+            dev = eng.flat_train.device
+            sd = {k: v.detach() for k, v in super().state_dict().items()}
+            flat_t = torch.zeros(self._flat_train.numel(), device=dev)
+            flat_f = torch.zeros(self._flat_frozen.numel(), device=dev)
+            with torch.no_grad():
+                for name, info in self._train_info.items():
+                    flat_t[info.offset:info.offset + info.numel].view(info.shape).copy_(sd[name].to(dev, torch.float32))
+                for name, info in self._frozen_info.items():
+                    flat_f[info.offset:info.offset + info.numel].view(info.shape).copy_(sd[name].to(dev, torch.float32))
+            self._install(flat_t, flat_f)
+            self._master = "module"
+            self._scatter_to_engine(eng)
+            return
         with torch.no_grad():
             eng.load_state({k: v.detach() for k, v in self.state_dict().items()})
         self._install(eng.flat_train, eng.flat_frozen)
@@ -298,9 +401,11 @@ class IQ(nn.Module):
         eng = self._engines.get(key)
         if eng is None:
             a = self.args
-            cfg = make_config(B, a.hidden_dim, a.pwffn_dim, a.latent_dim, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size,
+            Hh, Ff, Zz, dht = self._widths()
+            cfg = make_config(B, Hh, Ff, Zz, a.emb_dim, a.num_layers, a.num_heads, self.vocab_size,
                               answers.shape[1], 21, T, (h, w), self._dtype, 0.0, 0.0, num_regions=int(getattr(a, "num_regions", 0) or 0),
-                              region_dim=int(getattr(a, "region_dim", 0) or 0), region_pool=getattr(a, "region_pool", 0) or 0)
+                              region_dim=int(getattr(a, "region_dim", 0) or 0), region_pool=getattr(a, "region_pool", 0) or 0,
+                              head_dim_true=dht)
             eng = StepEngine(cfg, images.device)
             if self._primary is None:
                 eng.allocate()
@@ -314,6 +419,10 @@ class IQ(nn.Module):
         phase2 = bool(self.latent_transformer)
         if phase2 and eps is None:
             eps = torch.randn(B, self.args.latent_dim, device=images.device, generator=self.eps_generator)
+        if self._pad is not None:
+            self.sync_to_engine()
+            if eps is not None and eps.shape[1] != eng.cfg.latent_dim:
+                eps = torch.nn.functional.pad(eps.float(), (0, eng.cfg.latent_dim - eps.shape[1]))
         tokens, top_idx, top_vals = eng.decode_greedy(images.contiguous().float(), answers.contiguous(),
                                                       None if eps is None else eps.contiguous().float(), phase2, train_bn=self.training)
         eos = self.vocab.word2idx[self.vocab.SYM_EOS] if hasattr(self.vocab, "SYM_EOS") else 3

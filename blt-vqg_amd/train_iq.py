@@ -169,6 +169,11 @@ class TrainIQ(_Base):
         if phase2:
             eps = batch["eps"].to(questions.device) if "eps" in batch else torch.randn(questions.shape[0], self.args.latent_dim,
                                                                                        device=questions.device)
+        # padded widths (models.IQ / padded.py): the engine's optimiser owns the (padded) parameter buffers from here on; the latent noise
+        # has the real width, the pad columns get none
+        self.model.sync_to_engine(for_fused=True)
+        if eps is not None and eps.shape[1] != eng.cfg.latent_dim:
+            eps = torch.nn.functional.pad(eps.float(), (0, eng.cfg.latent_dim - eps.shape[1]))
         w = kl_weight(self.kliter, self.args.full_kl_step) if phase2 else 0.0
         self.model._step_seed += 1
         self._dp.run(None if images is None else images.contiguous().float(), context.contiguous(), posteriors.contiguous(),

@@ -271,6 +271,14 @@ typedef struct bltvqg_config {
      * alpha = softmax_r(s), feature = sum_r alpha_r p_r -> the same BatchNorm1d.  w_a is the extra parameter
      * encoder_cnn.region_attn.weight [1, H].  Defined by this build, parity against the oracle's restatement only. */
     int32_t region_pool;
+    /* Padded model widths.  The kernels move activations in 16-byte vectors, so hidden_dim / latent_dim / pwffn_dim are multiples of 8
+     * and the head width hidden_dim / num_heads is what the attention kernels tile; the reference's CLI defaults (train_iq.py:315-325:
+     * hidden 300 = 4 heads x 75, latent 300, FFN 600) are not.  The host mirror (models.IQ) creates the engine with PADDED widths —
+     * hidden_dim = num_heads * round8(75) = 320, latent_dim 304 (pwffn_dim 600 needs none) — keeps every pad weight at zero and scatters the
+     * reference-shaped parameters into the padded layout; head_dim_true (75; 0 = not padded) tells the engine the real head width for
+     * the places where the width itself enters the arithmetic: LayerNorm mean / variance over the real features only (pad columns stay
+     * zero and get zero gradient), the 1/sqrt(d_head) attention scale, the MSE mean over B x true width, the sinusoid timing signal. */
+    int32_t head_dim_true;
 } bltvqg_config;
 
 typedef struct bltvqg_engine bltvqg_engine;

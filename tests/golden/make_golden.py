@@ -157,6 +157,12 @@ CONFIGS = {
     # tiny2: 2 layers, d_head=32, odd vocab, B=6 — exercises multi-layer accumulation paths
     "tiny2": dict(cfg=SimpleNamespace(emb_dim=36, hidden_dim=128, latent_dim=32, pwffn_dim=96, num_layers=2, num_heads=4,
                                       vocab_size=203), B=6, hw=64, seed=12, full=True),
+    # ref300: the reference's CLI default WIDTHS (train_iq.py:315-325: hidden 300 = 4 heads of 75, latent 300, FFN 600, emb 300) at one
+    # layer and a small vocabulary: exercises the padded engine layout (blt-vqg_amd/padded.py); samples + gradient norms + selected tensors
+    "ref300": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=300, latent_dim=300, pwffn_dim=600, num_layers=1, num_heads=4,
+                                       vocab_size=211), B=4, hw=64, seed=15, full=False, keep=(
+        "decoder.output.bias", "embedding.1.bias", "decoder.decoder.dec.0.multi_head_attention_dec.query_linear.weight",
+        "answer_encoder.encoder.enc.0.layer_norm_mha.weight", "latent_layer.mean_logvar_posterior.0.weight", "encoder_cnn.bn.weight")),
     # small = BASELINE.json configs[0] model (2-layer, d_model 256) at B=8, 224x224: summaries only
     "small": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=256, latent_dim=256, pwffn_dim=512, num_layers=2, num_heads=4,
                                       vocab_size=8000), B=8, hw=224, seed=13, full=False),
@@ -231,6 +237,9 @@ def main():
                     norms.append(g.double().norm().item())
                 out[tag + ".grad_names"] = np.array(names)
                 out[tag + ".grad_norms"] = np.array(norms)
+                for n in c.get("keep", ()):
+                    if n in res["grads"]:
+                        out["%s.grad.%s" % (tag, n)] = res["grads"][n].numpy()
             if not phase2:
                 for k, v in res["buffers"].items():
                     if c["full"] or k.startswith("encoder_cnn.bn.") or k.startswith("encoder_cnn.cnn.bn1."):

@@ -40,7 +40,7 @@ def test_ctypes_table_matches_header():
 
 def test_config_struct_layout():
     import ctypes
-    assert ctypes.sizeof(_lib.Config) == 14 * 4 + 5 * 4 + 3 * 4      # + num_regions, region_dim, region_pool
+    assert ctypes.sizeof(_lib.Config) == 14 * 4 + 5 * 4 + 3 * 4 + 4      # + num_regions, region_dim, region_pool; + head_dim_true
 
 
 def test_argument_validation_without_gpu():
@@ -57,6 +57,18 @@ def test_argument_validation_without_gpu():
                       len_context=5, len_posterior=21, len_target=20, image_h=64, image_w=64, dtype=0)
     import ctypes
     assert not lib.bltvqg_engine_create(ctypes.byref(cfg))     # hidden_dim % 8 != 0 is rejected
+    # bltvqg_gemm_ex goes through the same operand validation as bltvqg_gemm: a pitch below round8(K), a rowtab without its
+    # index and a dropout probability of 1 are argument errors, not out-of-bounds LDS-DMA reads on the device
+    buf = (ctypes.c_char * 4096)()
+    a16 = ctypes.c_void_p((ctypes.addressof(buf) + 15) // 16 * 16)
+
+    def gemm_ex(lda=64, ldb=64, rowtab=None, drop_p=0.0, tile=(0, 0)):
+        return lib.bltvqg_gemm_ex(a16, lda, a16, ldb, a16, 64, 256, 64, 64, None, rowtab, None, 64, 0, drop_p, 0, 0, None, 0, 1.0, None, 0, None, 0, 0,
+                                  tile[0], tile[1], None)
+    for kw, what in ((dict(lda=56), b"lda"), (dict(ldb=56), b"ldb"), (dict(rowtab=a16), b"rowtab"), (dict(drop_p=1.0), b"dropout"),
+                     (dict(tile=(64, 0)), b"tile")):
+        rc = gemm_ex(**kw)
+        assert rc < 0 and what in lib.bltvqg_last_error_string(), (kw, lib.bltvqg_last_error_string())
 
 
 def test_host_paths_under_address_sanitizer():

@@ -316,3 +316,80 @@ def test_fused_step_then_torch_optimizer_never_reads_a_stale_weight_shadow():
     want = fused_forward()
     assert torch.equal(got, want)
     assert float((got - output.detach()).abs().max()) > 1e-3      # and the torch step really moved the model
+
+
+@pytest.mark.parametrize("phase2", [False, True])
+def test_reference_default_widths_match_the_reference(phase2):
+    """The reference's CLI default widths (train_iq.py:315-325: hidden 300 = 4 heads of 75, latent 300, FFN 600) through the padded engine
+    layout (blt-vqg_amd/padded.py), fp32 engine, against the fixture the reference itself produced (tests/golden/make_golden.py ref300):
+    loss within 1e-3 (north_star), argmax token ids bit-exact, gradients of the reference-shaped parameters <= 3e-3."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    z, cfg, state, batch = load_golden("ref300")
+    assert (cfg.hidden_dim, cfg.latent_dim, cfg.pwffn_dim, cfg.num_heads) == (300, 300, 600, 4)
+    tag = "p2" if phase2 else "p1"
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")
+    if phase2:
+        t.latent_transformer = True
+        t.model.switch_GVT_train_mode(True)
+        t.kliter = int(z[tag + ".kliter"])
+    b = {k: v.cuda() for k, v in batch.items()}
+    output, z_logit, kld, recon = t(b)
+    assert output.shape == (4, 20, cfg.vocab_size) and recon[0].shape == (4, 300) and recon[1].shape == (4, 300)
+    idx = torch.from_numpy(z[tag + ".output_idx"]).cuda()
+    assert rel_err(output.detach().reshape(-1)[idx].cpu(), z[tag + ".output_sample"]) < 2e-4
+    assert np.array_equal(output.argmax(-1).cpu().numpy().astype(np.int32), z[tag + ".argmax"])
+    assert rel_err(recon[0].detach().cpu(), z[tag + ".feats"]) < 2e-4 and rel_err(recon[1].detach().cpu(), z[tag + ".recon"]) < 2e-4
+    loss = t.calculate_losses(output, recon, kld, z_logit, b["questions"])[0]
+    assert abs(float(loss) - float(z[tag + ".loss"])) < 1e-3, (float(loss), float(z[tag + ".loss"]))
+    loss.backward()
+    names = [str(s_) for s_ in z[tag + ".grad_names"]]
+    norms = z[tag + ".grad_norms"]
+    params = dict(t.model.named_parameters())
+    for n_, g in zip(names, norms):
+        got = float(params[n_].grad.double().norm())
+        assert abs(got - g) <= 3e-3 * max(g, 1e-6) + 1e-7, (n_, got, g)
+    for k in z.files:
+        if k.startswith(tag + ".grad.") and not k.endswith(("grad_names", "grad_norms")):
+            n_ = k[len(tag) + 6:]
+            assert rel_err(params[n_].grad.cpu(), z[k]) < 3e-3, n_
+    if not phase2:          # BatchNorm running statistics reach the reference-shaped buffers
+        for k in z.files:
+            if k.startswith("p1.buf.") and "num_batches" not in k:
+                assert rel_err(t.model.state_dict()[k[7:]].cpu(), z[k]) < 1e-4, k
+
+
+def test_reference_default_widths_fused_steps_and_checkpoint(tmp_path):
+    """Fused training steps on the padded engine: the pad entries of every weight stay exactly zero (zero gradient, zero Adam step), the
+    nn.Parameters follow the engine's optimiser (state_dict gathers them), bf16 runs, and a checkpoint round-trips at reference shapes."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    z, cfg, state, batch = load_golden("ref300")
+    for precision in ("fp32", "bf16"):
+        t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg, precision=precision, num_pretraining_steps=1, attention_dropout=0.1, relu_dropout=0.1))
+        t.model.load_state_dict(_full_state(t.model, state))
+        t = t.to("cuda")
+        b = {k: v.cuda() for k, v in batch.items()}
+        before = {k: v.clone() for k, v in t.model.state_dict().items()}
+        losses = []
+        for _ in range(4):                                     # crosses the phase switch (latent nets start receiving gradients)
+            t.fused_training_step(b)
+            losses.append(t.last_stats()["loss"])
+        assert all(np.isfinite(losses)), losses
+        eng = t._last_engine
+        eng.optimizer_wait()
+        real = torch.zeros(eng.train_size, dtype=torch.bool, device="cuda")
+        real[t.model._pad_index(real.device)[0]] = True
+        assert float(eng.flat_train[~real].abs().max()) == 0.0          # pads: zero weights ...
+        assert float(eng.flat_grad[~real].abs().max()) == 0.0           # ... zero gradients
+        after = t.model.state_dict()
+        assert after["decoder.output.weight"].shape == (cfg.vocab_size, 300)
+        moved = sum(float((after[k].float() - before[k].float()).abs().max()) > 0 for k in before if "num_batches" not in k and "encoder_cnn.cnn.layer" not in k)
+        assert moved > 50
+        path = str(tmp_path / ("ref300_%s.ckpt" % precision))
+        t.save_checkpoint(path)
+        t2 = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg, precision=precision, num_pretraining_steps=1))
+        t2.load_checkpoint(path)
+        sd2 = t2.model.state_dict()
+        for k in after:
+            assert torch.equal(after[k].cpu().float(), sd2[k].cpu().float()), k

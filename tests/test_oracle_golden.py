@@ -53,11 +53,12 @@ def test_bn_running_stats_match_reference():
     assert n > 50
 
 
-@pytest.mark.parametrize("name", ["small", "big"])
+@pytest.mark.parametrize("name", ["small", "big", "ref300"])
 @pytest.mark.parametrize("phase2", [False, True])
 def test_oracle_matches_reference_small_cfg(name, phase2):
-    """BASELINE.json configs[0..1] model (2-layer d_model 256, 224x224 images) at B=8 and configs[2..3] model (6-layer d_model 512,
-    8 heads, F 2048) at B=4: summary fixtures produced by the reference."""
+    """BASELINE.json configs[0..1] model (2-layer d_model 256, 224x224 images) at B=8, configs[2..3] model (6-layer d_model 512,
+    8 heads, F 2048) at B=4, and the reference's CLI default widths (hidden 300 = 4 heads of 75, latent 300, FFN 600; train_iq.py:315-325):
+    summary fixtures produced by the reference."""
     z, cfg, state, batch = load_golden(name)
     tag = "p2" if phase2 else "p1"
     r = oracle_run(cfg, state, batch, phase2, kliter=int(z[tag + ".kliter"]))

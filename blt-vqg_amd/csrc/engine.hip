@@ -107,7 +107,7 @@ struct bltvqg_engine {
     // params_gen: bumped by every write to the shared parameters.  opt_gen / opt_done_ev: the asynchronous optimiser update (below) is a
     // write to the SHARED buffers, so "an update is in flight" belongs here too: every engine sharing them orders itself behind the
     // latest update it has not yet waited for (engine B's forward must not run under engine A's in-flight Adam).
-    struct AdamSteps { int main = 0, late = 0; long params_gen = 0; long opt_gen = 0; hipEvent_t opt_done_ev = nullptr; };
+    struct AdamSteps { int main = 0, late = 0; long params_gen = 0; long opt_gen = 0; hipEvent_t opt_done_ev = nullptr, opt_stage1_ev = nullptr; };
     std::shared_ptr<AdamSteps> steps = std::make_shared<AdamSteps>();
     int last_bwd_phase2 = 0;
     // workspace buffers
@@ -218,7 +218,13 @@ struct bltvqg_engine {
     // the consumers of trainable parameters wait for them: the frozen CNN (45 % of a step) starts at once, hiding the optimiser and
     // the tail of the all-reduce.  Every other entry point first orders itself behind the pending update (sync_opt).
     hipStream_t opt_stream = nullptr;
-    hipEvent_t opt_fork = nullptr, opt_done = nullptr;
+    hipEvent_t opt_fork = nullptr, opt_done = nullptr, opt_stage1 = nullptr;
+    // Staged update: Adam runs over the parameters in the order the NEXT forward needs them — first the two encoder stacks, the shared
+    // embedding and the CNN head (stage 1, its own event), then the decoder, vocabulary projection, reconstructor and the latent-phase heads
+    // (stage 2).  The next forward's token / encoder streams wait for stage 1 only, so stage 2 (half of the 2.2 GB pass), the decoder's
+    // transposed weight shadows and the gradient memset run underneath the encoder stacks instead of in front of them.
+    int64_t dec_end = 0, renc_off = 0;            // [0, dec_end): stage-2 part of the main region; [renc_off, tsize): stage-1 part of the late region
+    int t_dec_n = 0, t_main_n = 0, t_heads_n = 0; // tlist ranges: [0, t_dec_n) decoder side, [.., t_main_n) encoder + embedding, [.., t_heads_n) late heads, rest r_encoder
     long opt_seen = 0;           // the shared opt_gen this engine's caller stream is already ordered behind
     bool opt_is_pending() const { return opt_seen != steps->opt_gen; }
     void opt_mark_synced() { opt_seen = steps->opt_gen; }
@@ -365,6 +371,7 @@ struct bltvqg_engine {
             if (l > 0 && (tsize - bucket_start) * 4 >= BUCKET_TARGET_BYTES) dec_flush[l] = close_bucket(0);
         }
         const int t_dec_last = close_bucket(0);
+        dec_end = tsize;
         add_enc_stack("answer_encoder.encoder", 0, enc_flush);
         const int t_enc_last = close_bucket(0);
         add_t("embedding.1.weight", H, E, 0);
@@ -392,6 +399,7 @@ struct bltvqg_engine {
             add_t(std::string(nets[n]) + ".6.bias", 2 * Z, 0, 1);
         }
         const int t_late0 = close_bucket(1);
+        renc_off = tsize;
         add_enc_stack("answer_encoder.r_encoder", 1, renc_flush);
         const int t_renc_last = close_bucket(1);
         // completion order: the decoder's groups, the latent-phase heads (final with the decoder's last flush), the two encoder stacks'
@@ -431,6 +439,11 @@ struct bltvqg_engine {
             ttiles += ((rows + 63) / 64) * ((p.dims[1] + 63) / 64);
             tlist.push_back(t);
             if (tr) trows[p.off] = rows;
+        }
+        for (const TEnt& t : tlist) {      // (tlist is in parameter order)
+            if (t.off < dec_end) ++t_dec_n;
+            if (t.off < late_off) ++t_main_n;
+            if (t.off < renc_off) ++t_heads_n;
         }
 
         // ---- frozen backbone (torchvision resnet18 names, encoder_cnn.py:17) + running statistics ----
@@ -1165,17 +1178,42 @@ struct bltvqg_engine {
         // loss statistics [0..3]; [4] (gradient norm) belongs to the optimiser, which may still be reading it
         if (hipMemsetAsync(stats - 1, 0, 5 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
         if (overlap_opt) {
-            // the frozen CNN does not depend on the update: it is enqueued first, everything else goes behind the optimiser
+            // The frozen CNN does not depend on the update: it is enqueued first (unless it ran ahead: then the encoders' launches are),
+            // everything else goes behind the optimiser — the token / encoder streams behind its FIRST stage only (embedding + encoder
+            // parameters), the caller's stream behind the whole update, where the decoder-side weight shadows and the gradient memset
+            // then run underneath the encoder stacks.
             hipStream_t s0 = side[0];
+            const bool staged = steps->opt_stage1_ev != nullptr && blt_debug_get(20) != 1;
+            const bool derive = shadows_current();
             RC(fork(s, s0, fj[0]));
-            RC(cnn_fwd(images, s));
-            stamp(11, s);
-            RC(sync_opt(s0));
-            if (bn_train) RC(zero_grads_early(s0));
-            RC(forward_tokens(ctx, post, tgt, s0, s0));
+            const bool ahead = pf_n > 0;
+            if (!ahead) { RC(cnn_fwd(images, s)); stamp(11, s); }
+            if (staged) {
+                if (hipStreamWaitEvent(s0, steps->opt_stage1_ev, 0) != hipSuccess) { blt_set_error("engine_forward: optimiser wait failed"); return BLT_ERR_HIP; }
+                RC(shadows(s0, 1, derive));
+            } else {
+                RC(sync_opt(s0));
+                RC(shadows(s0, 3, derive));
+                if (bn_train) RC(zero_grads_early(s0));
+            }
+            RC(forward_tokens(ctx, post, tgt, s0, s0, false));
+            // Stage-2 consumers (decoder-side shadows, gradient memset) need the WHOLE update.  side[1] is the optimiser's own stream, so
+            // work enqueued there is behind it by stream order: with the conv stack inline on `s` (the long pole of this phase) they go
+            // there, in front of the context encoder (the shorter of the two stacks); with the stack run ahead `s` has nothing else to do.
+            if (staged && !ahead) {
+                RC(sync_opt(side[1]));      // (an engine that shares the parameters with the one whose stream ran the update is not behind it)
+                RC(shadows(side[1], 2, derive));
+                if (bn_train) RC(zero_grads_early(side[1]));
+            }
             RC(fork(s0, side[1], fj[1]));
             RC(stack_fwd(enc, nullptr, nullptr, side[1]));
             RC(stack_fwd(renc, nullptr, nullptr, s0));
+            if (ahead) { RC(cnn_fwd(images, s)); stamp(11, s); }      // (waits for the prefetched feature and the whole update, then the head)
+            if (staged && ahead) {
+                RC(shadows(s, 2, derive));
+                if (bn_train) RC(zero_grads_early(s));
+            }
+            shadows_done(derive);
             RC(fork(s0, s, fj[2]));
             RC(fork(side[1], s, fj[3]));
             opt_mark_synced();            // s is now ordered behind the update
@@ -1201,14 +1239,34 @@ struct bltvqg_engine {
 
     // weight shadows, token preparation (on `s`), then the shared embedding of the three token streams (on `se`, forked from `s`
     // unless they are the same stream)
-    int forward_tokens(const int64_t* ctx, const int64_t* post, const int64_t* tgt, hipStream_t s, hipStream_t se) {
-        // bf16 shadows of every GEMM weight (plain + transposed) in one launch; biases / LayerNorm / embedding rows are read in fp32
-        if (dt == BLT_BF16 && !tlist.empty()) {
-            if (trust_shadows && shadow_gen == steps->params_gen) RC(blt_shadow_transpose_bf16(wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
-            else {
-                RC(blt_shadow_transpose(train, wshadow, wshadowT, ttable, (int)tlist.size(), ttiles, s));
-                shadow_gen = steps->params_gen;        // the plain shadow mirrors the parameters as of now
-            }
+    // bf16 shadows of the GEMM weights (plain + transposed; biases / LayerNorm / embedding rows are read in fp32).  parts: bit 0 = the
+    // parameters the token / encoder path reads (two encoder stacks, shared embedding), bit 1 = the rest (decoder, vocabulary projection,
+    // reconstructor, latent-phase heads); 3 = everything, one launch.  derive: only the transposed copies, from the plain shadow the
+    // optimiser pass keeps current (shadows_current()); else both are rebuilt from the fp32 parameters.
+    bool shadows_current() const { return trust_shadows && shadow_gen == steps->params_gen; }
+    void shadows_done(bool derive) { if (!derive) shadow_gen = steps->params_gen; }      // the plain shadow mirrors the parameters as of now
+    int shadow_range(int e0, int e1, bool derive, hipStream_t s) {
+        if (e1 <= e0) return BLT_OK;
+        const int t0 = tlist[e0].tile0, t1 = (e1 < (int)tlist.size()) ? tlist[e1].tile0 : ttiles;
+        if (t1 <= t0) return BLT_OK;
+        const char* tab = (const char*)ttable + (size_t)e0 * sizeof(TEnt);
+        if (derive) return blt_shadow_transpose_bf16(wshadow, wshadowT, tab, e1 - e0, t1 - t0, s, t0);
+        return blt_shadow_transpose(train, wshadow, wshadowT, tab, e1 - e0, t1 - t0, s, t0);
+    }
+    int shadows(hipStream_t s, int parts, bool derive) {
+        if (dt != BLT_BF16 || tlist.empty()) return BLT_OK;
+        const int n = (int)tlist.size();
+        if (parts == 3) return shadow_range(0, n, derive, s);
+        if (parts & 1) { RC(shadow_range(t_dec_n, t_main_n, derive, s)); RC(shadow_range(t_heads_n, n, derive, s)); }
+        if (parts & 2) { RC(shadow_range(0, t_dec_n, derive, s)); RC(shadow_range(t_main_n, t_heads_n, derive, s)); }
+        return BLT_OK;
+    }
+
+    int forward_tokens(const int64_t* ctx, const int64_t* post, const int64_t* tgt, hipStream_t s, hipStream_t se, bool with_shadows = true) {
+        if (with_shadows) {
+            const bool derive = shadows_current();
+            RC(shadows(s, 3, derive));
+            shadows_done(derive);
         }
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         RC(blt_prep_tokens((const long long*)ctx, (const long long*)post, (const long long*)tgt, B, Sa, Sp, T, ids_all, pos_all, tgt_shift,
@@ -1627,20 +1685,22 @@ struct bltvqg_engine {
             RC(fork(s_in, opt_stream, opt_fork));
             s = opt_stream;
         }
-        const int rc_ = optimizer_kernels(lr, max_norm, b1, b2, eps, s);
+        const int rc_ = optimizer_kernels(lr, max_norm, b1, b2, eps, s, async_);
         if (rc_) return rc_;
         if (async_) {
             if (hipEventRecord(opt_done, opt_stream) != hipSuccess) { blt_set_error("engine_optimizer_step: event record failed"); return BLT_ERR_HIP; }
             ++steps->opt_gen;                 // every engine sharing these buffers (this one included) now has an update to wait for
             steps->opt_done_ev = opt_done;
+            steps->opt_stage1_ev = opt_stage1;
+        } else {
+            steps->opt_stage1_ev = nullptr;
         }
         return BLT_OK;
     }
-    int optimizer_kernels(float lr, float max_norm, float b1, float b2, float eps, hipStream_t s) {
-        const int64_t n_main = late_off, n_late = tsize - late_off;
+    int optimizer_kernels(float lr, float max_norm, float b1, float b2, float eps, hipStream_t s, bool staged) {
         if (hipMemsetAsync(stats + 4, 0, sizeof(float), s) != hipSuccess) return BLT_ERR_HIP;
         // the latent-phase parameters sit right behind the others in the flat buffers: one launch covers both regions when both are live
-        RC(blt_sumsq(grad, last_bwd_phase2 ? tsize : n_main, stats + 4, s));
+        RC(blt_sumsq(grad, last_bwd_phase2 ? tsize : late_off, stats + 4, s));
         const int step_main = ++steps->main;
         if (last_bwd_phase2) ++steps->late;
         const int step_late = steps->late;
@@ -1650,12 +1710,18 @@ struct bltvqg_engine {
         const bool was_valid = shadow_gen == steps->params_gen;
         ++steps->params_gen;
         shadow_gen = (sh && (last_bwd_phase2 || was_valid)) ? steps->params_gen : -1;
-        if (last_bwd_phase2 && step_late == step_main)      // same bias correction: one launch (only when training began in phase 2)
-            return blt_adam_step(train, grad, adam_m, adam_v, tsize, stats + 4, max_norm, lr, b1, b2, eps, step_main, s, sh);
-        RC(blt_adam_step(train, grad, adam_m, adam_v, n_main, stats + 4, max_norm, lr, b1, b2, eps, step_main, s, sh));
-        if (last_bwd_phase2)
-            RC(blt_adam_step(train + late_off, grad + late_off, adam_m + late_off, adam_v + late_off, n_late, stats + 4, max_norm, lr, b1, b2,
-                             eps, step_late, s, sh ? sh + (size_t)late_off * 2 : nullptr));
+        auto seg = [&](int64_t lo, int64_t hi, int step) -> int {
+            if (hi <= lo) return BLT_OK;
+            return blt_adam_step(train + lo, grad + lo, adam_m + lo, adam_v + lo, hi - lo, stats + 4, max_norm, lr, b1, b2, eps, step, s,
+                                 sh ? sh + (size_t)lo * 2 : nullptr);
+        };
+        // stage 1: what the next forward reads first — context encoder, shared embedding, CNN head | posterior encoder
+        RC(seg(dec_end, late_off, step_main));
+        if (last_bwd_phase2) RC(seg(renc_off, tsize, step_late));
+        if (staged && hipEventRecord(opt_stage1, s) != hipSuccess) { blt_set_error("engine_optimizer_step: event record failed"); return BLT_ERR_HIP; }
+        // stage 2: vocabulary projection, reconstructor, decoder | z_classifier, latent projection, latent nets
+        RC(seg(0, dec_end, step_main));
+        if (last_bwd_phase2) RC(seg(late_off, renc_off, step_late));
         return BLT_OK;
     }
 #undef RC
@@ -1702,9 +1768,11 @@ void bltvqg_engine_destroy(bltvqg_engine* e) {
         if (e->steps->opt_done_ev == e->opt_done) {      // an update of this engine may still be in flight for the engines sharing its state
             (void)hipEventSynchronize(e->opt_done);
             e->steps->opt_done_ev = nullptr;
+            e->steps->opt_stage1_ev = nullptr;
         }
         (void)hipEventDestroy(e->opt_done);
     }
+    if (e->opt_stage1) (void)hipEventDestroy(e->opt_stage1);
     for (size_t i = 0; i < e->prof.size(); ++i) { (void)hipEventDestroy(e->prof[i].a); (void)hipEventDestroy(e->prof[i].b); }
     delete e;
 }
@@ -1788,6 +1856,7 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
         }
     e->pf_n = 0; e->pool_in_use = false;
     if ((!e->opt_fork && hipEventCreateWithFlags(&e->opt_fork, hipEventDisableTiming) != hipSuccess) ||
+        (!e->opt_stage1 && hipEventCreateWithFlags(&e->opt_stage1, hipEventDisableTiming) != hipSuccess) ||
         (!e->opt_done && hipEventCreateWithFlags(&e->opt_done, hipEventDisableTiming) != hipSuccess)) {
         blt_set_error("engine_bind: event creation failed");
         return BLT_ERR_HIP;

@@ -218,9 +218,9 @@ int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, 
 int blt_conv_pack_w(int dtype, const float* w, void* out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad, hipStream_t s);
 int blt_copy2d(int dtype, const void* src, int lds_, void* dst, int ldd, long rows, int cols, hipStream_t s);
 // table_dev: int4 {element offset, rows, cols, first 64x64 tile} per matrix; dst_bf16 may be null (transposed copy only)
-int blt_shadow_transpose(const float* src, void* dst_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s);
+int blt_shadow_transpose(const float* src, void* dst_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s, int tile_base = 0);
 // transposed shadows only, from the plain bf16 shadow (kept current by blt_adam_step's shadow output)
-int blt_shadow_transpose_bf16(const void* src_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s);
+int blt_shadow_transpose_bf16(const void* src_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s, int tile_base = 0);
 
 // ---- losses ------------------------------------------------------------------------------------
 // token CE with ignore_index=0, mean over non-pad targets (count from counters[0]); writes d(logits) IN PLACE scaled by

@@ -171,15 +171,16 @@ __global__ void cast_rows_kernel(const TS* __restrict__ src, int lds_, TD* __res
 // `dstT` as the TRANSPOSE [cols, rows] (leading dimension rows).  The transposed copy turns the input-gradient GEMM
 // dX = dY W into the k-contiguous (NT) form that the LDS-DMA kernel takes.  One launch for the whole parameter buffer.
 __global__ __launch_bounds__(256) void shadow_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, bf16* __restrict__ dstT,
-                                                              const int4* __restrict__ table, int nent) {
+                                                              const int4* __restrict__ table, int nent, int tile_base) {
     __shared__ float tile[64][65];
+    const int bid = (int)blockIdx.x + tile_base;      // (a launch may cover a sub-range of the table: `table` points at its first entry)
     int e = 0;
-    while (e + 1 < nent && (int)blockIdx.x >= table[e + 1].w) ++e;          // uniform scan, <= a few dozen entries
+    while (e + 1 < nent && bid >= table[e + 1].w) ++e;          // uniform scan, <= a few dozen entries
     const int4 t = table[e];
     const int off = t.x, rows = t.y, cols = t.z < 0 ? -t.z : t.z;
     const bool transposed = t.z > 0;          // cols < 0: plain shadow only (rows not a multiple of 8)
     const int tiles_c = (cols + 63) >> 6;
-    const int lt = (int)blockIdx.x - t.w;
+    const int lt = bid - t.w;
     const int r0 = (lt / tiles_c) << 6, c0 = (lt % tiles_c) << 6;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
@@ -672,16 +673,17 @@ __global__ __launch_bounds__(256) void adam_scalar_kernel(float* __restrict__ p,
 // transposed bf16 shadows from the PLAIN bf16 shadow (which the optimiser pass above keeps current): same table as
 // shadow_transpose_kernel, half the bytes (no fp32 read, no plain write)
 __global__ __launch_bounds__(256) void shadow_transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dstT, const int4* __restrict__ table,
-                                                                   int nent) {
+                                                                   int nent, int tile_base) {
     // 64 x 64 tile through LDS; both sides move 4 bytes (2 bf16) per lane — a 2-byte-per-lane version ran at 1.5 TB/s
     __shared__ unsigned short tile[64][66];
+    const int bid = (int)blockIdx.x + tile_base;      // (a launch may cover a sub-range of the table: `table` points at its first entry)
     int e = 0;
-    while (e + 1 < nent && (int)blockIdx.x >= table[e + 1].w) ++e;
+    while (e + 1 < nent && bid >= table[e + 1].w) ++e;
     const int4 t = table[e];
     if (t.z <= 0) return;                      // plain shadow only
     const int off = t.x, rows = t.y, cols = t.z;
     const int tiles_c = (cols + 63) >> 6;
-    const int lt = (int)blockIdx.x - t.w;
+    const int lt = bid - t.w;
     const int r0 = (lt / tiles_c) << 6, c0 = (lt % tiles_c) << 6;
     const unsigned short* s16 = reinterpret_cast<const unsigned short*>(src) + (size_t)off;
     unsigned short* d16 = reinterpret_cast<unsigned short*>(dstT) + (size_t)off;
@@ -882,9 +884,10 @@ static int cast_rows_impl(int dtype_src, const void* src, int lds_, int dtype_ds
     return blt_check_launch("cast_rows");
 }
 
-int blt_shadow_transpose(const float* src, void* dst_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s) {
-    BLT_REQUIRE(src && dstT_bf16 && table_dev && nent > 0 && total_tiles > 0, "shadow_transpose: bad args");
-    hipLaunchKernelGGL(shadow_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, src, (bf16*)dst_bf16, (bf16*)dstT_bf16, (const int4*)table_dev, nent);
+// table_dev points at the FIRST entry of the range to process, nent entries, whose tiles are [tile_base, tile_base + total_tiles)
+int blt_shadow_transpose(const float* src, void* dst_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s, int tile_base) {
+    BLT_REQUIRE(src && dstT_bf16 && table_dev && nent > 0 && total_tiles > 0 && tile_base >= 0, "shadow_transpose: bad args");
+    hipLaunchKernelGGL(shadow_transpose_kernel, dim3(total_tiles), dim3(256), 0, s, src, (bf16*)dst_bf16, (bf16*)dstT_bf16, (const int4*)table_dev, nent, tile_base);
     return blt_check_launch("shadow_transpose");
 }
 
@@ -1034,9 +1037,9 @@ int blt_adam_step(float* p, const float* g, float* m, float* v, long n, const fl
     return blt_check_launch("adam");
 }
 
-int blt_shadow_transpose_bf16(const void* src_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s) {
-    BLT_REQUIRE(src_bf16 && dstT_bf16 && table_dev && nent > 0 && total_tiles > 0, "shadow_transpose_bf16: bad args");
-    hipLaunchKernelGGL(shadow_transpose_bf16_kernel, dim3(total_tiles), dim3(256), 0, s, (const bf16*)src_bf16, (bf16*)dstT_bf16, (const int4*)table_dev, nent);
+int blt_shadow_transpose_bf16(const void* src_bf16, void* dstT_bf16, const void* table_dev, int nent, int total_tiles, hipStream_t s, int tile_base) {
+    BLT_REQUIRE(src_bf16 && dstT_bf16 && table_dev && nent > 0 && total_tiles > 0 && tile_base >= 0, "shadow_transpose_bf16: bad args");
+    hipLaunchKernelGGL(shadow_transpose_bf16_kernel, dim3(total_tiles), dim3(256), 0, s, (const bf16*)src_bf16, (bf16*)dstT_bf16, (const int4*)table_dev, nent, tile_base);
     return blt_check_launch("shadow_transpose_bf16");
 }
 

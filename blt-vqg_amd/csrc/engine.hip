@@ -1478,7 +1478,9 @@ struct bltvqg_engine {
             // in-stack flush points (build_params: groups of whole layers of >= ~32 MB of parameters): the collected weight gradients go
             // to the weight-gradient stream now, run under the rest of THIS chain and close a gradient bucket, whose all-reduce (N > 1)
             // can start while backward is still running.  only while group_flush is on (a data-parallel exchange exists)
-            if (defer_wgrads && group_flush && flush_plan && (*flush_plan)[l] >= 0) RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
+            // (debug key 21, A/B: bit mask of the stacks that flush in-stack although no exchange asked for it: 1 decoder, 2 context, 4 posterior)
+            const bool forced = (blt_debug_get(21) >> (st.dec ? 0 : (st.id == 0 ? 1 : 2))) & 1;
+            if (defer_wgrads && (group_flush || forced) && flush_plan && (*flush_plan)[l] >= 0) RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
         }
         return BLT_OK;
     }

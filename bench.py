@@ -432,6 +432,32 @@ def main():
             "ms_per_step": round(dt_h / n * 1e3, 3), "pairs_per_s": round(B * world * n / dt_h, 1), "steps": n,
             "what": "same step, batch resident in HBM" if a.h2d else
                     "same step fed from a pinned host batch copied over PCIe every step, one step ahead on a copy stream (never the headline value)"}
+    if use_prefetch and not a.h2d and not a.no_extras and a.extra_steps > 0:
+        # How much of the conv stack the look-ahead hides: the stack alone and the rest of the step alone, each between
+        # device synchronisations (median of 8), against the overlapped steady state of the timed loop.
+        import statistics
+        switch_feed("resident", phase2, 0)
+        tc, tch = [], []
+        for i in range(10):
+            eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+            if eng.prefetch_pending() == 0:
+                eng.prefetch_images(d["images"])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step.run(None, d["answers"], d["posteriors"], d["questions"], eps, phase2, seed=2000 + i, kl_weight=HP["kl_weight"], lr=HP["lr"],
+                     max_norm=HP["max_norm"])
+            step.finish()
+            torch.cuda.synchronize()
+            tch.append((time.perf_counter() - t0) * 1e3)
+            t0 = time.perf_counter()
+            eng.prefetch_images(d["images"])
+            torch.cuda.synchronize()
+            tc.append((time.perf_counter() - t0) * 1e3)
+        conv_ms, chain_ms, ov_ms = statistics.median(tc[2:]), statistics.median(tch[2:]), dt / a.steps * 1e3
+        extras["overlap"] = {"conv_stack_alone_ms": round(conv_ms, 3), "rest_of_step_alone_ms": round(chain_ms, 3), "overlapped_ms": round(ov_ms, 3),
+                             "conv_stack_hidden_frac": round(max(0.0, conv_ms + chain_ms - ov_ms) / conv_ms, 3),
+                             "what": "frozen conv stack of batch i+1 (20 convolutions + BatchNorm2d + pool) on the look-ahead stream vs everything else of "
+                                     "step i; the two share the per-CU L2->LDS intake, DESIGN.md section 5c"}
     if dist and not a.no_extras and a.extra_steps > 0:
         # exposed communication per step (HIP events: end of backward on the step's stream -> end of the last all-reduce on the
         # communication stream), measured in a loop of its own so that the event pairs are not inside the headline's timed region

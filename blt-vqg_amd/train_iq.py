@@ -143,10 +143,24 @@ class TrainIQ(_Base):
         return self._optimizer
 
     # ---- fused path ----------------------------------------------------------------------------------------------------
-    def fused_training_step(self, batch, dist=None):
-        """One full reference training step inside the HIP engine.  Returns nothing; `last_stats()` syncs and reads the losses."""
+    def _images_on_device(self, batch):
+        """The batch's image tensor as the engine takes it (device, fp32, contiguous) — cached per batch object, so that the tensor handed
+        to the conv look-ahead as `next_batch` is the very one the next step passes."""
+        c = getattr(self, "_img_cache", None)
+        if c is not None and c[0] is batch:
+            return c[1]
+        t = batch["images"].to(self._device()).contiguous().float()
+        self._img_cache = (batch, t)
+        return t
+
+    def fused_training_step(self, batch, dist=None, next_batch=None):
+        """One full reference training step inside the HIP engine.  Returns nothing; `last_stats()` syncs and reads the losses.
+        next_batch (optional, one GPU, image mode): the batch of the NEXT call — its frozen ResNet-18 forward is enqueued one batch ahead
+        (models/encoder_cnn.py:18-19 freezes the backbone; DataParallelStep.run(next_images=...))."""
         self._phase_switch()
         images, context, posteriors, questions = self._unpack(batch)
+        if images is not None:
+            images = self._images_on_device(batch)
         if images is None:      # DeviceBatchProducer.batch(engine=...) wrote the images into this engine's packed stem input
             eng = batch["engine"]
         else:
@@ -176,9 +190,17 @@ class TrainIQ(_Base):
             eps = torch.nn.functional.pad(eps.float(), (0, eng.cfg.latent_dim - eps.shape[1]))
         w = kl_weight(self.kliter, self.args.full_kl_step) if phase2 else 0.0
         self.model._step_seed += 1
-        self._dp.run(None if images is None else images.contiguous().float(), context.contiguous(), posteriors.contiguous(),
+        nxt = None
+        look_ahead = (dist is None and images is not None and images.dim() == 4 and not getattr(self.args, "no_prefetch", False))
+        if look_ahead and next_batch is not None and next_batch.get("images") is not None and \
+                tuple(next_batch["images"].shape) == tuple(images.shape):
+            nxt = self._images_on_device(next_batch)
+        elif eng.prefetch_pending() and images is not None and self._dp._prefetched_ptr != images.data_ptr():
+            raise RuntimeError("fused_training_step: the engine holds the look-ahead conv stack of another batch than the one passed "
+                               "(pass the batch that was given as next_batch to the previous call)")
+        self._dp.run(images, context.contiguous(), posteriors.contiguous(),
                      questions.contiguous(), eps, phase2,
-                     self.model._base_seed + self.model._step_seed, w, noam_lr(self.iter, self.args.hidden_dim), 5.0)
+                     self.model._base_seed + self.model._step_seed, w, noam_lr(self.iter, self.args.hidden_dim), 5.0, next_images=nxt)
         self._last_engine, self._last_w = eng, w
         if phase2:
             self.kliter += 1
@@ -226,14 +248,24 @@ class TrainIQ(_Base):
     def fit(self, loader, max_steps, log_every=100, dist=None):
         """Minimal stand-in for pl.Trainer(max_steps=..., gradient_clip_val=5).fit (reference train_iq.py:372-374)."""
         step = 0
-        while step < max_steps:
-            for batch in loader:
-                self.fused_training_step(batch, dist)
-                step += 1
-                if log_every and step % log_every == 0:
-                    print("step %d %s" % (step, {k: round(v, 4) for k, v in self.last_stats().items()}), flush=True)
-                if step >= max_steps:
-                    break
+
+        def batches():
+            while True:
+                n = 0
+                for b in loader:
+                    n += 1
+                    yield b
+                if n == 0:
+                    return
+        it = batches()
+        cur = next(it, None)
+        while cur is not None and step < max_steps:
+            nxt = next(it, None) if step + 1 < max_steps else None      # one batch of look-ahead: its conv stack runs underneath this step
+            self.fused_training_step(cur, dist, next_batch=nxt)
+            step += 1
+            if log_every and step % log_every == 0:
+                print("step %d %s" % (step, {k: round(v, 4) for k, v in self.last_stats().items()}), flush=True)
+            cur = nxt
 
 
 def _fit_from_producer(self, producer, batch_size, max_steps, shuffle=True, log_every=100, dist=None):

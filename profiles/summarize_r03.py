@@ -116,9 +116,11 @@ def main():
             fh.write('"Linear-GEMM family (time-weighted)",,,,%.4f,\n' % (tot[0] / (1024 * tot[1] * 2.4)))
     print(open(os.path.join(ROOT, "r03_pmc_mfma_busy.csv")).read())
     # vector-memory path (texture addresser = the L1 / L2 -> LDS intake of a CU): busy share per kernel next to the MFMA share
+    if not glob.glob(os.path.join(SRC, "r03_ta", "*", "*_counter_collection.csv")):
+        return
     T, DT = counters("r03_ta")
     with open(os.path.join(ROOT, "r03_pmc_ta_busy.csv"), "w") as fh:
-        fh.write("kernel,launches,avg_duration_us,TA_BUSY_avr_pct,TA_BUSY_max_pct,tcp_pending_stall_cycles_per_us\n")
+        fh.write("kernel,launches,avg_duration_us,ta_busy_avr_share_of_wall(2.4GHz),ta_busy_max_share,tcp_pending_stall_share_per_tcp(256 TCPs)\n")
         agg2 = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, 0.0])
         for k, v in T.items():
             if not (is_gemm(k) or is_conv(k) or "layernorm" in k or "attn_" in k or "adam" in k):
@@ -128,7 +130,8 @@ def main():
             a[0] += n; a[1] += sum(DT[k]); a[2] += sum(v.get("TA_BUSY_avr", [])); a[3] += sum(v.get("TA_BUSY_max", [])); a[4] += sum(v.get("TCP_PENDING_STALL_CYCLES_sum", []))
         for k, a in sorted(agg2.items(), key=lambda kv: -kv[1][1]):
             if a[0]:
-                fh.write('"%s",%d,%.2f,%.1f,%.1f,%.0f\n' % (k, a[0], a[1] / a[0] / 1e3, a[2] / a[0], a[3] / a[0], a[4] / max(a[1] / 1e3, 1e-9)))
+                cyc = a[1] * 2.4      # kernel cycles at 2.4 GHz (durations are ns), summed over the launches
+                fh.write('"%s",%d,%.2f,%.3f,%.3f,%.3f\n' % (k, a[0], a[1] / a[0] / 1e3, a[2] / cyc, a[3] / cyc, a[4] / (256.0 * cyc)))
     print(open(os.path.join(ROOT, "r03_pmc_ta_busy.csv")).read())
 
 

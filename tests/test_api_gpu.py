@@ -396,3 +396,33 @@ def test_reference_default_widths_fused_steps_and_checkpoint(tmp_path):
         sd2 = t2.model.state_dict()
         for k in after:
             assert torch.equal(after[k].cpu().float(), sd2[k].cpu().float()), k
+
+
+def test_fit_runs_the_conv_stack_one_batch_ahead_and_trains_the_same():
+    """TrainIQ.fit hands every step the NEXT batch: its frozen ResNet-18 forward runs on the engine's conv stream underneath the current step
+    (models/encoder_cnn.py:18-19).  Same batches, same seeds: the look-ahead run ends with the parameters / BatchNorm statistics of the
+    inline run (to fp32-atomic order), and a batch other than the announced one is refused."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    import bltvqg_amd.synthetic as synthetic
+    z, cfg, state, batch = load_golden("tiny")
+    loader = []
+    for i in range(4):
+        b = synthetic.make_batch(4, cfg.vocab_size, cfg.latent_dim, seed=100 + i, image_hw=64)
+        loader.append({k: v.cuda() for k, v in b.items()})
+    finals = {}
+    for look in (False, True):
+        t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg, num_pretraining_steps=2, no_prefetch=not look, seed=5))
+        t.model.load_state_dict(_full_state(t.model, state))
+        t = t.to("cuda")
+        t.fit(loader, max_steps=6, log_every=0)
+        eng = t._last_engine
+        assert eng.prefetch_pending() == 0                         # the last step announced no next batch
+        t.last_stats()
+        finals[look] = {k: v.detach().float().cpu().clone() for k, v in t.model.state_dict().items()}
+    for k in finals[False]:
+        a, b_ = finals[False][k], finals[True][k]
+        tol = 1e-6 if ("running_" in k and "encoder_cnn.cnn." in k) else 2e-3
+        assert float((a - b_).abs().max()) <= tol * max(1.0, float(a.abs().max())), k
+    t.fused_training_step(loader[0], next_batch=loader[1])
+    with pytest.raises(RuntimeError, match="look-ahead"):
+        t.fused_training_step(loader[2])

@@ -109,6 +109,8 @@ def test_full_size_step_matches_one_oracle_step(name):
     agree = float((out.reshape(-1, V).argmax(-1)[clear] == ram[clear]).float().mean())
     worst = max(abs(gn[n] - g) / max(g, 1e-9) for n, g in ref_gn.items() if n in gn and g > 1e-6)
     print("%s bf16: loss %.5f vs %.5f, sampled logits rel %.4f, argmax agreement %.4f, worst gradient-norm rel %.4f" % (name, total, ref_loss, err, agree, worst))
-    assert abs(total - ref_loss) < 2e-2 * abs(ref_loss)
-    assert err < 6e-2
-    assert worst < 0.15
+    # bars = what is measured on MI355X (round 3: loss 0.003-0.04 %, sampled logits 1.0-1.9 %, gradient norms 0.2-0.5 %) with a
+    # 4-5x margin, so that a regression shows: loss 0.2 %, sampled logits 4 %, gradient norms 2 %
+    assert abs(total - ref_loss) < 2e-3 * abs(ref_loss)
+    assert err < 4e-2
+    assert worst < 0.02

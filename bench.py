@@ -246,6 +246,12 @@ def main():
     if a.gpus != world:
         print("warning: --gpus %d but WORLD_SIZE %d (the launcher's world size is what runs)" % (a.gpus, world), file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    # BLT_SHARE_GPU=1 + BLT_DIST_BACKEND=gloo: functional rehearsal of the N-rank step on a box with fewer GPUs than ranks (every rank on
+    # its LOCAL_RANK modulo the device count, gloo moving the device-resident gradients); the line it prints says so and is no measurement
+    share_gpu = os.environ.get("BLT_SHARE_GPU") == "1"
+    if share_gpu:
+        local = local % torch.cuda.device_count()
+    backend = os.environ.get("BLT_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -253,7 +259,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         assert dist.get_world_size() == world
 
     import bltvqg_amd.synthetic as synthetic
@@ -578,7 +587,9 @@ def main():
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "median_ms_per_step": round(median_ms, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype,
-            "data": "synthetic, pinned host batch copied over PCIe every step (one step ahead)" if a.h2d else "synthetic",
+            "data": ("synthetic, pinned host batch copied over PCIe every step (one step ahead)" if a.h2d else "synthetic") +
+                    (" — REHEARSAL: %d ranks share %d GPU(s) over %s, not a measurement" % (world, torch.cuda.device_count(), backend)
+                     if (share_gpu or backend != "nccl") else ""),
             "config": {"workload": "%s: IQ train step (fwd+loss+bwd+clip+Adam), %s cfg: %d-layer d_model=%d %d-head, per-GPU batch %d, %s, "
                                    "T=20/S_a=5/S_p=21, V=%d, phase %d, dropout 0.1" % (
                                        CONFIG_NAMES[a.config], a.config, cfg["num_layers"], cfg["hidden_dim"], cfg["num_heads"], B,

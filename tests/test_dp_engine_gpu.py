@@ -1,5 +1,7 @@
-"""Two RCCL ranks driving the REAL engine (skipped on boxes with fewer than 2 GPUs; tests/test_dp_gloo.py covers the same
-DataParallelStep logic on CPU with a stand-in engine): different shards per rank -> the all-reduced flat gradient equals the mean of the
+"""Two ranks driving the REAL engine: over RCCL on two GPUs where there are two, otherwise both ranks on the ONE GPU of the test box with the
+gloo backend moving the (device-resident) gradients — the same DataParallelStep code path: in-stack weight-gradient flushes, one event per
+gradient bucket, the communication stream, the optimiser forked from it.  (tests/test_dp_gloo.py covers the host logic on CPU with a
+stand-in engine.)  Different shards per rank -> the all-reduced flat gradient equals the mean of the
 two single-rank gradients, the phase-1 step leaves the phase-2-only bucket untouched, and the overlapped optimiser schedule (clip +
 Adam forked from the communication stream) gives the synchronous result.  Reference: pl.Trainer(gpus=N) = Lightning DDP,
 train_iq.py:372-373."""
@@ -33,9 +35,13 @@ def _worker(rank, world, port, out):
     import bltvqg_amd.synthetic as synthetic
     from bltvqg_amd.engine import StepEngine, make_config
     from bltvqg_amd.trainer import DataParallelStep, init_reference_style, shard_seed
-    torch.cuda.set_device(rank)
-    dev = torch.device("cuda", rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    shared = torch.cuda.device_count() < world                   # one-GPU box: both ranks share cuda:0, gloo carries the exchange
+    dev = torch.device("cuda", 0 if shared else rank)
+    torch.cuda.set_device(dev)
+    if shared:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     try:
         B, V, Z = 8, 97, 64
         cfg = make_config(B, 64, 128, Z, 20, 2, 4, V, image_hw=(64, 64), dtype=0, attention_dropout=0.0, relu_dropout=0.0)
@@ -45,6 +51,7 @@ def _worker(rank, world, port, out):
             e.allocate()
             init_reference_style(e, seed=5 + rank)              # ranks start apart: the broadcast must equalise them
             dp = DataParallelStep(e, dist, overlap_optimizer=overlap)
+            assert len(dp.buckets) >= 5 and dp.comm is not None
             for stepi, phase2 in enumerate((False, True, True)):
                 b = synthetic.make_batch(B, V, Z, seed=shard_seed(100 + stepi, rank), image_hw=64)
                 d = {k: v.to(dev) for k, v in b.items()}
@@ -89,7 +96,6 @@ def _worker(rank, world, port, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (the 1-GPU test boxes skip it; tests/test_dp_gloo.py covers the logic on CPU)")
 def test_two_rank_engine_gradients_are_the_mean_of_the_single_rank_gradients():
     import torch.multiprocessing as mp
     port = _free_port()

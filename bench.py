@@ -296,12 +296,13 @@ def main():
     d = {k: batch[k].to(dev) for k in keys}
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
 
-    # The conv stack runs one batch ahead on a stream of its own only when no gradient exchange needs one: the command processor runs at
-    # most four queues truly side by side (scratch/queues_exp.py: a fifth stream's kernels are time-sliced even with GPU_MAX_HW_QUEUES=8),
-    # and the step already uses the caller's stream + two engine streams; N > 1 gives the fourth to the communication stream
-    use_prefetch = (not a.no_prefetch) and not cfg.get("num_regions") and dist is None
-    conv_s = None
-    if use_prefetch:
+    # The conv stack runs one batch ahead on the step's FOURTH stream: the command processor runs at most four queues truly side by side
+    # (profiles/r03_queues_exp.py: a fifth stream's kernels are time-sliced even with GPU_MAX_HW_QUEUES=8) and the step already uses the
+    # caller's stream + two engine streams.  With N > 1 that fourth stream is the communication stream, which is idle until the first
+    # gradient bucket is final — where the next batch's stack runs — so DataParallelStep hands it to the engine for both.
+    use_prefetch = (not a.no_prefetch) and not cfg.get("num_regions")
+    conv_s = step.comm if (use_prefetch and dist is not None) else None
+    if use_prefetch and dist is None:
         # ONE stream for everything that runs a batch ahead (the conv stack; in the PCIe-fed loop also the copy in front of it), created
         # once: a stream that is destroyed does not give its hardware queue back, and a fifth queue is time-sliced against the others
         conv_s = torch.cuda.Stream(device=dev)

@@ -155,7 +155,7 @@ class TrainIQ(_Base):
 
     def fused_training_step(self, batch, dist=None, next_batch=None):
         """One full reference training step inside the HIP engine.  Returns nothing; `last_stats()` syncs and reads the losses.
-        next_batch (optional, one GPU, image mode): the batch of the NEXT call — its frozen ResNet-18 forward is enqueued one batch ahead
+        next_batch (optional, image mode): the batch of the NEXT call — its frozen ResNet-18 forward is enqueued one batch ahead
         (models/encoder_cnn.py:18-19 freezes the backbone; DataParallelStep.run(next_images=...))."""
         self._phase_switch()
         images, context, posteriors, questions = self._unpack(batch)
@@ -191,7 +191,7 @@ class TrainIQ(_Base):
         w = kl_weight(self.kliter, self.args.full_kl_step) if phase2 else 0.0
         self.model._step_seed += 1
         nxt = None
-        look_ahead = (dist is None and images is not None and images.dim() == 4 and not getattr(self.args, "no_prefetch", False))
+        look_ahead = (images is not None and images.dim() == 4 and not getattr(self.args, "no_prefetch", False))
         if look_ahead and next_batch is not None and next_batch.get("images") is not None and \
                 tuple(next_batch["images"].shape) == tuple(images.shape):
             nxt = self._images_on_device(next_batch)

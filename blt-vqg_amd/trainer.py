@@ -137,6 +137,12 @@ class DataParallelStep(object):
         # (StepEngine.optimizer_step(overlap=True)); call finish() before reading parameters
         self.overlap_optimizer = overlap_optimizer
         self.comm = torch.cuda.Stream(device=engine.device) if (dist is not None and self.cuda) else None
+        # The communication stream is idle from the start of a step until the first gradient bucket is final (~60 % of the step) — exactly
+        # where the NEXT batch's frozen conv stack runs when it is enqueued one batch ahead (run(next_images=...)).  One stream serves both,
+        # in order: conv stack of batch i+1, then the all-reduces of step i, then the optimiser fork; the step stays at four live streams
+        # (the command processor runs four queues side by side).
+        if self.comm is not None and hasattr(engine, "adopt_conv_stream") and engine.cfg.num_regions == 0:
+            engine.adopt_conv_stream(self.comm)
         self.buckets = engine.buckets()
         # with an exchange to overlap, the engine flushes weight gradients at every bucket boundary so that each bucket's all-reduce can
         # start under the rest of backward; on one GPU those extra launches only compete with the chain (+0.15 ms per step measured)

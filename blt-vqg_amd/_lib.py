@@ -151,6 +151,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: PyTorch-ROCm ships its own libamdhip64.so; a process must end up with ONE HIP runtime, the one that owns torch's device
+    # memory.  Loaded before torch, this library would bind the system runtime (/opt/rocm/lib) and every device pointer torch hands over
+    # would be foreign to it ("no ROCm-capable device is detected" on the first hipMemset).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "%s is missing: build it with `make -C blt-vqg_amd/csrc` (or __graft_entry__.build()). "

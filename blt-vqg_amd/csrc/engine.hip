@@ -1808,7 +1808,13 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
                 "engine_bind: misaligned buffer");
     e->train = train; e->grad = grad; e->adam_m = adam_m; e->adam_v = adam_v; e->frozen = frozen; e->ws = (char*)workspace;
     e->layout(e->ws);
-    if (hipMemset(workspace, 0, (size_t)e->ws_bytes) != hipSuccess) { blt_set_error("engine_bind: workspace memset failed"); return BLT_ERR_HIP; }
+    {
+        const hipError_t rc_ = hipMemset(workspace, 0, (size_t)e->ws_bytes);
+        if (rc_ != hipSuccess) {
+            blt_set_error("engine_bind: workspace memset of %lld bytes failed (%s)", (long long)e->ws_bytes, hipGetErrorString(rc_));
+            return BLT_ERR_HIP;
+        }
+    }
     // sinusoid timing signal, transformer_layers.py:542-558: [sin(pos*w_i) | cos(pos*w_i)], float64 then cast
     {
         // (padded widths: the signal is that of the TRUE width, each real feature i stored at its padded column)

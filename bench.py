@@ -476,8 +476,15 @@ def main():
             one_step(i, phase2, a.h2d)
         step.finish()
         torch.cuda.synchronize()
+        starts = step.bucket_start_ms()
         ex = sorted(step.exposed_ms())
         step.measure_exposed = False
+        if starts:
+            mid = starts[len(starts) // 2]
+            extras["bucket_ready_ms_before_backward_end"] = {
+                "by_collective": [{"bucket": i, "ms": v} for i, v in mid],
+                "what": "one measured step: how long before the END of backward each gradient bucket's collective could start (HIP events on the "
+                        "communication stream behind the bucket's wait); collectives run in this order, a value near 0 = final only with backward"}
         extras["exposed_comm_ms_per_step"] = {"median": round(ex[len(ex) // 2], 3), "max": round(ex[-1], 3), "steps": len(ex),
                                               "what": "HIP events: end of backward (step stream, all engine streams joined) -> end of the last gradient "
                                                       "all-reduce (communication stream); 0 = the exchange finished under backward"}

@@ -403,16 +403,19 @@ struct bltvqg_engine {
         add_enc_stack("answer_encoder.r_encoder", 1, renc_flush);
         const int t_renc_last = close_bucket(1);
         // completion order: the decoder's groups, the latent-phase heads (final with the decoder's last flush), the two encoder stacks'
-        // in-stack groups (the context encoder's first: 5 tokens per sample against 21), their last groups, the tail (embedding, CNN head)
+        // in-stack groups, their last groups, the tail (embedding, CNN head).  The POSTERIOR encoder's come first at each level: both chains
+        // are ~60 latency-bound launches whatever their row count, and the posterior one starts earlier (it is forked right behind the latent
+        // backward, the context one follows the CNN head's backward on the caller's stream) — profiles/r03_forced_dist_timeline.txt: posterior
+        // groups final at 5.2 / 6.0 ms, context groups at 6.0 / 6.4 ms of that step
         {
             std::vector<int> order, remap(tmp_buckets.size(), -1);
             for (int l = L - 1; l >= 0; --l) if (dec_flush[l] >= 0) order.push_back(dec_flush[l]);
             order.push_back(t_dec_last); order.push_back(t_late0);
             for (int l = L - 1; l >= 0; --l) {
-                if (enc_flush[l] >= 0) order.push_back(enc_flush[l]);
                 if (renc_flush[l] >= 0) order.push_back(renc_flush[l]);
+                if (enc_flush[l] >= 0) order.push_back(enc_flush[l]);
             }
-            order.push_back(t_enc_last); order.push_back(t_renc_last); order.push_back(t_tail);
+            order.push_back(t_renc_last); order.push_back(t_enc_last); order.push_back(t_tail);
             for (size_t i = 0; i < order.size(); ++i) { remap[order[i]] = (int)i; buckets.push_back(tmp_buckets[order[i]]); }
             for (int l = 0; l < L; ++l) {
                 if (dec_flush[l] >= 0) dec_flush[l] = remap[dec_flush[l]];

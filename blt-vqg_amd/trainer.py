@@ -158,6 +158,7 @@ class DataParallelStep(object):
         # last all-reduce on the communication stream); exposed_ms() = how long the optimiser had to wait for the exchange after backward
         self.measure_exposed = False
         self._exposed = []
+        self._bucket_marks = []
         self.check_ids_every = int(check_ids_every)      # every n-th step: raise if the batch held token ids outside the vocabulary
         if dist is not None and broadcast:
             # one-time parameter broadcast from rank 0 (DDP does the same at construction); engines of other batch shapes share these
@@ -173,11 +174,18 @@ class DataParallelStep(object):
 
     def reduce_gradients(self, phase2):
         e, dist = self.e, self.dist
+        marks = [] if (self.measure_exposed and self.comm is not None) else None
         for ids, off, n in comm_plan(self.buckets, phase2):
             for i in ids:
                 e.bucket_wait(i, self.comm)      # the side stream waits for the engine's "bucket i is final" event(s)
+            if marks is not None:                # when the communication stream got past the wait = when this collective could start
+                ev = torch.cuda.Event(enable_timing=True)
+                ev.record(self.comm)
+                marks.append((ids[0], ev))
             with self._on_comm():
                 allreduce_bucket(dist, e.flat_grad, off, n, self.wire)
+        if marks is not None:
+            self._bucket_marks.append(marks)
         if not self.overlap_optimizer and self.comm is not None:
             torch.cuda.current_stream(e.device).wait_stream(self.comm)
 
@@ -233,6 +241,17 @@ class DataParallelStep(object):
             b.synchronize()
             out.append(max(0.0, a.elapsed_time(b)))
         self._exposed = []
+        return out
+
+    def bucket_start_ms(self):
+        """Per measured step: for every collective, milliseconds from the moment it could start (the communication stream got past its
+        bucket's event) to the END of backward — positive = the collective was free to run that long underneath backward.  Pairs with
+        exposed_ms(); call it first (exposed_ms clears the record)."""
+        out = []
+        for (a, _), marks in zip(self._exposed, self._bucket_marks):
+            a.synchronize()
+            out.append([(i, round(ev.elapsed_time(a), 3)) for i, ev in marks])
+        self._bucket_marks = []
         return out
 
     def finish(self):

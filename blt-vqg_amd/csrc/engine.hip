@@ -1483,7 +1483,8 @@ struct bltvqg_engine {
             // can start while backward is still running.  only while group_flush is on (a data-parallel exchange exists)
             // (debug key 21, A/B: bit mask of the stacks that flush in-stack although no exchange asked for it: 1 decoder, 2 context, 4 posterior)
             const bool forced = (blt_debug_get(21) >> (st.dec ? 0 : (st.id == 0 ? 1 : 2))) & 1;
-            if (defer_wgrads && (group_flush || forced) && flush_plan && (*flush_plan)[l] >= 0) RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
+            if (defer_wgrads && ((group_flush && blt_debug_get(19) != 1) || forced) && flush_plan && (*flush_plan)[l] >= 0)      // (key 19 = 1: A/B, no in-stack flush)
+                RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
         }
         return BLT_OK;
     }
@@ -1569,7 +1570,7 @@ struct bltvqg_engine {
         // launched beside the grouped kernel they waited for its 40 us workgroups to free a CU one by one (0.55 ms instead of 0.1).  The
         // latent nets' own weight gradients ride in the same launch; bucket 0 (decoder.*) is complete when side[1] gets past it.
         RC(flush_wgrads(s, use_streams ? side[1] : s, fj[6], bk_dec_last, phase2 ? bk_late0 : -1));
-        if (!group_flush) RC(record_buckets(dec_flush, use_streams ? side[1] : s));
+        if (!group_flush || blt_debug_get(19) == 1) RC(record_buckets(dec_flush, use_streams ? side[1] : s));
         // d(image feature) is final here, long before the encoder chains are: the CNN head's backward (BatchNorm1d -> fc) goes to the
         // weight-gradient stream now instead of closing the chain
         if (use_streams) { RC(fork(s, side[1], fj[13])); RC(cnn_head_bwd(side[1])); }
@@ -1589,7 +1590,7 @@ struct bltvqg_engine {
             // encoder's weight gradients then run on s0 behind it, beside the context encoder's on side[1], and are joined at the very end
             if (s0 != s && hipEventRecord(fj[5], s0) != hipSuccess) { blt_set_error("backward: event record failed"); return BLT_ERR_HIP; }
             RC(flush_wgrads(s0, s0 != s ? s0 : side[1], fj[7], bk_renc_last));
-            if (!group_flush) RC(record_buckets(renc_flush, s0 != s ? s0 : side[1]));
+            if (!group_flush || blt_debug_get(19) == 1) RC(record_buckets(renc_flush, s0 != s ? s0 : side[1]));
             Memb = Mtot;
         }
         // ---- context encoder (main stream) ----
@@ -1602,7 +1603,7 @@ struct bltvqg_engine {
         RC(stack_bwd(enc, dX_all, nullptr, nullptr, s, &enc_flush));
         stamp(9, s);
         RC(flush_wgrads(s, use_streams ? side[1] : s, fj[8], bk_enc_last));
-        if (!group_flush) RC(record_buckets(enc_flush, use_streams ? side[1] : s));
+        if (!group_flush || blt_debug_get(19) == 1) RC(record_buckets(enc_flush, use_streams ? side[1] : s));
         defer_wgrads = false;
         if (s0 != s && hipStreamWaitEvent(s, fj[5], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
         // ---- shared embedding (rows of the streams that received gradient): weight + bias gradient to the side stream, the gradient of

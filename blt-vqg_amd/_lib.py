@@ -45,6 +45,7 @@ SIGNATURES = {
     "bltvqg_gemm_ex": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, F, U64, U32, P, I, F, P, I, P, I, I, I, I, P]),
     "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
     "bltvqg_gemm_repeat": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P]),
+    "bltvqg_gemm_rotate": (I, [I, P, I, I, L, P, I, I, L, P, I, I, L, I, I, I, I, I, P]),
     "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "bltvqg_layernorm_linear": (I, [P, I, P, P, F, P, P, P, P, I, P, I, F, U64, U32, P, I, P, I, I, I, I, P]),
     "bltvqg_linear_layernorm": (I, [P, I, P, I, P, I, F, U64, U32, P, I, P, I, P, I, P, P, F, P, P, P, I, I, I, P]),

@@ -81,6 +81,27 @@ int bltvqg_gemm_repeat(int dtype, const void* A, int lda, const void* B, int ldb
     return BLT_OK;
 }
 
+int bltvqg_gemm_rotate(int dtype, const void* A, int lda, int a_copies, int64_t a_stride_bytes, const void* B, int ldb, int b_copies,
+                       int64_t b_stride_bytes, void* C, int ldc, int c_copies, int64_t c_stride_bytes, int M, int N, int K, int chain, int reps,
+                       void* stream) {
+    BLT_REQUIRE(a_copies >= 1 && b_copies >= 1 && c_copies >= 1 && reps > 0 && (!chain || (N == K && c_copies >= 2)), "gemm_rotate: bad args");
+    GemmArgs g;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    for (int i = 0; i < reps; ++i) {
+        g.B = (const char*)B + (int64_t)(i % b_copies) * b_stride_bytes;
+        if (chain) {      // launch i reads what launch i-1 wrote: the dependent-chain case (operands freshly written by another kernel)
+            g.A = i == 0 ? A : (const void*)((char*)C + (int64_t)((i - 1) % c_copies) * c_stride_bytes);
+            g.lda = i == 0 ? lda : ldc;
+        } else {
+            g.A = (const char*)A + (int64_t)(i % a_copies) * a_stride_bytes;
+        }
+        g.C = (char*)C + (int64_t)(i % c_copies) * c_stride_bytes;
+        const int rc = blt_gemm(dtype, g, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return BLT_OK;
+}
+
 int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* dbias, int rows, int N, int K,
                         int split_k, void* stream) {
     BLT_REQUIRE(dY && X && dW && rows > 0 && N > 0 && K > 0, "linear_wgrad: bad args");

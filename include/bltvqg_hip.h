@@ -74,6 +74,12 @@ int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, 
  * host-side event pair measures device time per launch (a Python call per launch costs more than these kernels run). */
 int bltvqg_gemm_repeat(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu,
                        const void* R, int ldr, int reps, void* stream);
+/* Timing aid like bltvqg_gemm_repeat, with COLD operands: launch i takes A / B / C from copy i % copies (copies are *_stride_bytes apart), so
+ * that the operands of a launch were not touched by the launches just before it (weights of another layer); chain = 1 (N == K): launch i
+ * reads as A what launch i-1 wrote as C — the dependent chain of the transformer stacks, operands freshly written by the previous kernel. */
+int bltvqg_gemm_rotate(int dtype, const void* A, int lda, int a_copies, int64_t a_stride_bytes, const void* B, int ldb, int b_copies,
+                       int64_t b_stride_bytes, void* C, int ldc, int c_copies, int64_t c_stride_bytes, int M, int N, int K, int chain, int reps,
+                       void* stream);
 /* Backward of y = x W^T + b w.r.t. the parameters (autograd of nn.Linear, transformer_layers.py:453-456,400-408):
  * dW[N,K] += dY[rows,N]^T X[rows,K] and, when dbias is non-null, dbias[N] += column sums of dY — both fp32, in ONE launch (the bias
  * gradient falls out of the staging registers of the dY operand).  split_k > 0: up to that many slices of `rows`, fp32 atomics. */

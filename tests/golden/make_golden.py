@@ -160,7 +160,7 @@ CONFIGS = {
     # ref300: the reference's CLI default WIDTHS (train_iq.py:315-325: hidden 300 = 4 heads of 75, latent 300, FFN 600, emb 300) at one
     # layer and a small vocabulary: exercises the padded engine layout (blt-vqg_amd/padded.py); samples + gradient norms + selected tensors
     "ref300": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=300, latent_dim=300, pwffn_dim=600, num_layers=1, num_heads=4,
-                                       vocab_size=211), B=4, hw=64, seed=15, full=False, keep=(
+                                       vocab_size=211), B=4, hw=64, seed=15, full=False, decode=True, keep=(
         "decoder.output.bias", "embedding.1.bias", "decoder.decoder.dec.0.multi_head_attention_dec.query_linear.weight",
         "answer_encoder.encoder.enc.0.layer_norm_mha.weight", "latent_layer.mean_logvar_posterior.0.weight", "encoder_cnn.bn.weight")),
     # small = BASELINE.json configs[0] model (2-layer, d_model 256) at B=8, 224x224: summaries only
@@ -245,7 +245,7 @@ def main():
                     if c["full"] or k.startswith("encoder_cnn.bn.") or k.startswith("encoder_cnn.cnn.bn1."):
                         out["p1.buf." + k] = v.numpy()
             # the train-mode forward updated BN running stats inside the model; full_state is reloaded each run
-        if c["full"]:
+        if c["full"] or c.get("decode"):
             # greedy decoding (iq.py:117-152) under model.eval(), latent off and on (eps injected)
             import models.transformer_layers as TL
             for phase2 in (False, True):

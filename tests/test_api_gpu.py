@@ -363,6 +363,24 @@ def test_reference_default_widths_match_the_reference(phase2):
                 assert rel_err(t.model.state_dict()[k[7:]].cpu(), z[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize("phase2", [False, True])
+def test_reference_default_widths_greedy_decode_token_ids_bit_exact(phase2):
+    """IQ.decode_greedy at the reference's default widths (padded engine layout) against the reference's own decode of the ref300 fixture:
+    bit-exact token ids and top-6 indices, top-6 probabilities within 2e-3."""
+    from train_iq import SyntheticVocabulary, TrainIQ
+    z, cfg, state, batch = load_golden("ref300")
+    tag = "dec2" if phase2 else "dec1"
+    t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg))
+    t.model.load_state_dict(_full_state(t.model, state))
+    t = t.to("cuda")
+    t.eval()
+    t.model.switch_GVT_train_mode(phase2)
+    sent, top_args, top_vals = t.model.decode_greedy(batch["images"].cuda(), batch["answers"].cuda(), max_decode_length=12, eps=batch["eps"].cuda())
+    assert top_args.shape == (4, 13, 6) and len(sent) == 4
+    assert np.array_equal(top_args.cpu().numpy().astype(np.int32), z[tag + ".top_idx"])
+    assert np.allclose(top_vals.cpu().numpy(), z[tag + ".top_val"], rtol=2e-3, atol=1e-6)
+
+
 def test_reference_default_widths_fused_steps_and_checkpoint(tmp_path):
     """Fused training steps on the padded engine: the pad entries of every weight stay exactly zero (zero gradient, zero Adam step), the
     nn.Parameters follow the engine's optimiser (state_dict gathers them), bf16 runs, and a checkpoint round-trips at reference shapes."""

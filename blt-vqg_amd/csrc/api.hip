@@ -295,6 +295,16 @@ int bltvqg_attn_fwd(int dtype, const void* Q, int ldq, const void* K, int ldk, c
     a.Tq = Tq; a.Tk = Tk; a.d = d; a.causal = causal; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.stream_id = stream_id;
     return blt_attn_fwd(dtype, a, (hipStream_t)stream);
 }
+int bltvqg_attn_out_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, const void* Wo, int ldwo,
+                        const void* R, int ldr, void* Y, int ldy, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal,
+                        float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream) {
+    AttnArgs a;
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = O; a.ldo = ldo; a.key_ids = key_ids; a.B = B; a.heads = heads;
+    a.Tq = Tq; a.Tk = Tk; a.d = d; a.causal = causal; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.stream_id = stream_id;
+    a.Wo = Wo; a.ldwo = ldwo; a.R = R; a.ldr = ldr; a.Y = Y; a.ldy = ldy;
+    BLT_REQUIRE(Y && Wo && ldy >= heads * d && (!R || ldr >= heads * d) && ldwo >= heads * d, "attn_out_fwd: bad output / weight operands");
+    return blt_attn_out_fwd(BLT_BF16, a, (hipStream_t)stream);
+}
 int bltvqg_attn_bwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo, void* dQ, int lddq,
                     void* dK, int lddk, void* dV, int lddv, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal, float scale,
                     float drop_p, uint64_t seed, uint32_t stream_id, void* stream) {

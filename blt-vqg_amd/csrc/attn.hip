@@ -418,6 +418,138 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Attention + output projection + residual in one launch.  One workgroup per BATCH ELEMENT, wave h = head h: the attention part is the
+// one-wave kernel above; every wave then owns 64 output columns of Y = O Wo^T + R.  The A operand (the [Tq, H] context of this batch
+// element, all heads) is exchanged through LDS; the B operand needs no sharing at all — wave w's 64 rows of Wo go straight from
+// global memory into its MFMA fragments (16 bytes per lane = one fragment row), and the first quarter of them is requested BEFORE the
+// attention arithmetic, so the weight round trip hides under it.  Same MFMA, same ascending k order as gemm_nt2_kernel: the result is
+// bit-identical to the two-launch path (tests/test_ops_gpu.py).  Saves the output projection's launch (~10 us of skeleton) per attention.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, int MAXT>      // MAXT: thread budget (heads * 64 <= MAXT): 512 threads leave every wave 256 VGPRs (192 used); a 1024-thread form for 9..16 heads would spill
+__global__ __launch_bounds__(MAXT) void attn_out_fwd_kernel(const AttnArgs a) {
+    constexpr int KS = D / 32, CT = D / 16, PITCH = D * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;      // w = head = 64-column slice of the output
+    const int H = a.heads * D;
+    const int CP = H * 2 + 16;                                     // row pitch (bytes) of the [32, H] context tile
+    MfmaHead m;
+    m.b = blockIdx.x; m.h = w; m.hb = m.b * a.heads + w; m.n16 = lane & 15; m.g = lane >> 4;
+    char* vimg = smc + w * (32 * PITCH);
+    char* ctile = smc + a.heads * (32 * PITCH);
+    // ---- weights of this wave's 64 output columns: k-steps 0..3 of 16 requested now ----
+    const bf16* Wrow = (const bf16*)a.Wo + (size_t)(w * 64 + m.n16) * a.ldwo + m.g * 8;      // + jt * 16 rows, + ks * 32 columns
+    constexpr int NKS = 4;                                          // k-steps (of 32) per batch of weight fragments
+    bf16x8 wf[NKS][4];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) wf[ks][jt] = *reinterpret_cast<const bf16x8*>(Wrow + (size_t)jt * 16 * a.ldwo + ks * 32);
+    // ---- attention of head w (as attn_fwd_mfma_kernel) ----
+    bf16x8 kf[2][KS], qf[2][KS], vf[2][KS];
+    load_slice<D>((const bf16*)a.K + (size_t)m.b * a.Tk * a.ldk + m.h * D, a.ldk, a.Tk, m, kf, nullptr);
+    load_slice<D>((const bf16*)a.Q + (size_t)m.b * a.Tq * a.ldq + m.h * D, a.ldq, a.Tq, m, qf, nullptr);
+    load_slice<D>((const bf16*)a.V + (size_t)m.b * a.Tk * a.ldv + m.h * D, a.ldv, a.Tk, m, vf, vimg);
+    f32x4 st[2][2];
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            st[jt][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) st[jt][it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[jt][ks], qf[it][ks], st[jt][it], 0, 0, 0);
+        }
+    uint32_t masked[2];
+    softmax_t(a, m, st, masked);
+    if (a.drop_p > 0.f) {
+        const uint32_t thresh = dropout_threshold(a.drop_p);
+        const float ks_ = 1.f / (1.f - a.drop_p);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int i = 16 * it + m.n16;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt) {
+                const int j0 = 16 * jt + 4 * m.g;
+                if (i < a.Tq && j0 < a.Tk) {
+                    const uint32_t keep = keep4(a.seed, a.stream_id, ((uint64_t)m.hb * a.Tq + i) * a.Tk + j0, thresh);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st[jt][it][r] = ((keep >> r) & 1u) ? st[jt][it][r] * ks_ : 0.f;
+                }
+            }
+        }
+    }
+    bf16x8 pb[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) pb[it] = pack8(st[0][it], st[1][it]);
+    bf16* O = (bf16*)a.O + (size_t)m.b * a.Tq * a.ldo + m.h * D;
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const bf16x8 vt = tr_operand<D, true>(vimg, ct, m);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pb[it], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int i = 16 * it + m.n16;
+            s16x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = __builtin_bit_cast(short, (bf16)((i < a.Tq) ? o[e] : 0.f));
+            if (i < a.Tq) *reinterpret_cast<s16x4*>(O + (size_t)i * a.ldo + ct * 16 + 4 * m.g) = r;
+            *reinterpret_cast<s16x4*>(ctile + i * CP + (m.h * D + ct * 16 + 4 * m.g) * 2) = r;      // rows >= Tq: zeros
+        }
+    }
+    __syncthreads();      // every head's context of this batch element is in the tile
+    // ---- Y[:, 64 w .. 64 w + 64) = ctx Wo^T + R ----
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = H / 32;
+    for (int k0 = 0; k0 < nks; k0 += NKS) {
+        bf16x8 wn[NKS][4];
+        const bool more = k0 + NKS < nks;
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) wn[ks][jt] = *reinterpret_cast<const bf16x8*>(Wrow + (size_t)jt * 16 * a.ldwo + (k0 + NKS + ks) * 32);
+        }
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            bf16x8 af[2];
+#pragma unroll
+            for (int it = 0; it < 2; ++it) af[it] = *reinterpret_cast<const bf16x8*>(ctile + (16 * it + m.n16) * CP + ((k0 + ks) * 32 + m.g * 8) * 2);
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) acc[it][jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[it], wf[ks][jt], acc[it][jt], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) wf[ks][jt] = wn[ks][jt];
+        }
+    }
+    // D[m = 4 g + r][n = n16] of tile (it, jt): row 16 it + 4 g + r, column 64 w + 16 jt + n16
+    const bf16* R = (const bf16*)a.R;
+    bf16* Y = (bf16*)a.Y;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 16 * it + 4 * m.g + r;
+            if (i >= a.Tq) continue;
+            const size_t row = (size_t)m.b * a.Tq + i;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                const int n = w * 64 + 16 * jt + m.n16;
+                float v = acc[it][jt][r];
+                if (R != nullptr) v += (float)R[row * a.ldr + n];
+                Y[row * a.ldy + n] = (bf16)v;
+            }
+        }
+}
+
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
     constexpr int KS = D / 32, CT = D / 16, PITCH = D * 2 + 16;
@@ -620,6 +752,28 @@ int set_lds(K kern, size_t bytes, const char* what) {
 }
 
 }  // namespace
+
+bool blt_attn_out_fwd_ok(int dtype, const AttnArgs& a) {
+    return dtype == BLT_BF16 && a.d == 64 && a.heads >= 1 && a.heads <= 8 && a.Tq <= 32 && a.Tk <= 32 && mfma_ok(dtype, a, false) && a.Wo && a.Y &&
+           a.ldwo % 8 == 0 && (((uintptr_t)a.Wo) & 15) == 0 && a.ldo >= a.heads * 64;
+}
+int blt_attn_out_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
+    const int rc = check(a, false);
+    if (rc) return rc;
+    BLT_REQUIRE(blt_attn_out_fwd_ok(dtype, a), "attn_out_fwd: needs bf16, d = 64, heads <= 8, Tq, Tk <= 32, 16-byte aligned operands");
+    constexpr int PITCH = 64 * 2 + 16;
+    const size_t lds = (size_t)a.heads * 32 * PITCH + 32 * ((size_t)a.heads * 64 * 2 + 16);
+    static BltDevFlag set;
+    if (lds > 64 * 1024 && !set.get()) {
+        if (hipFuncSetAttribute((const void*)attn_out_fwd_kernel<64, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            blt_set_error("attn_out_fwd: hipFuncSetAttribute failed");
+            return BLT_ERR_HIP;
+        }
+        set.set();
+    }
+    hipLaunchKernelGGL((attn_out_fwd_kernel<64, 512>), dim3((unsigned)a.B), dim3((unsigned)a.heads * 64), lds, s, a);
+    return blt_check_launch("attn_out_fwd");
+}
 
 int blt_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "attn_fwd: bad dtype");

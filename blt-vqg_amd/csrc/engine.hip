@@ -822,6 +822,31 @@ struct bltvqg_engine {
         a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
         return blt_attn_fwd(dt, a, s);
     }
+    // attention, then its output Linear with the sub-layer's residual add in the epilogue.  A ONE-launch form exists (bf16, 64-wide heads,
+    // <= 8 heads, <= 32 tokens: attn.hip::attn_out_fwd_kernel, bit-identical, exported as bltvqg_attn_out_fwd) and is NOT used: measured
+    // 7.41 ms per step against 7.14 — a workgroup per batch element streams the whole 512 KB weight through its CU's ~70 GB/s intake
+    // (7+ us) to save a 10 us launch whose own intake is 224 KB.  debug key 22 = 2 selects it (A/B).
+    int attn_out_fwd(const void* q, int ldq, const void* k, const void* v, int ldkv, void* ctx, const std::string& wname, const void* resid, void* out,
+                     const int* key_ids, int Tq, int Tk, int causal, uint32_t stream_id, int M, hipStream_t s) {
+        AttnArgs a;
+        a.Q = q; a.ldq = ldq; a.K = k; a.V = v; a.ldk = ldkv; a.ldv = ldkv; a.O = ctx; a.ldo = H; a.key_ids = key_ids;
+        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh_true);
+        a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
+        int ldw;
+        a.Wo = W(wname, &ldw); a.ldwo = ldw; a.R = resid; a.ldr = H; a.Y = out; a.ldy = H;
+        if (blt_debug_get(22) == 2 && !ln_fused() && blt_attn_out_fwd_ok(dt, a)) {
+            const bool sampled = (prof_mask & 2) && (prof_gemm_count++ % prof_stride) == 0;
+            const int pi = sampled ? prof_begin(1, s) : -1;
+            if (pi >= 0) prof[pi].w = prof_stride;
+            const int rc = blt_attn_out_fwd(dt, a, s);
+            prof_end(pi, s, 2.0 * (double)M * (double)H * (double)H);      // the Linear's flops (the attention products are not counted in this family)
+            return rc;
+        }
+        RC(blt_attn_fwd(dt, a, s));
+        GemmArgs g = lin(ctx, H, wname, nullptr, out, H, M);
+        g.R = resid; g.ldr = H;
+        return gemm(dt, g, s);
+    }
     int attn_bwd(const void* q, int ldq, const void* k, const void* v, int ldkv, const void* dO, void* dq, int lddq, void* dk,
                  void* dv, int lddkv, const int* key_ids, int Tq, int Tk, int causal, uint32_t stream_id, hipStream_t s) {
         AttnArgs a;
@@ -915,15 +940,18 @@ struct bltvqg_engine {
                 if (lnA_on()) set_lnA(g, x, lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha"), y.xn1, y.m1, y.r1);
                 RC(gemm(dt, g, s));
             }
-            RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
-                        st.dec ? causal_mode : 0, sid(st.id, l, 0), s));
             const std::string ln2 = lp + (st.dec ? "layer_norm_mha_enc" : "layer_norm_ffn");
-            {
+            if (!ln_fused()) {
+                RC(attn_out_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, a1 + "output_linear.weight",
+                                x, y.x1, st.key_ids, S, S, st.dec ? causal_mode : 0, sid(st.id, l, 0), M, s));
+                if (!lnA_on()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s, ln_pp, ln_pv));
+            } else {
+                RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
+                            st.dec ? causal_mode : 0, sid(st.id, l, 0), s));
                 GemmArgs g = lin(y.ctx, H, a1 + "output_linear.weight", nullptr, y.x1, H, M);
                 g.R = x; g.ldr = H;
-                if (ln_fused()) set_ln(g, ln2, y.xn2, y.m2, y.r2);
+                set_ln(g, ln2, y.xn2, y.m2, y.r2);
                 RC(gemm(dt, g, s));
-                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s, ln_pp, ln_pv));
             }
             if (st.dec) {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
@@ -940,13 +968,18 @@ struct bltvqg_engine {
                     blt_set_error("engine_forward: stream wait failed");
                     return BLT_ERR_HIP;
                 }
-                RC(attn_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, src_ids, S, Sa, 0, sid(st.id, l, 3), s));
                 const std::string ln3 = lp + "layer_norm_ffn";
-                GemmArgs g = lin(y.ctx2, H, a2 + "output_linear.weight", nullptr, y.x1b, H, M);
-                g.R = y.x1; g.ldr = H;
-                if (ln_fused()) set_ln(g, ln3, y.xn3, y.m3, y.r3);
-                RC(gemm(dt, g, s));
-                if (!ln_fused() && !lnA_on()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s, ln_pp, ln_pv));
+                if (!ln_fused()) {
+                    RC(attn_out_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, a2 + "output_linear.weight", y.x1, y.x1b, src_ids, S, Sa,
+                                    0, sid(st.id, l, 3), M, s));
+                    if (!lnA_on()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s, ln_pp, ln_pv));
+                } else {
+                    RC(attn_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, src_ids, S, Sa, 0, sid(st.id, l, 3), s));
+                    GemmArgs g = lin(y.ctx2, H, a2 + "output_linear.weight", nullptr, y.x1b, H, M);
+                    g.R = y.x1; g.ldr = H;
+                    set_ln(g, ln3, y.xn3, y.m3, y.r3);
+                    RC(gemm(dt, g, s));
+                }
                 RC(ffn_fwd(lp + "positionwise_feed_forward.", ln3, y.xn3, y.m3, y.r3, y.x1b, y, M, st.id, l, next, l + 1 == L, s));
             } else {
                 RC(ffn_fwd(lp + "positionwise_feed_forward.", ln2, y.xn2, y.m2, y.r2, y.x1, y, M, st.id, l, next, l + 1 == L, s));

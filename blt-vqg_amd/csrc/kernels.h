@@ -182,8 +182,18 @@ struct AttnArgs {
     const void* dO = nullptr; int lddo = 0;
     void* dQ = nullptr; void* dK = nullptr; void* dV = nullptr; int lddq = 0, lddk = 0, lddv = 0;
     int accumulate_dkv = 0;
+    // fused forward (blt_attn_out_fwd): Y[B*Tq, H] = O Wo^T + R, with O (the attention context, H = heads * d) also written as usual
+    const void* Wo = nullptr; int ldwo = 0;      // [H, ldwo] bf16, k-contiguous (the Linear's weight)
+    const void* R = nullptr; int ldr = 0;        // residual rows [B*Tq, ldr] bf16
+    void* Y = nullptr; int ldy = 0;
 };
 int blt_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s);
+// MultiHeadAttention core + its output Linear + the residual add of the surrounding sub-layer in ONE launch (transformer_layers.py:494-532
+// + the `+ x` of :139,208,267,274): one workgroup per batch element, one wave per head; bf16, d = 64, heads <= 8, Tq, Tk <= 32.  The
+// context O is still written (backward's weight gradient reads it).  Bit-identical to blt_attn_fwd followed by the planned-tile GEMM.
+// Measured SLOWER in the step than the two launches (every workgroup streams the whole weight): an operator for callers with few rows, not the engine's path.
+bool blt_attn_out_fwd_ok(int dtype, const AttnArgs& a);
+int blt_attn_out_fwd(int dtype, const AttnArgs& a, hipStream_t s);
 int blt_attn_bwd(int dtype, const AttnArgs& a, hipStream_t s);
 
 // ---- embedding / token plumbing --------------------------------------------------------

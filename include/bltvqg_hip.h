@@ -190,6 +190,15 @@ int bltvqg_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma
 int bltvqg_attn_fwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                     const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal, float scale, float drop_p,
                     uint64_t seed, uint32_t stream_id, void* stream);
+/* The attention core, its output Linear and the residual add of the surrounding sub-layer in ONE launch (transformer_layers.py:494-532: the
+ * heads' context -> output_linear; + the `x +` of :139,208,267,274): O as bltvqg_attn_fwd writes it (backward's weight gradient reads it) AND
+ * Y[B*Tq, heads*d] = O Wo^T + R (R may be NULL).  One workgroup per batch element, one wave per head, the head's 64 rows of Wo [heads*d, ldwo]
+ * (bf16, k-contiguous) go straight from global memory into MFMA fragments.  bf16, d = 64, heads <= 8, Tq, Tk <= 32; bit-identical to
+ * bltvqg_attn_fwd followed by bltvqg_gemm (same MFMA, same ascending k order).  The train-step engine does NOT use it: at B = 256 each of the
+ * 256 workgroups streams the whole weight (512 KB) through its CU's ~70 GB/s intake, which costs more than the launch it saves. */
+int bltvqg_attn_out_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, const void* Wo, int ldwo,
+                        const void* R, int ldr, void* Y, int ldy, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal,
+                        float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
 int bltvqg_attn_bwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo,
                     void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int32_t* key_ids, int B, int heads, int Tq,
                     int Tk, int d, int causal, float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);

@@ -114,6 +114,16 @@ def attn_fwd(Q, K, V, key_ids, B, heads, Tq, Tk, d, causal, scale, drop_p=0.0, s
     return O
 
 
+def attn_out_fwd(Q, K, V, Wo, R, key_ids, B, heads, Tq, Tk, d, causal, scale, drop_p=0.0, seed=0, stream_id=0):
+    """fused attention + output Linear + residual: returns (O, Y)"""
+    O = torch.zeros(B * Tq, heads * d, dtype=Q.dtype, device=Q.device)
+    Y = torch.zeros(B * Tq, heads * d, dtype=Q.dtype, device=Q.device)
+    check(lib().bltvqg_attn_out_fwd(ptr(Q), Q.stride(0), ptr(K), K.stride(0), ptr(V), V.stride(0), ptr(O), O.stride(0), ptr(Wo), Wo.stride(0),
+                                    ptr(R), 0 if R is None else R.stride(0), ptr(Y), Y.stride(0), ptr(key_ids), B, heads, Tq, Tk, d, int(causal),
+                                    float(scale), float(drop_p), int(seed), int(stream_id), stream_ptr()), "attn_out_fwd")
+    return O, Y
+
+
 def attn_bwd(Q, K, V, dO, key_ids, B, heads, Tq, Tk, d, causal, scale, drop_p=0.0, seed=0, stream_id=0):
     dQ, dK, dV = torch.zeros_like(Q), torch.zeros_like(K), torch.zeros_like(V)
     check(lib().bltvqg_attn_bwd(DT[Q.dtype], ptr(Q), Q.stride(0), ptr(K), K.stride(0), ptr(V), V.stride(0), ptr(dO), dO.stride(0),

@@ -450,6 +450,36 @@ def test_attention_mfma_form_matches_reference_and_valu_form(case, p):
             assert torch.allclose(got, want, atol=tol * 8, rtol=tol * 4), float((got - want).abs().max())
 
 
+@pytest.mark.parametrize("case", [dict(B=5, h=4, Tq=20, Tk=20, causal=1), dict(B=9, h=8, Tq=20, Tk=5, causal=0), dict(B=256, h=8, Tq=21, Tk=21, causal=0),
+                                  dict(B=3, h=8, Tq=32, Tk=32, causal=1), dict(B=4, h=2, Tq=1, Tk=3, causal=0)])
+@pytest.mark.parametrize("p", [0.0, 0.2])
+@pytest.mark.parametrize("residual", [True, False])
+def test_fused_attention_output_projection_is_bit_identical_to_the_two_launch_path(case, p, residual):
+    """bltvqg_attn_out_fwd (attention core + output Linear + residual, one workgroup per batch element) against bltvqg_attn_fwd followed by
+    the planned-tile GEMM with the residual epilogue (transformer_layers.py:494-532 + the sub-layer's `x +`): the context AND the sub-layer
+    output must be BIT-identical — same MFMA instruction, same ascending k order, same Philox stream for the attention dropout."""
+    import gpu_ops as G
+    B, h, Tq, Tk, causal = case["B"], case["h"], case["Tq"], case["Tk"], case["causal"]
+    d, Hd = 64, case["h"] * 64
+    g = torch.Generator().manual_seed(B * 11 + Tq * 5 + Tk)
+    Q = torch.randn(B * Tq, Hd, generator=g).bfloat16().cuda()
+    kv = torch.randn(B * Tk, 2 * Hd, generator=g).bfloat16().cuda()
+    K, V = kv[:, :Hd], kv[:, Hd:]
+    Wo = (torch.randn(Hd, Hd, generator=g) * Hd ** -0.5).bfloat16().cuda()
+    R = torch.randn(B * Tq, Hd, generator=g).bfloat16().cuda() if residual else None
+    ids = torch.randint(1, 50, (B, Tk), generator=g, dtype=torch.int32)
+    if Tk > 2:
+        ids[0, Tk - 2:] = 0
+    ids = ids.cuda()
+    scale = d ** -0.5
+    O2 = G.attn_fwd(Q, K, V, ids, B, h, Tq, Tk, d, causal, scale, p, 99, 31)
+    Y2 = G.gemm(O2, Wo, B * Tq, Hd, Hd, R=R)
+    O1, Y1 = G.attn_out_fwd(Q, K, V, Wo, R, ids, B, h, Tq, Tk, d, causal, scale, p, 99, 31)
+    assert torch.isfinite(Y1.float()).all()
+    assert torch.equal(O1, O2)
+    assert torch.equal(Y1, Y2), float((Y1.float() - Y2.float()).abs().max())
+
+
 # --------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("V", [97, 8000])

@@ -66,3 +66,27 @@ def test_shipped_library_has_no_work_skipping_switch():
     lib.bltvqg_debug_set(7, 3)
     assert lib.bltvqg_debug_get(7) == 3
     lib.bltvqg_debug_set(7, 0)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r03_bench_default.json is the bench line of a default `python bench.py` run on an MI355X box: the driver's contract fields, the
+    roofline block of the dominant kernel family and the CPU baseline must all be there (a schema check, not a performance check)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = json.load(open(os.path.join(root, "profiles", "r03_bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "debug_keys", "loss_vs_oracle", "overlap", "f32"):
+        assert k in d, k
+    assert d["unit"] == "pairs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16"
+    assert "configs[2]" in d["config"]["workload"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] < 1.0
+    assert "static" in r["traffic_source"]
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "s_per_step"):
+        assert k in c, k
+    assert c["kind"] == "port" and d["debug_keys"] == {}
+    assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-3

@@ -176,7 +176,7 @@ struct bltvqg_engine {
     std::vector<Bucket> buckets;                         // completion order
     std::vector<int> dec_flush, enc_flush, renc_flush;   // per layer l: bucket closed by the flush after layer l's backward, or -1
     int bk_dec_last = -1, bk_late0 = -1, bk_enc_last = -1, bk_renc_last = -1, bk_tail = -1;
-    static constexpr int64_t BUCKET_TARGET_BYTES = 32ll << 20;
+    static constexpr int64_t BUCKET_TARGET_BYTES = 32ll << 20, BUCKET_TAIL_BYTES = 8ll << 20;
     // In-stack flushes exist for the data-parallel exchange (a bucket's all-reduce can start while backward is still running); on one GPU
     // they only take CUs from the chain (measured +0.15 ms per step on BASELINE configs[2]), so they are off until the step driver that owns
     // an exchange turns them on (bltvqg_engine_set_bucket_flush).  Off: one flush per stack, every bucket of the stack final with it.
@@ -345,7 +345,11 @@ struct bltvqg_engine {
             add_ffn(lp + "positionwise_feed_forward.", late);
             add_ln(lp + "layer_norm_mha", late);
             add_ln(lp + "layer_norm_ffn", late);
-            if (l > 0 && (tsize - bucket_start) * 4 >= BUCKET_TARGET_BYTES) flush_after[l] = close_bucket(late);
+            // ... and the last layers of an ENCODER stack one by one (when a layer is >= 8 MB): the two encoder chains end backward, so
+            // whatever their last flush carries is exchanged after it — one layer each instead of a 36 MB group (exposed bytes 82 -> 34 MB
+            // on BASELINE configs[2..3])
+            const int64_t pend = (tsize - bucket_start) * 4;
+            if (l > 0 && (pend >= BUCKET_TARGET_BYTES || (l <= 2 && pend >= BUCKET_TAIL_BYTES))) flush_after[l] = close_bucket(late);
         }
     }
 

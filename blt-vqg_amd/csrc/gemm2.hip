@@ -24,6 +24,12 @@
 #include <vector>
 #include "kernels.h"
 
+// LDS budget of one planned-tile workgroup: the whole CU (one workgroup per CU, as deep a ring as fits) unless an experiment build says
+// otherwise (make coexist: 79 KB, so that a Linear workgroup fits beside one 80 KB convolution workgroup)
+#ifndef NT2_LDS_CAP
+#define NT2_LDS_CAP (160 * 1024)
+#endif
+
 namespace {
 
 __device__ __attribute__((aligned(16))) uint4 g2_zero_page[1];
@@ -65,7 +71,7 @@ struct Nt2 {
     static constexpr int DUMP = 1024;          // ONE slot for every wave's beyond-the-tile DMA (zeros over zeros)
     // ring depth: as many stages as LDS holds (<= 8), so that NST - 1 K-steps (>= ~96 KB for the big tiles) are in flight per CU;
     // (AHEAD - 1) * PER_STAGE must fit the 6-bit vmcnt
-    static constexpr int NST = cmin(cmin(8, (160 * 1024 - DUMP) / STAGE), 63 / PER_STAGE + 2);
+    static constexpr int NST = cmin(cmin(8, (NT2_LDS_CAP - DUMP) / STAGE), 63 / PER_STAGE + 2);
     static constexpr int RING = NST * STAGE;
     static constexpr int AHEAD = NST - 1;
     static_assert(NST >= 2 && (AHEAD - 1) * PER_STAGE <= 63, "vmcnt is a 6-bit counter");
@@ -74,7 +80,7 @@ struct Nt2 {
     // a thread owns ONE group of 8 columns (tid % GPR; bias is loaded once) and every RPS-th slab row from tid / GPR on: IPP rows per pass
     static constexpr int GPR = BN / 8, RPS = NT / GPR, IPP = (SLAB_ROWS + RPS - 1) / RPS;
     static constexpr int LDS = (RING + DUMP > 2 * SLAB_BYTES) ? RING + DUMP : 2 * SLAB_BYTES;
-    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static_assert(LDS <= NT2_LDS_CAP, "LDS budget");
 };
 
 template <typename C>
@@ -583,12 +589,14 @@ struct TileOpt { int bm, bn; int (*launch)(const GemmArgs&, hipStream_t); };
 #define NT2(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN>>}
 const TileOpt kTiles[] = {
     NT2(64, 64, 2, 4),   NT2(64, 128, 2, 4),  NT2(128, 64, 4, 2),  NT2(128, 128, 2, 4),
-    NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(160, 192, 2, 4), NT2(160, 256, 2, 4),
-    NT2(192, 64, 4, 2),  NT2(192, 128, 2, 4), NT2(192, 192, 2, 4), NT2(192, 256, 2, 4),
-    NT2(128, 256, 2, 4), NT2(256, 128, 4, 2), NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
+    NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(192, 64, 4, 2),  NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
+#if NT2_LDS_CAP >= 160 * 1024      // (the co-residency experiment build caps a workgroup at 79 KB: two ring stages of <= 39 KB)
+    NT2(160, 192, 2, 4), NT2(160, 256, 2, 4), NT2(192, 128, 2, 4), NT2(192, 192, 2, 4), NT2(192, 256, 2, 4),
+    NT2(128, 256, 2, 4), NT2(256, 128, 4, 2),
     // one-round tile of the 2048-column problems when the chain runs on a 192-CU partition (engine_set_cu_masks): 23 x 8 / 24 x 8 workgroups
     // (239 VGPRs; 256 x 256 spills)
     NT2(224, 256, 2, 4),
+#endif
 };
 #undef NT2
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);

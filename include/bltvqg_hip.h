@@ -195,7 +195,7 @@ int bltvqg_attn_fwd(int dtype, const void* Q, int ldq, const void* K, int ldk, c
  * Y[B*Tq, heads*d] = O Wo^T + R (R may be NULL).  One workgroup per batch element, one wave per head, the head's 64 rows of Wo [heads*d, ldwo]
  * (bf16, k-contiguous) go straight from global memory into MFMA fragments.  bf16, d = 64, heads <= 8, Tq, Tk <= 32; bit-identical to
  * bltvqg_attn_fwd followed by bltvqg_gemm (same MFMA, same ascending k order).  The train-step engine does NOT use it: at B = 256 each of the
- * 256 workgroups streams the whole weight (512 KB) through its CU's ~70 GB/s intake, which costs more than the launch it saves (DESIGN.md 5c). */
+ * 256 workgroups streams the whole weight (512 KB) through its CU's ~70 GB/s intake, which costs more than the launch it saves (DESIGN.md 5c.9). */
 int bltvqg_attn_out_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, const void* Wo, int ldwo,
                         const void* R, int ldr, void* Y, int ldy, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal,
                         float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);

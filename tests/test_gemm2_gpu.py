@@ -170,3 +170,27 @@ def _wgrad_strided_cases():
     assert torch.equal(outs[1][0].cpu().double(), dx.double().cpu().t() @ emb[:, :300].double().cpu())
     assert torch.equal(outs[1][1].cpu().double(), dx.double().cpu().sum(0))
     assert torch.equal(outs[2][0].cpu().double(), gqkv[:, H:].double().cpu().t() @ xn.double().cpu())
+
+
+def test_gemm_rotate_computes_every_copy_and_the_chain():
+    """bltvqg_gemm_rotate (timing aid with cold operands): launch i uses copy i % copies of A / B / C; chain = 1 feeds launch i-1's output to
+    launch i.  Every copy must hold the plain GEMM's result (integer operands: exact)."""
+    from bltvqg_amd import _lib
+    from bltvqg_amd._lib import ptr, stream_ptr, check
+    lib = _lib.load()
+    M, N, K = 512, 128, 128
+    g = torch.Generator().manual_seed(3)
+    A = torch.randint(-3, 4, (3, M, K), generator=g).float().bfloat16().cuda()
+    B = torch.randint(-2, 3, (2, N, K), generator=g).float().bfloat16().cuda()
+    C = torch.zeros(6, M, N, dtype=torch.bfloat16, device="cuda")
+    check(lib.bltvqg_gemm_rotate(1, ptr(A), K, 3, M * K * 2, ptr(B), K, 2, N * K * 2, ptr(C), N, 6, M * N * 2, M, N, K, 0, 6, stream_ptr()), "rotate")
+    torch.cuda.synchronize()
+    for i in range(6):
+        want = (A[i % 3].float() @ B[i % 2].float().t())
+        assert torch.equal(C[i].float(), want.bfloat16().float()), i
+    # chain: N == K; launch 0 reads A[0], launch i reads C[(i - 1) % 2]
+    Bs = torch.eye(K).bfloat16().cuda().unsqueeze(0).contiguous()             # identity weights: every link of the chain reproduces A[0]
+    C2 = torch.zeros(2, M, K, dtype=torch.bfloat16, device="cuda")
+    check(lib.bltvqg_gemm_rotate(1, ptr(A), K, 1, 0, ptr(Bs), K, 1, 0, ptr(C2), K, 2, M * K * 2, M, K, K, 1, 5, stream_ptr()), "chain")
+    torch.cuda.synchronize()
+    assert torch.equal(C2[0], A[0]) and torch.equal(C2[1], A[0])

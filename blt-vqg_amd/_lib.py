@@ -43,6 +43,9 @@ SIGNATURES = {
     "bltvqg_build_has_ablations": (I, []),
     "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
     "bltvqg_gemm_ex": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, F, U64, U32, P, I, F, P, I, P, I, I, I, I, P]),
+    "bltvqg_gemm_rowstat": (I, [P, I, P, I, P, I, I, I, I, P, I, F, U64, U32, P, I, P, I, P, I, I, P]),
+    "bltvqg_ln_fold_prepare": (I, [P, I, I, P, P, P, P, P, P, P]),
+    "bltvqg_linear_ln_folded": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, P, F, I, F, U64, U32, I, I, P]),
     "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
     "bltvqg_gemm_repeat": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P]),
     "bltvqg_gemm_rotate": (I, [I, P, I, I, L, P, I, I, L, P, I, I, L, I, I, I, I, I, P]),

@@ -43,6 +43,39 @@ int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int 
     return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
 }
 
+int bltvqg_gemm_rowstat(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu, float drop_p,
+                        uint64_t seed, uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, float* out_stat, int tile_m, int tile_n, void* stream) {
+    BLT_REQUIRE(out_stat != nullptr, "gemm_rowstat: out_stat is null");
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.bias = bias; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id; g.C2 = C2; g.ldc2 = ldc2; g.R = R; g.ldr = ldr;
+    g.out_stat = out_stat;
+    BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g), "gemm_rowstat: operands do not fit the planned-tile kernel (bf16 NT, lda/ldb %% 8 == 0)");
+    BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "gemm_rowstat: tile_m / tile_n must both be 0 or both be a compiled tile shape");
+    g.nt2_bm = tile_m; g.nt2_bn = tile_n;
+    return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
+}
+
+int bltvqg_ln_fold_prepare(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* fold_s,
+                           float* fold_c, void* stream) {
+    return blt_ln_fold_prepare_one(W, gamma, beta, bias, Wf_bf16, fold_s, fold_c, N, K, (hipStream_t)stream);
+}
+
+int bltvqg_linear_ln_folded(const void* X, int ldx, const void* Wf, int ldw, void* Y, int ldy, int M, int N, int K, const float* fold_s, const float* fold_c,
+                            const float* row_stat, float* mean, float* rstd, float eps, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
+                            int tile_m, int tile_n, void* stream) {
+    BLT_REQUIRE(X && Wf && Y && fold_s && fold_c && row_stat && M > 0 && N > 0 && K > 0, "linear_ln_folded: null pointer / bad shape");
+    BLT_REQUIRE((mean == nullptr) == (rstd == nullptr), "linear_ln_folded: mean and rstd go together");
+    GemmArgs g;
+    g.A = X; g.lda = ldx; g.B = Wf; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.K = K;
+    g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id;
+    g.fold_s = fold_s; g.fold_c = fold_c; g.fold_stat = row_stat; g.fold_mean = mean; g.fold_rstd = rstd; g.fold_eps = eps; g.fold_n = (float)K;
+    BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g), "linear_ln_folded: operands do not fit the planned-tile kernel (bf16 NT, ldx/ldw %% 8 == 0)");
+    BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "linear_ln_folded: tile_m / tile_n must both be 0 or both be a compiled tile shape");
+    g.nt2_bm = tile_m; g.nt2_bn = tile_n;
+    return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
+}
+
 int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, const void* const* X, const int32_t* ldx, float* const* dW,
                               const int32_t* ldw, float* const* dbias, const int32_t* rows, const int32_t* N, const int32_t* K, void* table_dev,
                               int64_t table_bytes, void* stream) {

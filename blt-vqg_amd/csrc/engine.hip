@@ -41,6 +41,9 @@ struct Layer {   // saved activations of one transformer layer
     // decoder only
     void *q2, *kv2, *ctx2, *x1b, *xn3;
     float *m3, *r3;
+    // {sum, sum of squares} per row of the inputs of this layer's LayerNorms, left by the GEMM epilogue that produced those rows, for
+    // the Linear each LayerNorm is folded into (st1 of layer 0 = the embedding GEMM's rows: Stack::stat_in)
+    float *st1 = nullptr, *st2 = nullptr, *st3 = nullptr;
     // backward: gradients that are OPERANDS of a (deferred) weight-gradient GEMM live in buffers of their own, never reused inside one
     // backward pass, so that those GEMMs can run on a side stream while the main stream walks on down the chain:
     // gY = d(FFN output before the residual), gF = d(FFN hidden), gQKV = d(q|k|v), dx1..3 = d(sub-layer outputs), and for the
@@ -54,8 +57,12 @@ struct Stack {
     int id = 0;           // dropout stream namespace
     int scr = 0;          // gradient scratch set used by this stack's backward
     int S = 0, M = 0;
+    // only row 0 of every sample of this stack's output is read (the posterior encoder: encoder_transformer.py:35 takes
+    // response_encoder_outputs[:, 0]): everything behind the TOP layer's attention core is row-wise, so it runs on those B rows only
+    bool row0 = false;
     const int* key_ids = nullptr;
     void* x_in = nullptr;
+    float* stat_in = nullptr;   // row statistics of x_in (the embedding GEMM's epilogue; rows_add_stat for the decoder's row 0)
     std::vector<Layer> layers;
     void* out = nullptr;
     float *mF = nullptr, *rF = nullptr;
@@ -231,6 +238,71 @@ struct bltvqg_engine {
     int sync_opt(hipStream_t s) {
         if (!opt_is_pending() || !steps->opt_done_ev) return BLT_OK;
         if (hipStreamWaitEvent(s, steps->opt_done_ev, 0) != hipSuccess) { blt_set_error("engine: optimiser wait failed"); return BLT_ERR_HIP; }
+        return BLT_OK;
+    }
+    // ---- LayerNorm folded into the Linear that consumes it (round 4; bf16, unpadded widths) -------------------------------------------
+    // Every LayerNorm inside the stacks feeds exactly one Linear (q|k|v, the cross-attention query, the first FFN layer):
+    //   LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n,  W' = W diag(gamma), s_n = sum_k W'[n,k], c_n = sum_k beta[k] W[n,k] + b_n.
+    // The GEMM reads the RAW rows x against W' (wshadowF, rebuilt with s / c by ONE launch per optimiser stage: blt_ln_fold_prepare) and
+    // finishes the normalisation in its epilogue; the row sums come from the epilogue of the GEMM that produced x (GemmArgs::out_stat).
+    // 42 of the 45 layernorm_fwd launches of a step disappear (the three stack-final ones stay); the normalised tensor the weight
+    // gradient needs is written by the LayerNorm's BACKWARD launch instead (blt_layernorm_bwd xn_out).  debug key 25 = 1: unfolded (A/B).
+    bool fold_ok = false;
+    void* wshadowF = nullptr;
+    float *fold_s = nullptr, *fold_c = nullptr;
+    std::map<std::string, int> fold_srow;         // consumer weight -> first row in fold_s / fold_c
+    std::vector<BltFoldEnt> fold_tab[2];          // [0] the two encoder stacks (stage-1 parameters of the optimiser), [1] the decoder
+    int fold_nrows[2] = {0, 0};
+    void* fold_tab_dev[2] = {nullptr, nullptr};
+    int fold_rows_total = 0;
+    float *stat_pool = nullptr, *stat_emb = nullptr;
+    size_t stat_pool_floats = 0;
+    bool fold_on() const { return fold_ok && blt_debug_get(25) != 1; }
+    void add_fold(int which, const std::string& wname, int rows, const std::string& ln, const char* bias) {
+        const PInfo& w = tpi(wname);
+        BltFoldEnt e;
+        e.w_off = w.off; e.g_off = tpi(ln + ".weight").off; e.b_off = tpi(ln + ".bias").off; e.bias_off = bias ? tpi(bias).off : -1;
+        e.rows = rows; e.K = w.dims[1]; e.srow = fold_rows_total; e.row0 = fold_nrows[which];
+        fold_srow[wname] = fold_rows_total;
+        fold_rows_total += (rows + 7) / 8 * 8;
+        fold_nrows[which] += rows;
+        fold_tab[which].push_back(e);
+    }
+    void build_fold() {
+        fold_ok = dt == BLT_BF16 && ln_pp == 0 && H % 8 == 0;
+        if (!fold_ok) return;
+        const Stack* sts[3] = {&enc, &renc, &dec};
+        for (const Stack* st : sts)
+            for (int l = 0; l < L; ++l) {
+                const std::string lp = st->prefix + (st->dec ? ".dec." : ".enc.") + std::to_string(l) + ".";
+                const int w = st->dec ? 1 : 0;
+                add_fold(w, lp + (st->dec ? "multi_head_attention_dec." : "multi_head_attention.") + "query_linear.weight", 3 * H,
+                         lp + (st->dec ? "layer_norm_mha_dec" : "layer_norm_mha"), nullptr);
+                if (st->dec) add_fold(w, lp + "multi_head_attention_enc_dec.query_linear.weight", H, lp + "layer_norm_mha_enc", nullptr);
+                add_fold(w, lp + "positionwise_feed_forward.layers.0.weight", F, lp + "layer_norm_ffn", (lp + "positionwise_feed_forward.layers.0.bias").c_str());
+            }
+    }
+    int fold_prepare(int parts, hipStream_t s) {
+        if (!fold_on()) return BLT_OK;
+        for (int w = 0; w < 2; ++w)
+            if (((parts >> w) & 1) && !fold_tab[w].empty()) {
+                const int rc = blt_ln_fold_prepare(train, wshadowF, fold_s, fold_c, fold_tab_dev[w], (int)fold_tab[w].size(), fold_nrows[w], s);
+                if (rc) return rc;
+            }
+        return BLT_OK;
+    }
+    // the folded form of Y = LN(x) W^T (+ b): A = the raw rows, B = W', statistics in / mean, rstd out
+    void set_fold(GemmArgs& g, const void* x, int ldx, const std::string& wname, const float* stat, float* m, float* r) {
+        const PInfo& p = tpi(wname);
+        g.A = x; g.lda = ldx;
+        g.B = (const char*)wshadowF + p.off * 2; g.ldb = p.dims[1];
+        g.bias = nullptr;
+        const int sr = fold_srow.at(wname);
+        g.fold_s = fold_s + sr; g.fold_c = fold_c + sr; g.fold_stat = stat; g.fold_mean = m; g.fold_rstd = r; g.fold_eps = 1e-5f; g.fold_n = (float)H;
+    }
+    int zero_stats(hipStream_t s) {
+        if (!fold_on() || !stat_pool) return BLT_OK;
+        if (hipMemsetAsync(stat_pool, 0, stat_pool_floats * sizeof(float), s) != hipSuccess) { blt_set_error("engine: statistics memset failed"); return BLT_ERR_HIP; }
         return BLT_OK;
     }
     bool use_streams = true;
@@ -513,6 +585,11 @@ struct bltvqg_engine {
         auto AI = [&](int64_t n) -> int* { return (int*)A(n * 4); };
         wshadow = (dt == BLT_BF16) ? A(tsize * 2) : nullptr;
         wshadowT = (dt == BLT_BF16) ? A(tsize * 2) : nullptr;
+        if (fold_ok) {
+            wshadowF = A(tsize * 2);
+            fold_s = AF(fold_rows_total); fold_c = AF(fold_rows_total);
+            for (int w = 0; w < 2; ++w) fold_tab_dev[w] = A((int64_t)fold_tab[w].size() * sizeof(BltFoldEnt) + 64);
+        }
         ttable = (dt == BLT_BF16) ? A((int64_t)tlist.size() * 16) : nullptr;
         const int ce = 16 / es;
         ld_wemb = round_up(E, ce);
@@ -581,6 +658,22 @@ struct bltvqg_engine {
             s.mF = AF(s.M); s.rF = AF(s.M);
         };
         lay_stack(enc); lay_stack(renc); lay_stack(dec);
+        if (fold_ok) {      // one contiguous pool: a single memset per forward
+            int64_t n = 2 * (int64_t)Mtot;
+            for (Stack* st : {&enc, &renc, &dec}) n += (int64_t)L * (st->dec ? 3 : 2) * 2 * st->M;
+            stat_pool_floats = (size_t)n;
+            stat_pool = AF(n);
+            float* q = stat_pool;
+            stat_emb = q; q += 2 * (int64_t)Mtot;
+            enc.stat_in = stat_emb; dec.stat_in = stat_emb + 2 * (int64_t)Ma; renc.stat_in = stat_emb + 2 * (int64_t)(Ma + Mt);
+            for (Stack* st : {&enc, &renc, &dec})
+                for (int l = 0; l < L; ++l) {
+                    Layer& y = st->layers[l];
+                    y.st1 = q; q += 2 * (int64_t)st->M;      // (layer 0 reads Stack::stat_in instead)
+                    y.st2 = q; q += 2 * (int64_t)st->M;
+                    if (st->dec) { y.st3 = q; q += 2 * (int64_t)st->M; }
+                }
+        }
         mlvp_h1 = AT((int64_t)B * 2 * Z); mlvp_h2 = AT((int64_t)B * 2 * Z); mlvp = AT((int64_t)B * 2 * Z);
         cat_in = AT((int64_t)B * 2 * H);
         mlvq_h1 = AT((int64_t)B * 2 * Z); mlvq_h2 = AT((int64_t)B * 2 * Z); mlvq = AT((int64_t)B * 2 * Z);
@@ -631,8 +724,9 @@ struct bltvqg_engine {
         fcb = regions ? "encoder_cnn.region_proj.bias" : "encoder_cnn.cnn.fc.bias";
         build_params();
         enc.prefix = "answer_encoder.encoder"; enc.id = 0; enc.S = Sa; enc.M = Ma;
-        renc.prefix = "answer_encoder.r_encoder"; renc.id = 1; renc.scr = 1; renc.S = Sp; renc.M = Mp;
+        renc.prefix = "answer_encoder.r_encoder"; renc.id = 1; renc.scr = 1; renc.S = Sp; renc.M = Mp; renc.row0 = true;
         dec.prefix = "decoder.decoder"; dec.id = 2; dec.S = T; dec.M = Mt; dec.dec = true;
+        build_fold();
         ws_bytes = layout(nullptr);
     }
 
@@ -775,7 +869,7 @@ struct bltvqg_engine {
     // LayerNorm backward; with deferred weight gradients its dgamma / dbeta go the same way: the launch on the dependent chain only
     // stores per-workgroup partial sums, one reduce launch per flush adds them on the side stream
     int ln_bwd(const void* dy, const void* x, const std::string& ln, const float* mean, const float* rstd, const void* dres, void* dx, long M,
-               hipStream_t s, const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr) {
+               hipStream_t s, const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr, long ld = 0, void* xn_out = nullptr) {
         float* part = nullptr;
         const int grid = blt_layernorm_bwd_grid(M, H);
         if (defer_wgrads && blt_debug_get(7) != 4 && ln_pool && ln_pool_used + (size_t)grid * 2 * H <= ln_pool_floats) {
@@ -785,7 +879,7 @@ struct bltvqg_engine {
             pending_ln.push_back(e);
         }
         return blt_layernorm_bwd(dt, dy, x, P(ln + ".weight"), mean, rstd, dres, dx, G(ln + ".weight"), G(ln + ".bias"), M, H, s, maskY, mask_scale,
-                                 out2, part, ln_pp, ln_pv);
+                                 out2, part, ln_pp, ln_pv, ld, xn_out ? P(ln + ".bias") : nullptr, xn_out);
     }
 
     // dX = dY W with a vocabulary-sized contraction (K = V): few output tiles and a long K loop, so the K range is split over
@@ -826,31 +920,28 @@ struct bltvqg_engine {
         a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
         return blt_attn_fwd(dt, a, s);
     }
-    // attention, then its output Linear with the sub-layer's residual add in the epilogue.  A ONE-launch form exists (bf16, 64-wide heads,
-    // <= 8 heads, <= 32 tokens: attn.hip::attn_out_fwd_kernel, bit-identical, exported as bltvqg_attn_out_fwd) and is NOT used: measured
-    // 7.41 ms per step against 7.14 — a workgroup per batch element streams the whole 512 KB weight through its CU's ~70 GB/s intake
-    // (7+ us) to save a 10 us launch whose own intake is 224 KB.  debug key 22 = 2 selects it (A/B).
+    // Rows of the row-wise part of layer l (everything behind the attention core): all M rows at stride H, or — top layer of a stack
+    // whose output is read at row 0 of every sample only — B rows at stride S * H (row b of the view = row b * S of the tensor).  Nothing
+    // that was computed for the other rows was ever read: the reference computes them and drops them (encoder_transformer.py:24,35).
+    // debug key 23 bit 1: all rows (A/B, and the bit-identity test).
+    struct Rows { int M; int ldH; int ldF; bool sub; };
+    Rows rows_of(const Stack& st, int l) const {
+        if (st.row0 && l == L - 1 && !(blt_debug_get(23) & 2)) return Rows{B, st.S * H, st.S * F, true};
+        return Rows{st.M, H, F, false};
+    }
+    int ln_fwd(const void* x, const std::string& ln, void* out, float* m, float* r, const Rows& rw, hipStream_t s) {
+        return blt_layernorm_fwd(dt, x, P(ln + ".weight"), P(ln + ".bias"), out, m, r, rw.M, H, 1e-5f, s, ln_pp, ln_pv, rw.ldH);
+    }
+    // attention core over all rows, then its output Linear (+ the sub-layer's residual in the epilogue) over the rows of `rw`
     int attn_out_fwd(const void* q, int ldq, const void* k, const void* v, int ldkv, void* ctx, const std::string& wname, const void* resid, void* out,
-                     const int* key_ids, int Tq, int Tk, int causal, uint32_t stream_id, int M, hipStream_t s) {
-        AttnArgs a;
-        a.Q = q; a.ldq = ldq; a.K = k; a.V = v; a.ldk = ldkv; a.ldv = ldkv; a.O = ctx; a.ldo = H; a.key_ids = key_ids;
-        a.B = B; a.heads = NH; a.Tq = Tq; a.Tk = Tk; a.d = dh; a.causal = causal; a.scale = 1.f / sqrtf((float)dh_true);
-        a.drop_p = c.attention_dropout; a.seed = seed; a.stream_id = stream_id;
-        int ldw;
-        a.Wo = W(wname, &ldw); a.ldwo = ldw; a.R = resid; a.ldr = H; a.Y = out; a.ldy = H;
-        if (blt_debug_get(22) == 2 && !ln_fused() && blt_attn_out_fwd_ok(dt, a)) {
-            const bool sampled = (prof_mask & 2) && (prof_gemm_count++ % prof_stride) == 0;
-            const int pi = sampled ? prof_begin(1, s) : -1;
-            if (pi >= 0) prof[pi].w = prof_stride;
-            const int rc = blt_attn_out_fwd(dt, a, s);
-            prof_end(pi, s, 2.0 * (double)M * (double)H * (double)H);      // the Linear's flops (the attention products are not counted in this family)
-            return rc;
-        }
-        RC(blt_attn_fwd(dt, a, s));
-        GemmArgs g = lin(ctx, H, wname, nullptr, out, H, M);
-        g.R = resid; g.ldr = H;
+                     const int* key_ids, int Tq, int Tk, int causal, uint32_t stream_id, const Rows& rw, float* out_stat, hipStream_t s) {
+        RC(attn_fwd(q, ldq, k, v, ldkv, ctx, key_ids, Tq, Tk, causal, stream_id, s));
+        GemmArgs g = lin(ctx, rw.ldH, wname, nullptr, out, rw.ldH, rw.M);
+        g.R = resid; g.ldr = rw.ldH;
+        g.out_stat = out_stat;      // row sums of `out` for the LayerNorm that reads it (folded into ITS consumer)
         return gemm(dt, g, s);
     }
+
     int attn_bwd(const void* q, int ldq, const void* k, const void* v, int ldkv, const void* dO, void* dq, int lddq, void* dk,
                  void* dv, int lddkv, const int* key_ids, int Tq, int Tk, int causal, uint32_t stream_id, hipStream_t s) {
         AttnArgs a;
@@ -861,44 +952,26 @@ struct bltvqg_engine {
         return blt_attn_bwd(dt, a, s);
     }
 
-    // A LayerNorm that directly follows a Linear of the stacks CAN run inside that GEMM's epilogue when a workgroup owns whole rows
-    // (bf16, d_model <= 256; gemm_dma_ln_kernel): set_ln() attaches it, ln_fused() tells the caller to skip its own launch.  Measured
-    // on the B=128 step it does not pay: every workgroup then streams the whole weight matrix, and what the 14 saved launches give
-    // (~5 us each) the slower GEMMs take back (2.91 vs 2.89 ms with 32-row tiles, 2.96 ms with 64-row tiles) — so it is off unless
-    // debug key 7 is 3 (A/B switch); the operator stays exported (bltvqg_linear_layernorm) and tested.
-    bool ln_fused() const { return blt_debug_get(7) == 3 && dt == BLT_BF16 && H <= 256 && H % 8 == 0 && ln_pp == 0; }
-    void set_ln(GemmArgs& g, const std::string& ln, void* out, float* m, float* r) {
-        g.ln_gamma = P(ln + ".weight"); g.ln_beta = P(ln + ".bias"); g.ln_out = out; g.ln_mean = m; g.ln_rstd = r; g.ln_eps = 1e-5f;
-    }
-    struct NextLN { std::string name; void* out = nullptr; float *m = nullptr, *r = nullptr; };
-    // LayerNorm folded into the Linear that consumes it (GemmArgs::lnA_*, gemm_dma_lnA_kernel): every LayerNorm inside the stacks feeds
-    // exactly one GEMM (q|k|v, the cross-attention query, the first FFN layer), so in bf16 with d_model <= 256 none of them needs to be a
-    // launch of its own.  Measured: 14 launches fewer per step and the SAME step time (2.80 ms) — the folded GEMM's load -> normalise ->
-    // MFMA chain is as long as LayerNorm launch + GEMM launch were, which says that these kernels are bound by dependent memory round
-    // trips, not by the launch itself.  Kept as an exported, tested operator (bltvqg_layernorm_linear); the engine uses it only under
-    // debug key 7 = 6 (A/B).
-    bool lnA_on() const { return dt == BLT_BF16 && H <= 256 && H % 8 == 0 && blt_debug_get(7) == 6 && ln_pp == 0; }
-    // GEMM input: the normalised tensor `xn`, or — folded — the raw tensor x plus the LayerNorm that produces xn (written as a by-product)
-    void set_lnA(GemmArgs& g, const void* x, const std::string& ln, void* xn, float* m, float* r) {
-        g.A = x; g.lnA_gamma = P(ln + ".weight"); g.lnA_beta = P(ln + ".bias"); g.lnA_out = xn; g.lnA_mean = m; g.lnA_rstd = r; g.lnA_eps = 1e-5f;
-    }
-
-    // x2 = xres + dropout(relu(W2 dropout(relu(W1 LN(xres) + b1)) + b2)); ln = the FFN's LayerNorm (output xn, statistics m / r);
-    // `next` = the LayerNorm that consumes x2 (next layer's first one or the stack's final one)
-    int ffn_fwd(const std::string& fp_, const std::string& ln, void* xn, float* m, float* r, const void* xres, Layer& y, int M, int stack, int l,
-                const NextLN& next, bool next_is_final, hipStream_t s) {
-        GemmArgs g = lin(xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, F, M);
-        if (lnA_on()) set_lnA(g, xres, ln, xn, m, r);
+    // x2 = xres + dropout(relu(W2 dropout(relu(W1 xn + b1)) + b2)), xn = `ln`(xres): computed by a launch of its own (m / r / xn written
+    // there) or — fold_on() — inside the first Linear from the raw rows and their sums `stat` (m / r written by that GEMM).  out_stat: row
+    // sums of x2 for the next layer's first LayerNorm.
+    int ffn_fwd(const std::string& fp_, const std::string& ln, void* xn, float* m, float* r, const float* stat, const void* xres, Layer& y,
+                const Rows& rw, int stack, int l, float* out_stat, hipStream_t s) {
+        GemmArgs g;
+        if (fold_on()) {
+            g = mk(nullptr, 0, 0, nullptr, 0, 0, y.h, rw.ldF, rw.M, F, H);
+            set_fold(g, xres, rw.ldH, fp_ + "layers.0.weight", stat, m, r);
+        } else {
+            RC(ln_fwd(xres, ln, xn, m, r, rw, s));
+            g = lin(xn, rw.ldH, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, rw.ldF, rw.M);
+        }
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 1);
         RC(gemm(dt, g, s));
-        g = lin(y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), y.x2, H, M);
+        g = lin(y.h, rw.ldF, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), y.x2, rw.ldH, rw.M);
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 2);
-        g.C2 = y.y2; g.ldc2 = H; g.R = xres; g.ldr = H;
-        if (ln_fused()) set_ln(g, next.name, next.out, next.m, next.r);
-        RC(gemm(dt, g, s));
-        if (!ln_fused() && (next_is_final || !lnA_on()))
-            RC(blt_layernorm_fwd(dt, y.x2, P(next.name + ".weight"), P(next.name + ".bias"), next.out, next.m, next.r, M, H, 1e-5f, s, ln_pp, ln_pv));
-        return BLT_OK;
+        g.C2 = y.y2; g.ldc2 = rw.ldH; g.R = xres; g.ldr = rw.ldH;
+        g.out_stat = out_stat;
+        return gemm(dt, g, s);
     }
 
     // encoder-side key/value projections of every decoder layer ([2H,H] fused operand): they depend on encoder_outputs only, so they
@@ -919,50 +992,38 @@ struct bltvqg_engine {
         const int M = st.M, S = st.S;
         const void* x = st.x_in;
         auto lname = [&](int l) { return st.prefix + (st.dec ? ".dec." : ".enc.") + std::to_string(l) + "."; };
-        if (!lnA_on()) {   // the first LayerNorm reads the shared embedding's output
-            const std::string ln1 = lname(0) + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
-            Layer& y0 = st.layers[0];
-            RC(blt_layernorm_fwd(dt, x, P(ln1 + ".weight"), P(ln1 + ".bias"), y0.xn1, y0.m1, y0.r1, M, H, 1e-5f, s, ln_pp, ln_pv));
-        }
+        const Rows all{M, H, F, false};
+        const bool fold = fold_on();
         for (int l = 0; l < L; ++l) {
             Layer& y = st.layers[l];
             const std::string lp = lname(l);
             const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
-            // the LayerNorm behind this layer's FFN: the next layer's first one, or the stack's final one
-            NextLN next;
-            if (l + 1 < L) {
-                next.name = lname(l + 1) + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
-                next.out = st.layers[l + 1].xn1; next.m = st.layers[l + 1].m1; next.r = st.layers[l + 1].r1;
-            } else {
-                next.name = st.prefix + ".layer_norm"; next.out = st.out; next.m = st.mF; next.r = st.rF;
-            }
+            const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
+            const Rows rw = rows_of(st, l);
             // fused QKV projection: query/key/value weights are adjacent in the flat buffer -> one [3H,H] operand
-            {
+            if (fold) {
+                GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, y.qkv, 3 * H, M, 3 * H, H);
+                set_fold(g, x, H, a1 + "query_linear.weight", l == 0 ? st.stat_in : y.st1, y.m1, y.r1);
+                RC(gemm(dt, g, s));
+            } else {
+                RC(ln_fwd(x, ln1, y.xn1, y.m1, y.r1, all, s));
                 int ldw;
                 const void* w = W(a1 + "query_linear.weight", &ldw);
-                GemmArgs g = mk(y.xn1, H, 0, w, ldw, 0, y.qkv, 3 * H, M, 3 * H, H);
-                if (lnA_on()) set_lnA(g, x, lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha"), y.xn1, y.m1, y.r1);
-                RC(gemm(dt, g, s));
+                RC(gemm(dt, mk(y.xn1, H, 0, w, ldw, 0, y.qkv, 3 * H, M, 3 * H, H), s));
             }
             const std::string ln2 = lp + (st.dec ? "layer_norm_mha_enc" : "layer_norm_ffn");
-            if (!ln_fused()) {
-                RC(attn_out_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, a1 + "output_linear.weight",
-                                x, y.x1, st.key_ids, S, S, st.dec ? causal_mode : 0, sid(st.id, l, 0), M, s));
-                if (!lnA_on()) RC(blt_layernorm_fwd(dt, y.x1, P(ln2 + ".weight"), P(ln2 + ".bias"), y.xn2, y.m2, y.r2, M, H, 1e-5f, s, ln_pp, ln_pv));
-            } else {
-                RC(attn_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, st.key_ids, S, S,
-                            st.dec ? causal_mode : 0, sid(st.id, l, 0), s));
-                GemmArgs g = lin(y.ctx, H, a1 + "output_linear.weight", nullptr, y.x1, H, M);
-                g.R = x; g.ldr = H;
-                set_ln(g, ln2, y.xn2, y.m2, y.r2);
-                RC(gemm(dt, g, s));
-            }
+            RC(attn_out_fwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, y.ctx, a1 + "output_linear.weight",
+                            x, y.x1, st.key_ids, S, S, st.dec ? causal_mode : 0, sid(st.id, l, 0), rw, fold ? y.st2 : nullptr, s));
+            float* next_stat = (fold && l + 1 < L) ? st.layers[l + 1].st1 : nullptr;
             if (st.dec) {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
-                {
-                    GemmArgs g = lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M);
-                    if (lnA_on()) set_lnA(g, y.x1, ln2, y.xn2, y.m2, y.r2);
+                if (fold) {
+                    GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, y.q2, H, M, H, H);
+                    set_fold(g, y.x1, H, a2 + "query_linear.weight", y.st2, y.m2, y.r2);
                     RC(gemm(dt, g, s));
+                } else {
+                    RC(ln_fwd(y.x1, ln2, y.xn2, y.m2, y.r2, rw, s));
+                    RC(gemm(dt, lin(y.xn2, H, a2 + "query_linear.weight", nullptr, y.q2, H, M), s));
                 }
                 if (!kv_hoisted) {
                     int ldw;
@@ -972,25 +1033,17 @@ struct bltvqg_engine {
                     blt_set_error("engine_forward: stream wait failed");
                     return BLT_ERR_HIP;
                 }
-                const std::string ln3 = lp + "layer_norm_ffn";
-                if (!ln_fused()) {
-                    RC(attn_out_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, a2 + "output_linear.weight", y.x1, y.x1b, src_ids, S, Sa,
-                                    0, sid(st.id, l, 3), M, s));
-                    if (!lnA_on()) RC(blt_layernorm_fwd(dt, y.x1b, P(ln3 + ".weight"), P(ln3 + ".bias"), y.xn3, y.m3, y.r3, M, H, 1e-5f, s, ln_pp, ln_pv));
-                } else {
-                    RC(attn_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, src_ids, S, Sa, 0, sid(st.id, l, 3), s));
-                    GemmArgs g = lin(y.ctx2, H, a2 + "output_linear.weight", nullptr, y.x1b, H, M);
-                    g.R = y.x1; g.ldr = H;
-                    set_ln(g, ln3, y.xn3, y.m3, y.r3);
-                    RC(gemm(dt, g, s));
-                }
-                RC(ffn_fwd(lp + "positionwise_feed_forward.", ln3, y.xn3, y.m3, y.r3, y.x1b, y, M, st.id, l, next, l + 1 == L, s));
+                RC(attn_out_fwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, y.ctx2, a2 + "output_linear.weight", y.x1, y.x1b, src_ids, S, Sa,
+                                0, sid(st.id, l, 3), rw, fold ? y.st3 : nullptr, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", lp + "layer_norm_ffn", y.xn3, y.m3, y.r3, y.st3, y.x1b, y, rw, st.id, l, next_stat, s));
             } else {
-                RC(ffn_fwd(lp + "positionwise_feed_forward.", ln2, y.xn2, y.m2, y.r2, y.x1, y, M, st.id, l, next, l + 1 == L, s));
+                RC(ffn_fwd(lp + "positionwise_feed_forward.", ln2, y.xn2, y.m2, y.r2, y.st2, y.x1, y, rw, st.id, l, next_stat, s));
             }
             x = y.x2;
         }
-        return BLT_OK;
+        // the stack's final LayerNorm (transformer_layers.py:150,219) over the rows the top layer produced: a launch of its own (its
+        // consumers are not one Linear: the row-0 injections, the cross-attention K/V projections of six layers, the vocabulary projection)
+        return ln_fwd(x, st.prefix + ".layer_norm", st.out, st.mF, st.rF, rows_of(st, L - 1), s);
     }
 
     // the LDS-patch kernel can take the previous convolution's raw output and apply its BatchNorm + ReLU on the staged patch
@@ -1217,6 +1270,7 @@ struct bltvqg_engine {
         if (opt_is_pending() && !overlap_opt) { RC(sync_opt(s)); opt_mark_synced(); }
         // loss statistics [0..3]; [4] (gradient norm) belongs to the optimiser, which may still be reading it
         if (hipMemsetAsync(stats - 1, 0, 5 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
+        RC(zero_stats(s));      // row statistics of the folded LayerNorms (every stream of this forward is forked from `s` behind this)
         if (overlap_opt) {
             // The frozen CNN does not depend on the update: it is enqueued first (unless it ran ahead: then the encoders' launches are),
             // everything else goes behind the optimiser — the token / encoder streams behind its FIRST stage only (embedding + encoder
@@ -1247,7 +1301,7 @@ struct bltvqg_engine {
             }
             RC(fork(s0, side[1], fj[1]));
             RC(stack_fwd(enc, nullptr, nullptr, side[1]));
-            RC(stack_fwd(renc, nullptr, nullptr, s0));
+            if (run_renc()) RC(stack_fwd(renc, nullptr, nullptr, s0));
             if (ahead) { RC(cnn_fwd(images, s)); stamp(11, s); }      // (waits for the prefetched feature and the whole update, then the head)
             if (staged && ahead) {
                 RC(shadows(s, 2, derive));
@@ -1270,8 +1324,7 @@ struct bltvqg_engine {
         // side streams exist, so that the GPU is not left waiting for it behind the (short) encoder stacks' enqueue
         if (use_streams) { RC(cnn_fwd(images, s)); stamp(11, s); }      // [11] image feature done (CNN stream, before the encoders are joined)
         RC(stack_fwd(enc, nullptr, nullptr, s1));
-        // the reference runs r_encoder in both phases (encoder_transformer.py:23-25)
-        RC(stack_fwd(renc, nullptr, nullptr, s0));
+        if (run_renc()) RC(stack_fwd(renc, nullptr, nullptr, s0));
         if (!use_streams) RC(cnn_fwd(images, s));
         if (use_streams) { RC(fork(s0, s, fj[2])); RC(fork(s1, s, fj[3])); }
         return forward_tail(eps, s);
@@ -1296,11 +1349,19 @@ struct bltvqg_engine {
     int shadows(hipStream_t s, int parts, bool derive) {
         if (dt != BLT_BF16 || tlist.empty()) return BLT_OK;
         const int n = (int)tlist.size();
+        // (the gamma-folded operands W' / s / c of the LayerNorm consumers are rebuilt from the fp32 parameters with the same parts)
+        RC(fold_prepare(parts, s));
         if (parts == 3) return shadow_range(0, n, derive, s);
         if (parts & 1) { RC(shadow_range(t_dec_n, t_main_n, derive, s)); RC(shadow_range(t_heads_n, n, derive, s)); }
         if (parts & 2) { RC(shadow_range(0, t_dec_n, derive, s)); RC(shadow_range(t_main_n, t_heads_n, derive, s)); }
         return BLT_OK;
     }
+
+    // The posterior encoder's output feeds the latent layer only (encoder_transformer.py:33-35): while `latent_transformer` is off
+    // (train_iq.py:108-111, the first num_pretraining_steps steps) the reference still runs r_encoder and drops the result
+    // (encoder_transformer.py:23-25) — no output, loss, gradient or statistic depends on it, and dropout here is addressed by site id, so
+    // skipping it shifts no random stream.  debug key 23 bit 0: run it anyway (A/B and the bit-identity test).
+    bool run_renc() const { return phase2 || (blt_debug_get(23) & 1); }
 
     int forward_tokens(const int64_t* ctx, const int64_t* post, const int64_t* tgt, hipStream_t s, hipStream_t se, bool with_shadows = true) {
         if (with_shadows) {
@@ -1313,19 +1374,29 @@ struct bltvqg_engine {
                            tgt32, ctx32, post32, counters, V, stats - 1, s));
         if (se != s) RC(fork(s, se, fj[0]));
         // shared embedding over the three token streams at once (iq.py:72-78): gather -> Linear(E,H) + bias + timing signal
-        RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Mtot, E, Epad, se));
+        // (token rows are ordered context | target | posterior: without the posterior encoder its rows are not embedded either)
+        const int Memb = run_renc() ? Mtot : Ma + Mt;
+        RC(blt_embed_gather(dt, P("embedding.0.weight"), ids_all, emb_rows, Memb, E, Epad, se));
         {
             int ldw;
             const void* w = W("embedding.1.weight", &ldw);
-            GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Mtot, H, E);
+            GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Memb, H, E);
             g.bias = P("embedding.1.bias");
             g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
+            if (fold_on()) g.out_stat = stat_emb;      // the first LayerNorm of every stack is folded into its q|k|v projection
             RC(gemm(dt, g, se));
         }
         enc.x_in = X_all; enc.key_ids = ctx32;
         dec.x_in = (char*)X_all + (size_t)Ma * H * es; dec.key_ids = tgt_shift;
         renc.x_in = (char*)X_all + (size_t)(Ma + Mt) * H * es; renc.key_ids = post32;
         return BLT_OK;
+    }
+
+    // target_embedding[:,0] += image_features (+ z) (decoder_transformer.py:31,34); with folded LayerNorms the row sums of those B rows
+    // (left by the embedding GEMM) are replaced by those of the new rows
+    int dec_row0_add(const void* z, hipStream_t s) {
+        if (fold_on()) return blt_rows_add_stat(dt, dec.x_in, (long)T * H, feats, H, z, H, B, H, 1, dec.stat_in, 2L * T, s);
+        return blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, z, H, B, H, 1, s);
     }
 
     // everything after the image feature exists: latent, decoder, vocabulary projection, reconstructor (all on `s`)
@@ -1350,13 +1421,13 @@ struct bltvqg_engine {
             RC(blt_latent_fwd(dt, mlvp, mlvq, eps_dev, zlat, stats + 2, B, Z, 2 * Z, s));
             RC(gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
             // target_embedding[:,0] += image_features + z ; z_logit = z_classifier(z + image_features)
-            RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, zproj, H, B, H, 1, s));
+            RC(dec_row0_add(zproj, s));
             if (sb != s) RC(fork(s, sb, fj[12]));            // the branch continues behind z
             RC(blt_rows_add(dt, zc_in, H, feats, H, zproj, H, B, H, 0, sb));
             RC(gemm(dt, lin(zc_in, H, "decoder.z_classifier.weight", "decoder.z_classifier.bias", zlogit, ldV, B), sb));
             RC(blt_rows_add(dt, r_in, H, enc.out, (long)Sa * H, zproj, H, B, H, 0, sb));
         } else {
-            RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, nullptr, 0, B, H, 1, s));
+            RC(dec_row0_add(nullptr, s));
             if (sb != s) { RC(fork(s, sb, fj[11])); RC(dec_kv_fwd(sb)); }
             RC(blt_copy2d(dt, enc.out, Sa * H, r_in, H, B, H, sb));
         }
@@ -1399,6 +1470,8 @@ struct bltvqg_engine {
     }
     int decode_body(const float* images, const int64_t* ctx, const float* eps, int* tokens, int* top_idx, float* top_val, hipStream_t s) {
         if (dt == BLT_BF16) RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
+        RC(fold_prepare(3, s));
+        RC(zero_stats(s));
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         if (hipMemsetAsync(stats - 1, 0, sizeof(float), s) != hipSuccess) { blt_set_error("engine_decode_greedy: memset failed"); return BLT_ERR_HIP; }
         RC(blt_prep_decode((const long long*)ctx, B, Sa, T, ids_all, pos_all, ctx32, V, stats - 1, s));
@@ -1411,6 +1484,7 @@ struct bltvqg_engine {
             GemmArgs g = mk((char*)emb_rows + (size_t)row0 * Epad * es, Epad, 0, we, ldw, 0, (char*)X_all + (size_t)row0 * H * es, H, rows, H, E);
             g.bias = P("embedding.1.bias");
             g.rowtab = timing; g.rowidx = pos_all + row0; g.ldt = H;
+            if (fold_on()) g.out_stat = stat_emb + 2 * (size_t)row0;
             return gemm(dt, g, s);
         };
         RC(embed(0, Ma));
@@ -1427,8 +1501,9 @@ struct bltvqg_engine {
             RC(gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
         }
         for (int t = 0; t < T; ++t) {
+            RC(zero_stats(s));      // (every pass recomputes the decoder rows: their statistics start from zero again; the encoder's are dead by now)
             RC(embed(Ma, Mt));
-            RC(blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, phase2 ? zproj : nullptr, H, B, H, 1, s));     // [:,0] += z + image_features
+            RC(dec_row0_add(phase2 ? zproj : nullptr, s));     // [:,0] += z + image_features
             RC(stack_fwd(dec, enc.out, ctx32, s));
             GemmArgs g = lin((char*)dec.out + (size_t)t * H * es, T * H, "decoder.output.weight", "decoder.output.bias", zlogit, ldV, B);
             RC(gemm(dt, g, s));
@@ -1440,19 +1515,20 @@ struct bltvqg_engine {
     // ---------------------------------------------------------------------------------------------
     // backward pieces.  `dx` holds the gradient w.r.t. the layer OUTPUT on entry and w.r.t. its INPUT on exit.
     // ---------------------------------------------------------------------------------------------
-    // dx_in = d(sub-layer output); dx_out = d(sub-layer input) = LayerNorm backward of the FFN branch + dx_in (residual)
+    // dx_in = d(sub-layer output); dx_out = d(sub-layer input) = LayerNorm backward of the FFN branch + dx_in (residual); over the rows of `rw`
     int ffn_bwd(const std::string& fp_, const void* xn, const void* xres, const float* m, const float* r, const std::string& ln,
-                Layer& y, const void* dx_in, void* dx_out, int M, int k, hipStream_t s) {
+                Layer& y, const void* dx_in, void* dx_out, const Rows& rw, int k, hipStream_t s) {
         void* gB = sB[k];
         const float ks = relu_ks();
         // y.gY = d(FFN output) through the ReLU + dropout: already written by the LayerNorm backward that produced dx_in
-        RC(wgrad_later(y.gY, H, y.h, F, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), M, s));
-        GemmArgs g = dgrad(y.gY, H, fp_ + "layers.1.weight", y.gF, F, M);
-        g.maskY = y.h; g.ldm = F; g.mask_scale = ks;
+        RC(wgrad_later(y.gY, rw.ldH, y.h, rw.ldF, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), rw.M, s));
+        GemmArgs g = dgrad(y.gY, rw.ldH, fp_ + "layers.1.weight", y.gF, rw.ldF, rw.M);
+        g.maskY = y.h; g.ldm = rw.ldF; g.mask_scale = ks;
         RC(gemm(dt, g, s));
-        RC(wgrad_later(y.gF, F, xn, H, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), M, s));
-        RC(gemm(dt, dgrad(y.gF, F, fp_ + "layers.0.weight", gB, H, M), s));
-        return ln_bwd(gB, xres, ln, m, r, dx_in, dx_out, M, s);
+        RC(gemm(dt, dgrad(y.gF, rw.ldF, fp_ + "layers.0.weight", gB, rw.ldH, rw.M), s));
+        // (folded LayerNorm: its output xn — the X operand of the first Linear's weight gradient — is written by THIS backward launch)
+        RC(ln_bwd(gB, xres, ln, m, r, dx_in, dx_out, rw.M, s, nullptr, 1.f, nullptr, rw.ldH, fold_on() ? const_cast<void*>(xn) : nullptr));
+        return wgrad_later(y.gF, rw.ldF, xn, rw.ldH, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), rw.M, s);
     }
 
     // `dx` holds d(stack output before the final LayerNorm) on entry and d(stack input) on exit; the gradients in between live in the
@@ -1468,8 +1544,17 @@ struct bltvqg_engine {
             const std::string lp = st.prefix + (st.dec ? ".dec." : ".enc.") + std::to_string(l) + ".";
             const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
             const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
+            const Rows rw = rows_of(st, l);
+            if (rw.sub) {
+                // row-0-only top layer: its row-wise backward touches B strided rows; the attention core below and the residual gradient of
+                // the first LayerNorm's backward read ALL rows, whose gradient is zero everywhere else
+                if (hipMemsetAsync(y.dx1, 0, (size_t)M * H * es, s) != hipSuccess || hipMemsetAsync(gA, 0, (size_t)M * H * es, s) != hipSuccess) {
+                    blt_set_error("backward: memset failed");
+                    return BLT_ERR_HIP;
+                }
+            }
             if (st.dec) {
-                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, cur, y.dx1, M, st.scr, s));
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, cur, y.dx1, rw, st.scr, s));
                 cur = y.dx1;
                 // encoder-decoder attention
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
@@ -1477,7 +1562,6 @@ struct bltvqg_engine {
                 RC(gemm(dt, dgrad(cur, H, a2 + "output_linear.weight", gA, H, M), s));
                 RC(attn_bwd(y.q2, H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, gA, y.gQ, H, y.gKV, (char*)y.gKV + (size_t)H * es, 2 * H, src_ids,
                             S, Sa, 0, sid(st.id, l, 3), s));
-                RC(wgrad_later(y.gQ, H, y.xn2, H, a2 + "query_linear.weight", nullptr, M, s));
                 RC(gemm(dt, dgrad(y.gQ, H, a2 + "query_linear.weight", gC, H, M), s));
                 {   // key/value projections of encoder_outputs: [2H,H] fused
                     const PInfo& pk = tpi(a2 + "key_linear.weight");
@@ -1489,39 +1573,45 @@ struct bltvqg_engine {
                     RC(gemm(dt, g, s));
                 }
                 const std::string ln2 = lp + "layer_norm_mha_enc";
-                RC(ln_bwd(gC, y.x1, ln2, y.m2, y.r2, cur, y.dx2, M, s));
+                RC(ln_bwd(gC, y.x1, ln2, y.m2, y.r2, cur, y.dx2, M, s, nullptr, 1.f, nullptr, 0, fold_on() ? y.xn2 : nullptr));
+                RC(wgrad_later(y.gQ, H, y.xn2, H, a2 + "query_linear.weight", nullptr, M, s));
                 cur = y.dx2;
             } else {
-                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, cur, y.dx1, M, st.scr, s));
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, cur, y.dx1, rw, st.scr, s));
                 cur = y.dx1;
             }
-            // self attention
-            RC(wgrad_later(cur, H, y.ctx, H, a1 + "output_linear.weight", nullptr, M, s));
-            RC(gemm(dt, dgrad(cur, H, a1 + "output_linear.weight", gA, H, M), s));
+            // self attention: output projection over the rows of `rw`, the attention core and the q|k|v projection over all rows
+            RC(wgrad_later(cur, rw.ldH, y.ctx, rw.ldH, a1 + "output_linear.weight", nullptr, rw.M, s));
+            RC(gemm(dt, dgrad(cur, rw.ldH, a1 + "output_linear.weight", gA, rw.ldH, rw.M), s));
             RC(attn_bwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, gA, y.gQKV, 3 * H,
                         (char*)y.gQKV + (size_t)H * es, (char*)y.gQKV + (size_t)2 * H * es, 3 * H, st.key_ids, S, S, st.dec ? 1 : 0, sid(st.id, l, 0), s));
-            {
-                const PInfo& pq = tpi(a1 + "query_linear.weight");
-                GemmArgs g = mk(y.gQKV, 3 * H, 1, y.xn1, H, 1, grad + pq.off, H, 3 * H, H, M);
-                g.out_f32 = 1; g.split_k = 32;
-                RC(wgrad_later(g, s));
-                RC(gemm(dt, dgrad_rows(y.gQKV, 3 * H, a1 + "query_linear.weight", 3 * H, gB, H, M), s));
-            }
+            RC(gemm(dt, dgrad_rows(y.gQKV, 3 * H, a1 + "query_linear.weight", 3 * H, gB, H, M), s));
             // the last sub-layer of the stack writes d(stack input) back into the caller's buffer (its old content is dead by now:
             // only the top layer's FFN branch read it, on this same stream)
             void* out = (l == 0) ? dx : (st.dec ? y.dx3 : y.dx2);
             // ... and, for the layer below, the masked gradient that opens its FFN backward (ffn_bwd)
             const void* nmask = (l > 0) ? st.layers[l - 1].y2 : nullptr;
             void* ngY = (l > 0) ? st.layers[l - 1].gY : nullptr;
-            RC(ln_bwd(gB, x, ln1, y.m1, y.r1, cur, out, M, s, nmask, relu_ks(), ngY));
+            RC(ln_bwd(gB, x, ln1, y.m1, y.r1, cur, out, M, s, nmask, relu_ks(), ngY, 0, fold_on() ? y.xn1 : nullptr));
+            {   // q|k|v weight gradient: its X operand is this LayerNorm's output
+                const PInfo& pq = tpi(a1 + "query_linear.weight");
+                GemmArgs g = mk(y.gQKV, 3 * H, 1, y.xn1, H, 1, grad + pq.off, H, 3 * H, H, M);
+                g.out_f32 = 1; g.split_k = 32;
+                RC(wgrad_later(g, s));
+            }
             cur = out;
             // in-stack flush points (build_params: groups of whole layers of >= ~32 MB of parameters): the collected weight gradients go
             // to the weight-gradient stream now, run under the rest of THIS chain and close a gradient bucket, whose all-reduce (N > 1)
             // can start while backward is still running.  only while group_flush is on (a data-parallel exchange exists)
             // (debug key 21, A/B: bit mask of the stacks that flush in-stack although no exchange asked for it: 1 decoder, 2 context, 4 posterior)
             const bool forced = (blt_debug_get(21) >> (st.dec ? 0 : (st.id == 0 ? 1 : 2))) & 1;
-            if (defer_wgrads && ((group_flush && blt_debug_get(19) != 1) || forced) && flush_plan && (*flush_plan)[l] >= 0)      // (key 19 = 1: A/B, no in-stack flush)
+            if (defer_wgrads && ((group_flush && blt_debug_get(19) != 1) || forced) && flush_plan && (*flush_plan)[l] >= 0) {      // (key 19 = 1: A/B, no in-stack flush)
+                // The decoder's first flush carries the reconstructor's / z_classifier's weight gradients too, whose operands (d_recon, g_rec1,
+                // dzl) are written on the BRANCH stream side[0] (backward_core); `s` joins that branch only behind the decoder chain, so the
+                // weight-gradient stream orders itself behind the branch here (fj[12] was recorded on it before this chain started)
+                if (st.dec && use_streams && hipStreamWaitEvent(side[1], fj[12], 0) != hipSuccess) { blt_set_error("backward: stream join failed"); return BLT_ERR_HIP; }
                 RC(flush_wgrads(s, side[1], fj[6], (*flush_plan)[l]));
+            }
         }
         return BLT_OK;
     }
@@ -1616,12 +1706,14 @@ struct bltvqg_engine {
         if (phase2) {
             // ---- posterior encoder (side stream, own scratch set): only row 0 of its output carries gradient ----
             if (s0 != s) RC(fork(s, s0, fj[4]));
-            if (hipMemsetAsync(d_renc, 0, (size_t)Mp * H * es, s0) != hipSuccess) { blt_set_error("backward: memset failed"); return BLT_ERR_HIP; }
+            // (row-0-only top layer: the final LayerNorm's backward reads and writes those B rows only, nothing reads the others)
+            const Rows rwP = rows_of(renc, L - 1);
+            if (!rwP.sub && hipMemsetAsync(d_renc, 0, (size_t)Mp * H * es, s0) != hipSuccess) { blt_set_error("backward: memset failed"); return BLT_ERR_HIP; }
             RC(blt_rows_add(dt, d_renc, (long)Sp * H, g_cat, 2 * H, nullptr, 0, B, H, 0, s0));
             void* dxP = (char*)dX_all + (size_t)(Ma + Mt) * H * es;
             const void* xL = renc.layers[L - 1].x2;
-            RC(ln_bwd(d_renc, xL, "answer_encoder.r_encoder.layer_norm", renc.mF, renc.rF, nullptr, dxP, Mp, s0, renc.layers[L - 1].y2, relu_ks(),
-                      renc.layers[L - 1].gY));
+            RC(ln_bwd(d_renc, xL, "answer_encoder.r_encoder.layer_norm", renc.mF, renc.rF, nullptr, dxP, rwP.M, s0, renc.layers[L - 1].y2, relu_ks(),
+                      renc.layers[L - 1].gY, rwP.ldH));
             RC(stack_bwd(renc, dxP, nullptr, nullptr, s0, &renc_flush));
             // the main stream will join s0 at THIS point (it needs the chain's result for the embedding backward); the posterior
             // encoder's weight gradients then run on s0 behind it, beside the context encoder's on side[1], and are joined at the very end
@@ -1878,6 +1970,12 @@ int bltvqg_engine_bind(bltvqg_engine* e, float* train, float* grad, float* adam_
             blt_set_error("engine_bind: transposed-shadow table upload failed");
             return BLT_ERR_HIP;
         }
+        for (int w = 0; w < 2; ++w)
+            if (e->fold_ok && !e->fold_tab[w].empty() &&
+                hipMemcpy(e->fold_tab_dev[w], e->fold_tab[w].data(), e->fold_tab[w].size() * sizeof(BltFoldEnt), hipMemcpyHostToDevice) != hipSuccess) {
+                blt_set_error("engine_bind: LayerNorm-fold table upload failed");
+                return BLT_ERR_HIP;
+            }
     }
     if (!e->grad_zero_ev && hipEventCreateWithFlags(&e->grad_zero_ev, hipEventDisableTiming) != hipSuccess) {
         blt_set_error("engine_bind: event creation failed");

@@ -1132,9 +1132,9 @@ int dispatch_tile(const GemmArgs& a, int bm, int bn, int splits, hipStream_t s) 
 // [16] = 1 VALU attention kernels instead of the MFMA form; [17] = 1 bn1 as a separate pass (not fused into conv2's patch staging);
 // [18] = 1 stem and max-pool as two launches; [19] conv3x3_pp tile form (1 = 128 positions everywhere, 2 = 256 positions also for
 // Cout % 128 == 0).  Every key defaults to 0 = the shipped path; the A/B keys exist so that tests and measurements can compare forms.
-static int g_debug[24] = {0};
-void blt_debug_set(int key, int value) { if (key >= 0 && key < 24) g_debug[key] = value; }
-int blt_debug_get(int key) { return (key >= 0 && key < 24) ? g_debug[key] : 0; }
+static int g_debug[32] = {0};
+void blt_debug_set(int key, int value) { if (key >= 0 && key < 32) g_debug[key] = value; }
+int blt_debug_get(int key) { return (key >= 0 && key < 32) ? g_debug[key] : 0; }
 
 struct Choice { int bm, bn, no_dma; };
 static std::unordered_map<uint64_t, Choice> g_tuned;     // filled by autotune mode: measured best kernel per GEMM descriptor
@@ -1291,8 +1291,10 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
                     ((uintptr_t)a.ln_gamma % 16) == 0 && ((uintptr_t)a.ln_beta % 16) == 0 && ((uintptr_t)a.ln_out % 16) == 0, "gemm: fused LayerNorm operands must be 16-byte aligned");
         return launch_dma_ln(a, stream);
     }
-    if (!g_debug[8] && !a.force_tile && !a.no_dma && blt_gemm_nt2_ok(dtype, a))
+    if ((!g_debug[8] || a.fold_s || a.out_stat) && !a.force_tile && !a.no_dma && blt_gemm_nt2_ok(dtype, a))
         return blt_gemm_nt2(a, stream, a.nt2_bm ? a.nt2_bm : g_debug[9], a.nt2_bm ? a.nt2_bn : g_debug[10]);
+    BLT_REQUIRE(!a.fold_s && !a.out_stat, "gemm: the LayerNorm-fold / row-statistics epilogue needs the planned-tile bf16 NT kernel (bf16, k-contiguous "
+                                          "operands with ld %% 8 == 0, no residual / mask / second output with fold)");
     const int splits = blt_gemm_splits(a, dtype);
     if (g_debug[2] && splits == 1 && !a.accumulate && !a.force_tile && g_tuned.find(tune_key(a, dtype)) == g_tuned.end()) {
         int rc = autotune(dtype, a, stream);

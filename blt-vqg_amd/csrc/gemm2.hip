@@ -83,14 +83,27 @@ struct Nt2 {
     static_assert(LDS <= NT2_LDS_CAP, "LDS budget");
 };
 
-template <typename C>
+// sum over the GPR (8, 16 or 32) consecutive lanes that hold one result row (all lanes of the wave take part)
+template <int GPR>
+__device__ __forceinline__ float rowgroup_sum(float v) {
+    v += dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);                       // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);                      // row_half_mirror: the other quad of the 8
+    if (GPR >= 16) v += dpp_mov<0x140>(v);       // row_mirror: the other half of the 16
+    if (GPR >= 32) { float a, b; xor16_pair(v, a, b); v = a + b; }
+    return v;
+}
+
+// FOLD: the consumer of a LayerNorm (GemmArgs::fold_*): A holds the RAW rows, B the gamma-scaled weight shadow W'; the epilogue finishes
+// rstd_m * (acc - mean_m * s_n) + c_n.  Those launches (q|k|v, cross-attention query, first FFN layer) carry no bias / residual / mask /
+// second output / row table, so the variant reuses their registers.
+template <typename C, bool FOLD>
 __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
-    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NW = C::NW, NT = C::NT, TM = C::TM, TN = C::TN, CS = C::CS;
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NW = C::NW, TM = C::TM, TN = C::TN, CS = C::CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::NWN, wn = wave % C::NWN;
-    const int tiles_n = (p.N + BN - 1) / BN;
     // consecutive workgroups walk down a column of tiles: they share the B (weight) panel, and A panels are re-read tiles_n times from L2
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tile_n = blockIdx.x / tiles_m, tile_m = blockIdx.x % tiles_m;
@@ -157,17 +170,49 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
     const bool pre_ok = (p.ldr % 8 == 0) && (p.ldm % 8 == 0);
     const bool fast = t_on && (nv == 8) && pre_ok && (p.ldc % 8 == 0) && (!p.C2 || p.ldc2 % 8 == 0) && (!p.rowtab || p.ldt % 4 == 0) &&
                       (!p.bias || (((uintptr_t)(p.bias + n)) & 15) == 0);
-    float bias[8];
+    float bias[8], fsn[FOLD ? 8 : 1];
+    float f_mu[FOLD ? TM : 1][FOLD ? IPP : 1], f_rs[FOLD ? TM : 1][FOLD ? IPP : 1];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
-    if (p.bias && t_on) {
-        if (fast) Vec8<float>::load(p.bias + n, bias);
-        else {
+    {
+        const float* bp = FOLD ? p.fold_c : p.bias;      // (folded: c_n = sum_k beta_k W[n,k] + b_n takes the bias' place)
+        if (bp && t_on) {
+            if (fast) Vec8<float>::load(bp + n, bias);
+            else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) if (e < nv) bias[e] = p.bias[n + e];
+                for (int e = 0; e < 8; ++e) if (e < nv) bias[e] = bp[n + e];
+            }
         }
     }
-    if (fast) {
+    if constexpr (FOLD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fsn[e] = 0.f;
+        if (t_on) {
+            if (fast && (((uintptr_t)(p.fold_s + n)) & 15) == 0) Vec8<float>::load(p.fold_s + n, fsn);
+            else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) if (e < nv) fsn[e] = p.fold_s[n + e];
+            }
+        }
+        // LayerNorm statistics of this thread's rows from the sums the producer of A left behind: mean = S1 / n, var = S2 / n - mean^2
+        // (fp32; biased, as nn.LayerNorm); the first column group of the first column tile also stores mean / rstd for the backward
+#pragma unroll
+        for (int pp = 0; pp < TM; ++pp)
+#pragma unroll
+            for (int q = 0; q < IPP; ++q) {
+                const int sr = sr0 + q * RPS;
+                const int m = m0 + (sr >> 4) * C::WM + pp * 16 + (sr & 15);
+                float mu = 0.f, rs = 0.f;
+                if (sr < C::SLAB_ROWS && m < p.M) {
+                    const float2 st = *reinterpret_cast<const float2*>(p.fold_stat + 2 * (size_t)m);
+                    mu = st.x / p.fold_n;
+                    rs = rsqrtf(fmaxf(st.y / p.fold_n - mu * mu, 0.f) + p.fold_eps);
+                    if (tile_n == 0 && cg == 0 && p.fold_mean != nullptr) { p.fold_mean[m] = mu; p.fold_rstd[m] = rs; }
+                }
+                f_mu[pp][q] = mu; f_rs[pp][q] = rs;
+            }
+    }
+    if (!FOLD && fast) {
 #pragma unroll
         for (int pp = 0; pp < TM; ++pp)
 #pragma unroll
@@ -242,21 +287,27 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) Cs[(wm * 16 + lg * 4 + r) * CS + wn * C::WN + j * 16 + l15] = acc[pp][j][r];
         __syncthreads();      // slab pp complete; slab pp-1's readers are behind this barrier too, so pp+1 may overwrite it next pass
-        if (!t_on) continue;
 #pragma unroll
         for (int q = 0; q < IPP; ++q) {
             const int sr = sr0 + q * RPS;
             const int m = m0 + (sr >> 4) * C::WM + pp * 16 + (sr & 15);
-            if (sr >= C::SLAB_ROWS || m >= p.M) continue;
+            const bool act = t_on && sr < C::SLAB_ROWS && m < p.M;
+            float st1 = 0.f, st2 = 0.f;
+            if (act) {
             float v[8], t[8];
             {
                 const float4 x0 = *reinterpret_cast<const float4*>(&Cs[sr * CS + cg * 8]);
                 const float4 x1 = *reinterpret_cast<const float4*>(&Cs[sr * CS + cg * 8 + 4]);
                 v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
             }
+            if constexpr (FOLD) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
-            if (p.rowtab) {
+                for (int e = 0; e < 8; ++e) v[e] = f_rs[pp][q] * (v[e] - f_mu[pp][q] * fsn[e]) + bias[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
+            }
+            if (!FOLD && p.rowtab) {
                 const float* tr = p.rowtab + (size_t)p.rowidx[m] * p.ldt + n;
                 if (fast) {
                     Vec8<float>::load(tr, t);
@@ -277,6 +328,7 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (dropout_lane(w, e) >= thresh) ? v[e] * keep_scale : 0.f;
             }
+            if constexpr (!FOLD) {
             if (p.maskY) {
                 if (fast) {
                     uint4 mraw = rP[pp][q];
@@ -309,26 +361,48 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
                     for (int e = 0; e < 8; ++e) if (e < nv) v[e] += (float)rp[e];
                 }
             }
+            }
             bf16* cp = (bf16*)p.C + (size_t)m * p.ldc + n;
+            bf16x8 ov;
             if (fast) {
-                if (p.accumulate) {
+                if (!FOLD && p.accumulate) {
                     Vec8<bf16>::load(cp, t);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += t[e];
                 }
-                Vec8<bf16>::store(cp, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[e] = (bf16)v[e];
+                *reinterpret_cast<bf16x8*>(cp) = ov;
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) if (e < nv) cp[e] = (bf16)(p.accumulate ? (float)cp[e] + v[e] : v[e]);
+                for (int e = 0; e < 8; ++e) {
+                    ov[e] = (bf16)0.f;
+                    if (e < nv) { ov[e] = (bf16)((!FOLD && p.accumulate) ? (float)cp[e] + v[e] : v[e]); cp[e] = ov[e]; }
+                }
+            }
+            if (p.out_stat) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float x = (float)ov[e]; st1 += x; st2 += x * x; }      // (of the row AS STORED)
+            }
+            }
+            // row statistics for the LayerNorm that reads this result and is folded into ITS consumer: the GPR lanes that hold one row
+            // add up (every lane of the wave takes part, inactive ones with zeros), then one float atomic per row, statistic and column tile
+            if (p.out_stat) {
+                if constexpr (GPR == 8 || GPR == 16 || GPR == 32) {
+                    st1 = rowgroup_sum<GPR>(st1); st2 = rowgroup_sum<GPR>(st2);
+                    if (act && cg == 0) { atomicAdd(p.out_stat + 2 * (size_t)m, st1); atomicAdd(p.out_stat + 2 * (size_t)m + 1, st2); }      // (column group 0 is active whenever its row is)
+                } else if (act) {
+                    atomicAdd(p.out_stat + 2 * (size_t)m, st1); atomicAdd(p.out_stat + 2 * (size_t)m + 1, st2);
+                }
             }
         }
     }
 }
 
-template <typename C>
-int launch_nt2(const GemmArgs& a, hipStream_t s) {
+template <typename C, bool FOLD>
+int launch_nt2_(const GemmArgs& a, hipStream_t s) {
     static BltDevFlag attr_set;
-    auto kern = gemm_nt2_kernel<C>;
+    auto kern = gemm_nt2_kernel<C, FOLD>;
     if (!attr_set.get()) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
             blt_set_error("gemm_nt2: hipFuncSetAttribute(%d) failed", C::LDS);
@@ -339,6 +413,10 @@ int launch_nt2(const GemmArgs& a, hipStream_t s) {
     const long tiles = (long)cdiv(a.M, C::BM) * cdiv(a.N, C::BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(C::NT), C::LDS, s, a);
     return blt_check_launch("gemm_nt2");
+}
+template <typename C>
+int launch_nt2(const GemmArgs& a, hipStream_t s) {
+    return a.fold_s ? launch_nt2_<C, true>(a, s) : launch_nt2_<C, false>(a, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -635,8 +713,11 @@ int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn) {
 }
 
 bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a) {
+    // (the LayerNorm-fold / row-statistics forms exist only here: they take this kernel at any row count)
+    const bool fold_ok = !a.fold_s || (a.fold_c && a.fold_stat && a.fold_n > 0.f && !a.bias && a.alpha == 1.f && !a.R && !a.maskY && !a.C2 && !a.rowtab &&
+                                       !a.accumulate);
     return dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv && !a.out_f32 && a.split_k == 0 && !a.stat_sum && !a.ln_out && !a.lnA_out &&
-           !a.a_rowsum && a.lda % 8 == 0 && a.ldb % 8 == 0 && a.M >= 256;
+           !a.a_rowsum && a.lda % 8 == 0 && a.ldb % 8 == 0 && fold_ok && (a.M >= 256 || a.fold_s || a.out_stat);
 }
 
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm, int force_bn) {

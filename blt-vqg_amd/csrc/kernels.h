@@ -78,6 +78,19 @@ struct GemmArgs {
     float* ln_rstd = nullptr;
     float ln_eps = 1e-5f;
     int nt2_bm = 0, nt2_bn = 0;      // force a tile shape of the planned-tile kernel (bltvqg_gemm_ex)
+    // ---- LayerNorm folded into the Linear that consumes it (gemm2.hip, bf16): LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n with
+    // W' = W diag(gamma) (the bf16 operand B), s_n = sum_k W'[n,k], c_n = sum_k beta[k] W[n,k] + b_n.  A holds the RAW rows x; their
+    // {sum, sum of squares} come from fold_stat, left there by the launch that produced x (out_stat of a GEMM, rows_add's statistics
+    // form).  No bias / alpha (folded into fold_c), no residual / mask / second output / row table / accumulate with it.
+    const float* fold_s = nullptr;      // [N]
+    const float* fold_c = nullptr;      // [N]
+    const float* fold_stat = nullptr;   // [M][2]
+    float* fold_mean = nullptr;         // [M], written by the first column tile (the LayerNorm's backward reads them); may be null
+    float* fold_rstd = nullptr;
+    float fold_eps = 1e-5f;
+    float fold_n = 0.f;                 // features per row the statistics cover (the LayerNorm's width)
+    // out_stat[m][0..1] += {sum, sum of squares} of result row m AS STORED (bf16-rounded), float atomics: zero it before the launch
+    float* out_stat = nullptr;
 };
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
@@ -128,7 +141,7 @@ int blt_conv_stem_direct(const void* x_padded, const void* w, void* y, int N, in
 // carry gamma = beta = 0, do not count in mean / variance and get a zero gradient (the reference's default widths: 4 heads of 75 stored
 // as 4 x 80, models.IQ pads them)
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                      long rows, int cols, float eps, hipStream_t s, int pad_period = 0, int pad_valid = 0);
+                      long rows, int cols, float eps, hipStream_t s, int pad_period = 0, int pad_valid = 0, long ld = 0);
 // dx = LNbwd(dy) (+ dres if non-null); dgamma/dbeta are ACCUMULATED (+=) with float atomics
 // optional second output out2 = (maskY != 0) ? dx * mask_scale : 0 (the ReLU/dropout backward that consumes dx, fused)
 // partials (optional, blt_layernorm_bwd_grid(rows, cols) * 2 * cols floats): the workgroups' dgamma / dbeta sums are stored there
@@ -136,7 +149,8 @@ int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
                       const void* maskY = nullptr, float mask_scale = 1.f, void* out2 = nullptr, float* partials = nullptr, int pad_period = 0,
-                      int pad_valid = 0);
+                      int pad_valid = 0, long ld = 0,      // ld: row stride (elements) of every row-indexed tensor, 0 = cols
+                      const float* beta = nullptr, void* xn_out = nullptr);      // xn_out: also store the LayerNorm's forward output (needs beta)
 int blt_layernorm_bwd_grid(long rows, int cols);
 #define BLT_LN_RED_MAX 24
 struct LnRed { const float* part; float* dgamma; float* dbeta; int nblocks; int cols; };
@@ -211,6 +225,15 @@ int blt_prep_tokens(const long long* ctx, const long long* post, const long long
 // y[b*ystride + j] (+)= a[b*astride + j] (+ c[b*cstride + j]) for j < n  (row-0 injections and their gradients)
 int blt_rows_add(int dtype, void* y, long ystride, const void* a, long astride, const void* c, long cstride, int B, int n,
                  int accumulate, hipStream_t s);
+// same, one wave per row, and stat[b * stat_stride + 0..1] = {sum, sum of squares} of result row b as stored (GemmArgs::fold_stat)
+int blt_rows_add_stat(int dtype, void* y, long ystride, const void* a, long astride, const void* c, long cstride, int B, int n, int accumulate,
+                      float* stat, long stat_stride, hipStream_t s);
+// LayerNorm folded into its consumer Linear: W' = bf16(W diag(gamma)) at the weight's offset in wfold_bf16, fold_s / fold_c rows at
+// the entry's srow (misc.hip::FoldEnt table on the device, `row0` = prefix sum of rows)
+struct BltFoldEnt { long w_off, g_off, b_off, bias_off; int rows, K, srow, row0; };
+int blt_ln_fold_prepare(const float* train, void* wfold_bf16, float* fold_s, float* fold_c, const void* table_dev, int nent, int total_rows, hipStream_t s);
+int blt_ln_fold_prepare_one(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* fold_s, float* fold_c, int N,
+                            int K, hipStream_t s);
 // y = dy * (ymask != 0) * scale
 // d_feats += dx0 + g_zc; d_zproj = dx0 + g_rin + g_zc (if non-null); d_enc[:,0] += g_rin   (misc.hip: the row-0 injections' backward)
 int blt_row0_sums(int dtype, const void* dx0, long sdx, const void* g_rin, const void* g_zc, void* d_feats, void* d_zproj, void* d_enc, long senc,

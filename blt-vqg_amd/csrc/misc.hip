@@ -793,6 +793,83 @@ __global__ void dropout_mask_kernel(uint64_t seed, uint32_t stream_id, long rows
     }
 }
 
+
+// rows_add with the row statistics of the RESULT (one wave per row): stat[b * stat_stride + 0..1] = {sum, sum of squares} of row b as
+// stored — the row-0 injections change rows whose LayerNorm is folded into the Linear that consumes it (GemmArgs::fold_stat), so the
+// sums the embedding GEMM left for those rows are replaced here
+template <typename T>
+__global__ __launch_bounds__(256) void rows_add_stat_kernel(T* __restrict__ y, long ys, const T* __restrict__ a, long as, const T* __restrict__ c, long cs,
+                                                            int B, int n, int accumulate, float* __restrict__ stat, long stat_stride) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = lane; j < n; j += 64) {
+        float v = to_f32(a[(long)b * as + j]);
+        if (c != nullptr) v += to_f32(c[(long)b * cs + j]);
+        if (accumulate) v += to_f32(y[(long)b * ys + j]);
+        const T o = from_f32<T>(v);
+        y[(long)b * ys + j] = o;
+        const float x = to_f32(o);
+        s1 += x; s2 += x * x;
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2);
+    if (lane == 0) { stat[(long)b * stat_stride] = s1; stat[(long)b * stat_stride + 1] = s2; }
+}
+
+// LayerNorm folded into its consumer Linear (gemm2.hip, GemmArgs::fold_*): per output row n of the weight W [rows, K] (fp32 master)
+//   W'[n, k] = bf16(W[n, k] * gamma[k])        the GEMM's B operand
+//   s[n]     = sum_k float(W'[n, k])           (of the ROUNDED operand: what the MFMA multiplies the mean with)
+//   c[n]     = sum_k beta[k] * W[n, k] + bias[n]
+// One wave per row, all entries of a table in one launch.
+struct FoldEnt { long w_off, g_off, b_off, bias_off; int rows, K, srow, row0; };
+__device__ __forceinline__ void fold_row(const float* __restrict__ w, const float* __restrict__ g, const float* __restrict__ bt, bf16* __restrict__ o,
+                                         int K, int lane, float& s_out, float& c_out) {
+    float s = 0.f, c = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        float wv[8], gv[8], bv[8], ov[8];
+        Vec8<float>::load(w + k, wv);
+        Vec8<float>::load(g + k, gv);
+        Vec8<float>::load(bt + k, bv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bf16 q = (bf16)(wv[i] * gv[i]);
+            ov[i] = (float)q;
+            s += ov[i];
+            c += bv[i] * wv[i];
+        }
+        Vec8<bf16>::store(o + k, ov);
+    }
+    s_out = wave_sum(s); c_out = wave_sum(c);
+}
+__global__ __launch_bounds__(256) void ln_fold_prepare_kernel(const float* __restrict__ train, bf16* __restrict__ wfold, float* __restrict__ fs,
+                                                              float* __restrict__ fc, const FoldEnt* __restrict__ tab, int nent, int total_rows) {
+    const int lane = threadIdx.x & 63;
+    const int R = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (R >= total_rows) return;
+    int e = 0;
+    while (e + 1 < nent && tab[e + 1].row0 <= R) ++e;
+    const FoldEnt t = tab[e];
+    const int r = R - t.row0;
+    float s, c;
+    fold_row(train + t.w_off + (long)r * t.K, train + t.g_off, train + t.b_off, wfold + t.w_off + (long)r * t.K, t.K, lane, s, c);
+    if (lane == 0) {
+        fs[t.srow + r] = s;
+        fc[t.srow + r] = c + (t.bias_off >= 0 ? train[t.bias_off + r] : 0.f);
+    }
+}
+// one weight, explicit pointers (the C-ABI operator bltvqg_ln_fold_prepare)
+__global__ __launch_bounds__(256) void ln_fold_prepare_one_kernel(const float* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  const float* __restrict__ bias, bf16* __restrict__ Wf, float* __restrict__ fs,
+                                                                  float* __restrict__ fc, int N, int K) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= N) return;
+    float s, c;
+    fold_row(W + (long)r * K, gamma, beta, Wf + (long)r * K, K, lane, s, c);
+    if (lane == 0) { fs[r] = s; fc[r] = c + (bias ? bias[r] : 0.f); }
+}
+
 }  // namespace
 
 #define T_SWITCH(dtype, NAME, GRID, BLOCK, LDS, STREAM, ...)                                        \
@@ -835,6 +912,30 @@ int blt_rows_add(int dtype, void* y, long ys, const void* a, long as, const void
     if (dtype == BLT_F32) hipLaunchKernelGGL(rows_add_kernel<float>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (float*)y, ys, (const float*)a, as, (const float*)c, cs, B, n, accumulate);
     else hipLaunchKernelGGL(rows_add_kernel<bf16>, dim3(ew_grid((long)B * n)), dim3(256), 0, s, (bf16*)y, ys, (const bf16*)a, as, (const bf16*)c, cs, B, n, accumulate);
     return blt_check_launch("rows_add");
+}
+
+int blt_rows_add_stat(int dtype, void* y, long ys, const void* a, long as, const void* c, long cs, int B, int n, int accumulate, float* stat,
+                      long stat_stride, hipStream_t s) {
+    CHECK_DTYPE(dtype, "rows_add_stat");
+    BLT_REQUIRE(y && a && stat && B > 0 && n > 0 && stat_stride >= 2, "rows_add_stat: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(rows_add_stat_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, s, (float*)y, ys, (const float*)a, as, (const float*)c, cs, B, n, accumulate, stat, stat_stride);
+    else hipLaunchKernelGGL(rows_add_stat_kernel<bf16>, dim3(cdiv(B, 4)), dim3(256), 0, s, (bf16*)y, ys, (const bf16*)a, as, (const bf16*)c, cs, B, n, accumulate, stat, stat_stride);
+    return blt_check_launch("rows_add_stat");
+}
+
+int blt_ln_fold_prepare(const float* train, void* wfold_bf16, float* fold_s, float* fold_c, const void* table_dev, int nent, int total_rows, hipStream_t s) {
+    BLT_REQUIRE(train && wfold_bf16 && fold_s && fold_c && table_dev && nent > 0 && total_rows > 0, "ln_fold_prepare: bad args");
+    hipLaunchKernelGGL(ln_fold_prepare_kernel, dim3(cdiv(total_rows, 4)), dim3(256), 0, s, train, (bf16*)wfold_bf16, fold_s, fold_c, (const FoldEnt*)table_dev, nent, total_rows);
+    return blt_check_launch("ln_fold_prepare");
+}
+
+int blt_ln_fold_prepare_one(const float* W, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* fold_s, float* fold_c, int N,
+                            int K, hipStream_t s) {
+    BLT_REQUIRE(W && gamma && beta && Wf_bf16 && fold_s && fold_c && N > 0 && K > 0 && K % 8 == 0, "ln_fold_prepare: bad args (K %% 8 == 0)");
+    BLT_REQUIRE(((uintptr_t)W % 16) == 0 && ((uintptr_t)gamma % 16) == 0 && ((uintptr_t)beta % 16) == 0 && ((uintptr_t)Wf_bf16 % 16) == 0,
+                "ln_fold_prepare: operands must be 16-byte aligned");
+    hipLaunchKernelGGL(ln_fold_prepare_one_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, W, gamma, beta, bias, (bf16*)Wf_bf16, fold_s, fold_c, N, K);
+    return blt_check_launch("ln_fold_prepare");
 }
 
 int blt_row0_sums(int dtype, const void* dx0, long sdx, const void* g_rin, const void* g_zc, void* d_feats, void* d_zproj, void* d_enc, long senc,

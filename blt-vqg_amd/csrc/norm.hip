@@ -14,7 +14,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, T* __restrict__ y,
                                                            float* __restrict__ mean, float* __restrict__ rstd, long rows,
-                                                           int cols, float eps, int pad_period, int pad_valid) {
+                                                           int cols, float eps, int pad_period, int pad_valid, long ld) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     for (int j = 0; j < LN_MAX_CHUNKS; ++j) {
         const int c = lane + 64 * j;
         if (c < nch) {
-            Vec8<T>::load(x + row * cols + c * 8, v[j]);
+            Vec8<T>::load(x + row * ld + c * 8, v[j]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += v[j][e];
         }
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
             Vec8<float>::load(beta + c * 8, b);
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (v[j][e] - mu) * rs * g[e] + b[e];
-            Vec8<T>::store(y + row * cols + c * 8, o);
+            Vec8<T>::store(y + row * ld + c * 8, o);
         }
     }
 }
@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                            T* dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, long rows, int cols,
                                                            const T* __restrict__ maskY, float mask_scale, T* __restrict__ out2,
-                                                           float* __restrict__ partials, int pad_period, int pad_valid) {
+                                                           float* __restrict__ partials, int pad_period, int pad_valid, long ld,
+                                                           const float* __restrict__ beta, T* __restrict__ xn_out) {
     const int lane = threadIdx.x & 63;
     const int nch = cols >> 3;
     const int lpr = (nch <= 32) ? 32 : 64, rpw = 64 / lpr;
@@ -118,9 +119,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             for (int j = 0; j < NCH; ++j) {
                 const int c = l + lpr * j;
                 if (rok && c < nch) {
-                    Vec8<T>::load(dy + row * cols + c * 8, d[r][j]);
-                    Vec8<T>::load(x + row * cols + c * 8, xh[r][j]);
-                    if (dres != nullptr) Vec8<T>::load(dres + row * cols + c * 8, rr[r][j]);
+                    Vec8<T>::load(dy + row * ld + c * 8, d[r][j]);
+                    Vec8<T>::load(x + row * ld + c * 8, xh[r][j]);
+                    if (dres != nullptr) Vec8<T>::load(dres + row * ld + c * 8, rr[r][j]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { d[r][j][e] = 0.f; xh[r][j][e] = 0.f; }
@@ -158,15 +159,25 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] += rr[r][j][e];
                         }
-                        Vec8<T>::store(dx + row * cols + c * 8, o);
+                        Vec8<T>::store(dx + row * ld + c * 8, o);
+                        if (xn_out != nullptr) {
+                            // the LayerNorm's OUTPUT, as its forward launch would have stored it ((x - mean) * rstd * gamma + beta, rounded to
+                            // T): with the LayerNorm folded into the Linear that consumes it nothing wrote it in forward, and the weight
+                            // gradient of that Linear (deferred, behind this launch) reads it
+                            float bt[8], xo[8];
+                            Vec8<float>::load(beta + c * 8, bt);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) xo[e] = xh[r][j][e] * g[j][e] + bt[e];
+                            Vec8<T>::store(xn_out + row * ld + c * 8, xo);
+                        }
                         if (out2 != nullptr) {
                             // the consumer of dx is a ReLU + dropout backward (the FFN output of the next layer down): emit its masked,
                             // rescaled gradient here instead of in a launch of its own
                             float mk[8];
-                            Vec8<T>::load(maskY + row * cols + c * 8, mk);
+                            Vec8<T>::load(maskY + row * ld + c * 8, mk);
 #pragma unroll
                             for (int e = 0; e < 8; ++e) o[e] = (mk[e] != 0.f) ? o[e] * mask_scale : 0.f;
-                            Vec8<T>::store(out2 + row * cols + c * 8, o);
+                            Vec8<T>::store(out2 + row * ld + c * 8, o);
                         }
                     }
                 }
@@ -544,7 +555,9 @@ inline int ew_grid(long n) {
     } while (0)
 
 int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
-                      long rows, int cols, float eps, hipStream_t s, int pad_period, int pad_valid) {
+                      long rows, int cols, float eps, hipStream_t s, int pad_period, int pad_valid, long ld) {
+    if (ld == 0) ld = cols;
+    BLT_REQUIRE(ld >= cols && ld % 8 == 0, "layernorm_fwd: row stride %ld must be a multiple of 8 and >= cols", ld);
     BLT_REQUIRE((pad_period == 0 && pad_valid == 0) || (pad_period > 0 && pad_valid > 0 && pad_valid <= pad_period && cols % pad_period == 0),
                 "layernorm_fwd: bad pad pattern %d / %d for %d columns", pad_valid, pad_period, cols);
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "layernorm_fwd: bad dtype");
@@ -552,8 +565,8 @@ int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
     BLT_REQUIRE(x && gamma && beta && y && mean && rstd, "layernorm_fwd: null pointer");
     const int grid = cdiv(rows, 4);
     DISPATCH_T(dtype,
-               hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps, pad_period, pad_valid),
-               hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, pad_period, pad_valid));
+               hipLaunchKernelGGL(layernorm_fwd_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, gamma, beta, (float*)y, mean, rstd, rows, cols, eps, pad_period, pad_valid, ld),
+               hipLaunchKernelGGL(layernorm_fwd_kernel<bf16>, dim3(grid), dim3(256), 0, s, (const bf16*)x, gamma, beta, (bf16*)y, mean, rstd, rows, cols, eps, pad_period, pad_valid, ld));
     return blt_check_launch("layernorm_fwd");
 }
 
@@ -597,7 +610,11 @@ int blt_ln_param_reduce(const LnRedArgs& a, hipStream_t s) {
 
 int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gamma, const float* mean, const float* rstd,
                       const void* dres, void* dx, float* dgamma, float* dbeta, long rows, int cols, hipStream_t s,
-                      const void* maskY, float mask_scale, void* out2, float* partials, int pad_period, int pad_valid) {
+                      const void* maskY, float mask_scale, void* out2, float* partials, int pad_period, int pad_valid, long ld,
+                      const float* beta, void* xn_out) {
+    if (ld == 0) ld = cols;
+    BLT_REQUIRE(xn_out == nullptr || beta != nullptr, "layernorm_bwd: xn_out needs beta");
+    BLT_REQUIRE(ld >= cols && ld % 8 == 0, "layernorm_bwd: row stride %ld must be a multiple of 8 and >= cols", ld);
     BLT_REQUIRE((maskY == nullptr) == (out2 == nullptr), "layernorm_bwd: maskY and out2 go together");
     BLT_REQUIRE((pad_period == 0 && pad_valid == 0) || (pad_period > 0 && pad_valid > 0 && pad_valid <= pad_period && cols % pad_period == 0),
                 "layernorm_bwd: bad pad pattern %d / %d for %d columns", pad_valid, pad_period, cols);
@@ -608,7 +625,7 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     if (grid < 1) grid = 1;
 #define LN_BWD_LAUNCH(T_, NCH_, R_)                                                                                                         \
     hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NCH_, R_>), dim3(grid), dim3(256), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, \
-                       (const T_*)dres, (T_*)dx, dgamma, dbeta, rows, cols, (const T_*)maskY, mask_scale, (T_*)out2, partials, pad_period, pad_valid)
+                       (const T_*)dres, (T_*)dx, dgamma, dbeta, rows, cols, (const T_*)maskY, mask_scale, (T_*)out2, partials, pad_period, pad_valid, ld, beta, (T_*)xn_out)
 #define LN_BWD_BY_COLS(T_)                                                                                                                 \
     do {                                                                                                                                    \
         if (cols <= 512) LN_BWD_LAUNCH(T_, 1, 4);                                                                                           \

@@ -38,7 +38,7 @@ int bltvqg_version(void);
 const char* bltvqg_last_error_string(void);
 /* tuning switches for A/B benchmarks: key 0 = disable the LDS-DMA GEMM ring (value 1), key 1 = force a GEMM tile (64/128/12864) */
 void bltvqg_debug_set(int key, int value);
-int bltvqg_debug_get(int key);      /* keys 0..23; bench.py echoes every non-zero key in its JSON line */
+int bltvqg_debug_get(int key);      /* keys 0..31; bench.py echoes every non-zero key in its JSON line */
 /* 1 only in the ablation build (make -C blt-vqg_amd/csrc ablate -> libbltvqg_hip_ablate.so, -DBLT_ABLATE): there debug keys 14 (skip the
  * grouped weight-gradient launches) and 15 (skip the conv stack) exist as TIMING ablations with wrong results.  The shipped library has
  * no switch that skips work. */
@@ -63,6 +63,24 @@ int bltvqg_gemm(int dtype, const void* A, int lda, int transA, const void* B, in
 int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, const float* rowtab,
                    const int32_t* rowidx, int ldt, int relu, float drop_p, uint64_t seed, uint32_t stream_id, const void* maskY, int ldm, float mask_scale,
                    void* C2, int ldc2, const void* R, int ldr, int accumulate, int tile_m, int tile_n, void* stream);
+/* ---- LayerNorm folded into the Linear that consumes it (round 4).  Every pre-LayerNorm inside the reference's Encoder / Decoder layers
+ * feeds exactly one Linear (transformer_layers.py:260-262 -> q|k|v, :271-273 -> FFN layer 0, :326-328, :340-342 -> cross-attention query,
+ * :356-358 -> FFN layer 0), so  LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n  with W' = W diag(gamma), s_n = sum_k W'[n,k],
+ * c_n = sum_k beta[k] W[n,k] + b_n: the normalisation moves into the GEMM epilogue, the row sums come from the epilogue of the GEMM that
+ * PRODUCED x, and the layernorm launch between the two disappears.
+ * bltvqg_gemm_rowstat: bltvqg_gemm_ex's Linear (bias, relu, dropout, second output C2, residual R) that also ADDS the {sum, sum of squares}
+ *   of every result row AS STORED (bf16-rounded) to out_stat[m][0..1] (float atomics: zero out_stat before the launch).
+ * bltvqg_ln_fold_prepare: W'[N,K] (bf16), s[N] (of the ROUNDED W'), c[N] (fp32 W; bias may be NULL) from the fp32 parameters.
+ * bltvqg_linear_ln_folded: Y = [dropout][relu](rstd_m (X Wf^T - mean_m s_n) + c_n) with mean_m / rstd_m from row_stat[m] = {sum, sum of
+ *   squares} of row m of X over its K features (biased variance, eps inside the square root, as nn.LayerNorm); mean / rstd (both or
+ *   neither) receive the statistics (the LayerNorm's backward reads them). */
+int bltvqg_gemm_rowstat(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu, float drop_p,
+                        uint64_t seed, uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, float* out_stat, int tile_m, int tile_n, void* stream);
+int bltvqg_ln_fold_prepare(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* fold_s,
+                           float* fold_c, void* stream);
+int bltvqg_linear_ln_folded(const void* X, int ldx, const void* Wf, int ldw, void* Y, int ldy, int M, int N, int K, const float* fold_s, const float* fold_c,
+                            const float* row_stat, float* mean, float* rstd, float eps, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
+                            int tile_m, int tile_n, void* stream);
 /* Weight gradients of n Linear layers in ONE launch (bf16 operands, fp32 results): dW_i[N_i, K_i] = dY_i[rows_i, N_i]^T X_i[rows_i, K_i]
  * and dbias_i[N_i] = column sums of dY_i (dbias_i may be NULL).  Results are STORED unless the launch is short of tiles and slices
  * the contraction (then they are atomically added: dW / dbias must be zero on entry, as the engine's gradient buffer is).  The

@@ -43,9 +43,10 @@ SIGNATURES = {
     "bltvqg_build_has_ablations": (I, []),
     "bltvqg_gemm": (I, [I, P, I, I, P, I, I, P, I, I, I, I, P, I, F, U64, U32, P, I, F, P, I, I, I, I, I, P]),
     "bltvqg_gemm_ex": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, F, U64, U32, P, I, F, P, I, P, I, I, I, I, P]),
-    "bltvqg_gemm_rowstat": (I, [P, I, P, I, P, I, I, I, I, P, I, F, U64, U32, P, I, P, I, P, I, I, P]),
+    "bltvqg_gemm_rowstat": (I, [P, I, P, I, P, I, I, I, I, P, I, F, U64, U32, P, I, P, I, P, I, I, I, P]),
+    "bltvqg_gemm_rowstat_parts": (I, [I, I, I, I]),
     "bltvqg_ln_fold_prepare": (I, [P, I, I, P, P, P, P, P, P, P]),
-    "bltvqg_linear_ln_folded": (I, [P, I, P, I, P, I, I, I, I, P, P, P, P, P, F, I, F, U64, U32, I, I, P]),
+    "bltvqg_linear_ln_folded": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, P, P, F, I, F, U64, U32, I, I, P]),
     "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
     "bltvqg_gemm_repeat": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P]),
     "bltvqg_gemm_rotate": (I, [I, P, I, I, L, P, I, I, L, P, I, I, L, I, I, I, I, I, P]),
@@ -108,6 +109,8 @@ SIGNATURES = {
     "bltvqg_engine_set_cu_masks": (I, [P, P, P, P, I, I]),
     "bltvqg_engine_chain_stream": (I, [P, ctypes.POINTER(ctypes.c_void_p)]),
     "bltvqg_engine_conv_stream": (I, [P, ctypes.POINTER(ctypes.c_void_p)]),
+    "bltvqg_engine_conv_stream_wait": (I, [P, P]),
+    "bltvqg_engine_side_stream": (I, [P, I, ctypes.POINTER(ctypes.c_void_p)]),
     "bltvqg_engine_adopt_conv_stream": (I, [P, P]),
     "bltvqg_engine_create": (P, [ctypes.POINTER(Config)]),
     "bltvqg_engine_destroy": (None, [P]),
@@ -137,6 +140,7 @@ SIGNATURES = {
     "bltvqg_engine_profile_enable": (I, [P, I]),
     "bltvqg_engine_profile_read": (I, [P, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]),
     "bltvqg_engine_profile_read_class": (I, [P, I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)]),
+    "bltvqg_engine_profile_read_streams": (I, [P, I, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "bltvqg_engine_phase_stamps": (I, [P, ctypes.POINTER(ctypes.c_float)]),
     "bltvqg_engine_set_bucket_flush": (I, [P, I]),
     "bltvqg_engine_num_buckets": (I, [P]),

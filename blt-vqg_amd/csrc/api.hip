@@ -44,16 +44,24 @@ int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int 
 }
 
 int bltvqg_gemm_rowstat(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu, float drop_p,
-                        uint64_t seed, uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, float* out_stat, int tile_m, int tile_n, void* stream) {
-    BLT_REQUIRE(out_stat != nullptr, "gemm_rowstat: out_stat is null");
+                        uint64_t seed, uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, float* out_stat, int stat_slots, int tile_m, int tile_n,
+                        void* stream) {
+    BLT_REQUIRE(out_stat != nullptr && stat_slots >= 1, "gemm_rowstat: out_stat is null / stat_slots < 1");
     GemmArgs g;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.bias = bias; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id; g.C2 = C2; g.ldc2 = ldc2; g.R = R; g.ldr = ldr;
-    g.out_stat = out_stat;
+    g.out_stat = out_stat; g.stat_slots = stat_slots;
     BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g), "gemm_rowstat: operands do not fit the planned-tile kernel (bf16 NT, lda/ldb %% 8 == 0)");
     BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "gemm_rowstat: tile_m / tile_n must both be 0 or both be a compiled tile shape");
     g.nt2_bm = tile_m; g.nt2_bn = tile_n;
     return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
+}
+
+int bltvqg_gemm_rowstat_parts(int M, int N, int K, int tile_n) {
+    if (tile_n > 0) return cdiv(N, tile_n);
+    int bm = 0, bn = 0;
+    blt_gemm_nt2_tile(M, N, K, &bm, &bn, true);
+    return bn > 0 ? cdiv(N, bn) : 0;
 }
 
 int bltvqg_ln_fold_prepare(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* fold_s,
@@ -62,13 +70,15 @@ int bltvqg_ln_fold_prepare(const float* W, int N, int K, const float* gamma, con
 }
 
 int bltvqg_linear_ln_folded(const void* X, int ldx, const void* Wf, int ldw, void* Y, int ldy, int M, int N, int K, const float* fold_s, const float* fold_c,
-                            const float* row_stat, float* mean, float* rstd, float eps, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
-                            int tile_m, int tile_n, void* stream) {
+                            const float* row_stat, int stat_slots, int stat_parts, float* mean, float* rstd, float eps, int relu, float drop_p, uint64_t seed,
+                            uint32_t stream_id, int tile_m, int tile_n, void* stream) {
     BLT_REQUIRE(X && Wf && Y && fold_s && fold_c && row_stat && M > 0 && N > 0 && K > 0, "linear_ln_folded: null pointer / bad shape");
+    BLT_REQUIRE(stat_parts >= 1 && stat_parts <= stat_slots, "linear_ln_folded: stat_parts must be in [1, stat_slots]");
     BLT_REQUIRE((mean == nullptr) == (rstd == nullptr), "linear_ln_folded: mean and rstd go together");
     GemmArgs g;
     g.A = X; g.lda = ldx; g.B = Wf; g.ldb = ldw; g.C = Y; g.ldc = ldy; g.M = M; g.N = N; g.K = K;
     g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id;
+    g.stat_slots = stat_slots; g.fold_np = stat_parts;
     g.fold_s = fold_s; g.fold_c = fold_c; g.fold_stat = row_stat; g.fold_mean = mean; g.fold_rstd = rstd; g.fold_eps = eps; g.fold_n = (float)K;
     BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g), "linear_ln_folded: operands do not fit the planned-tile kernel (bf16 NT, ldx/ldw %% 8 == 0)");
     BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "linear_ln_folded: tile_m / tile_n must both be 0 or both be a compiled tile shape");

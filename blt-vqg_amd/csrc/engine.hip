@@ -63,6 +63,7 @@ struct Stack {
     const int* key_ids = nullptr;
     void* x_in = nullptr;
     float* stat_in = nullptr;   // row statistics of x_in (the embedding GEMM's epilogue; rows_add_stat for the decoder's row 0)
+    int stat_in_parts = 1;      // ... in that many partial-sum slots per row (the column tiles of the GEMM that wrote them)
     std::vector<Layer> layers;
     void* out = nullptr;
     float *mF = nullptr, *rF = nullptr;
@@ -257,6 +258,14 @@ struct bltvqg_engine {
     int fold_rows_total = 0;
     float *stat_pool = nullptr, *stat_emb = nullptr;
     size_t stat_pool_floats = 0;
+    // statistics slots per row: one per column tile of the producing GEMM (plain stores; the consumer adds them in slot order)
+    int stat_slots = 8;
+    // how many column tiles the planned-tile kernel cuts an [M, H] result into when it also writes row statistics
+    int stat_parts(int M, int K) const {
+        int bm = 0, bn = 0;
+        blt_gemm_nt2_tile(M, H, K, &bm, &bn, true);
+        return bn > 0 ? (H + bn - 1) / bn : 1;
+    }
     bool fold_on() const { return fold_ok && blt_debug_get(25) != 1; }
     void add_fold(int which, const std::string& wname, int rows, const std::string& ln, const char* bias) {
         const PInfo& w = tpi(wname);
@@ -270,6 +279,7 @@ struct bltvqg_engine {
     }
     void build_fold() {
         fold_ok = dt == BLT_BF16 && ln_pp == 0 && H % 8 == 0;
+        stat_slots = (H + 63) / 64;      // the narrowest compiled tile has 64 columns
         if (!fold_ok) return;
         const Stack* sts[3] = {&enc, &renc, &dec};
         for (const Stack* st : sts)
@@ -292,19 +302,16 @@ struct bltvqg_engine {
         return BLT_OK;
     }
     // the folded form of Y = LN(x) W^T (+ b): A = the raw rows, B = W', statistics in / mean, rstd out
-    void set_fold(GemmArgs& g, const void* x, int ldx, const std::string& wname, const float* stat, float* m, float* r) {
+    void set_fold(GemmArgs& g, const void* x, int ldx, const std::string& wname, const float* stat, int parts, float* m, float* r) {
         const PInfo& p = tpi(wname);
         g.A = x; g.lda = ldx;
         g.B = (const char*)wshadowF + p.off * 2; g.ldb = p.dims[1];
         g.bias = nullptr;
         const int sr = fold_srow.at(wname);
+        g.stat_slots = stat_slots; g.fold_np = parts;
         g.fold_s = fold_s + sr; g.fold_c = fold_c + sr; g.fold_stat = stat; g.fold_mean = m; g.fold_rstd = r; g.fold_eps = 1e-5f; g.fold_n = (float)H;
     }
-    int zero_stats(hipStream_t s) {
-        if (!fold_on() || !stat_pool) return BLT_OK;
-        if (hipMemsetAsync(stat_pool, 0, stat_pool_floats * sizeof(float), s) != hipSuccess) { blt_set_error("engine: statistics memset failed"); return BLT_ERR_HIP; }
-        return BLT_OK;
-    }
+    void set_stat(GemmArgs& g, float* stat) { g.out_stat = stat; g.stat_slots = stat_slots; }
     bool use_streams = true;
     int causal_mode = 1;       // 1 = training mask (pad OR future -> -1e18), 2 = prefix decoding (future keys excluded)
     bool bn_train = true;      // false: BatchNorm layers use their running statistics (module.eval(), greedy decoding)
@@ -326,7 +333,9 @@ struct bltvqg_engine {
         stamp_used[i] = true;
     }
     int prof_mask = 0;
-    struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; int w = 1; double flops = 0.0; };
+    struct ProfRec { hipEvent_t a = nullptr, b = nullptr; int cls = 0; int w = 1; double flops = 0.0; int sidx = 0; };
+    // which of the step's streams a bracket sits on: 0 = the caller's, 1 / 2 = the engine's side streams, 3 = the conv look-ahead stream, 4 = other
+    int stream_index(hipStream_t s) const { return s == side[0] ? 1 : s == side[1] ? 2 : (cnn_stream && s == cnn_stream) ? 3 : (s == opt_stream ? 2 : 0); }
     // class-1 launches that go through gemm() are bracketed every prof_stride-th time and counted prof_stride times (an event pair is a
     // ~5 us bubble on its stream: 210 pairs would stretch the one profiled step of bench.py by ~2.5 ms); grouped weight-gradient launches
     // (4 per step, 15 % of the family's flops each) and convolutions are always bracketed
@@ -342,6 +351,7 @@ struct bltvqg_engine {
         }
         prof[prof_n].cls = cls;
         prof[prof_n].w = 1;
+        prof[prof_n].sidx = stream_index(s);
         (void)hipEventRecord(prof[prof_n].a, s);
         return (int)prof_n++;
     }
@@ -659,19 +669,20 @@ struct bltvqg_engine {
         };
         lay_stack(enc); lay_stack(renc); lay_stack(dec);
         if (fold_ok) {      // one contiguous pool: a single memset per forward
-            int64_t n = 2 * (int64_t)Mtot;
-            for (Stack* st : {&enc, &renc, &dec}) n += (int64_t)L * (st->dec ? 3 : 2) * 2 * st->M;
+            const int64_t per_row = 2 * (int64_t)stat_slots;
+            int64_t n = per_row * Mtot;
+            for (Stack* st : {&enc, &renc, &dec}) n += (int64_t)L * (st->dec ? 3 : 2) * per_row * st->M;
             stat_pool_floats = (size_t)n;
             stat_pool = AF(n);
             float* q = stat_pool;
-            stat_emb = q; q += 2 * (int64_t)Mtot;
-            enc.stat_in = stat_emb; dec.stat_in = stat_emb + 2 * (int64_t)Ma; renc.stat_in = stat_emb + 2 * (int64_t)(Ma + Mt);
+            stat_emb = q; q += per_row * Mtot;
+            enc.stat_in = stat_emb; dec.stat_in = stat_emb + per_row * Ma; renc.stat_in = stat_emb + per_row * (Ma + Mt);
             for (Stack* st : {&enc, &renc, &dec})
                 for (int l = 0; l < L; ++l) {
                     Layer& y = st->layers[l];
-                    y.st1 = q; q += 2 * (int64_t)st->M;      // (layer 0 reads Stack::stat_in instead)
-                    y.st2 = q; q += 2 * (int64_t)st->M;
-                    if (st->dec) { y.st3 = q; q += 2 * (int64_t)st->M; }
+                    y.st1 = q; q += per_row * st->M;      // (layer 0 reads Stack::stat_in instead)
+                    y.st2 = q; q += per_row * st->M;
+                    if (st->dec) { y.st3 = q; q += per_row * st->M; }
                 }
         }
         mlvp_h1 = AT((int64_t)B * 2 * Z); mlvp_h2 = AT((int64_t)B * 2 * Z); mlvp = AT((int64_t)B * 2 * Z);
@@ -938,7 +949,7 @@ struct bltvqg_engine {
         RC(attn_fwd(q, ldq, k, v, ldkv, ctx, key_ids, Tq, Tk, causal, stream_id, s));
         GemmArgs g = lin(ctx, rw.ldH, wname, nullptr, out, rw.ldH, rw.M);
         g.R = resid; g.ldr = rw.ldH;
-        g.out_stat = out_stat;      // row sums of `out` for the LayerNorm that reads it (folded into ITS consumer)
+        if (out_stat) set_stat(g, out_stat);      // row sums of `out` for the LayerNorm that reads it (folded into ITS consumer)
         return gemm(dt, g, s);
     }
 
@@ -960,7 +971,7 @@ struct bltvqg_engine {
         GemmArgs g;
         if (fold_on()) {
             g = mk(nullptr, 0, 0, nullptr, 0, 0, y.h, rw.ldF, rw.M, F, H);
-            set_fold(g, xres, rw.ldH, fp_ + "layers.0.weight", stat, m, r);
+            set_fold(g, xres, rw.ldH, fp_ + "layers.0.weight", stat, stat_parts(rw.M, H), m, r);      // (xres = an attention output projection's result)
         } else {
             RC(ln_fwd(xres, ln, xn, m, r, rw, s));
             g = lin(xn, rw.ldH, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, rw.ldF, rw.M);
@@ -970,7 +981,7 @@ struct bltvqg_engine {
         g = lin(y.h, rw.ldF, fp_ + "layers.1.weight", (fp_ + "layers.1.bias").c_str(), y.x2, rw.ldH, rw.M);
         g.relu = 1; g.drop_p = c.relu_dropout; g.seed = seed; g.stream_id = sid(stack, l, 2);
         g.C2 = y.y2; g.ldc2 = rw.ldH; g.R = xres; g.ldr = rw.ldH;
-        g.out_stat = out_stat;
+        if (out_stat) set_stat(g, out_stat);
         return gemm(dt, g, s);
     }
 
@@ -1003,7 +1014,8 @@ struct bltvqg_engine {
             // fused QKV projection: query/key/value weights are adjacent in the flat buffer -> one [3H,H] operand
             if (fold) {
                 GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, y.qkv, 3 * H, M, 3 * H, H);
-                set_fold(g, x, H, a1 + "query_linear.weight", l == 0 ? st.stat_in : y.st1, y.m1, y.r1);
+                // (x = the embedding GEMM's rows, or the second FFN Linear's result of the layer below — never the row-0-only top layer's)
+                set_fold(g, x, H, a1 + "query_linear.weight", l == 0 ? st.stat_in : y.st1, l == 0 ? st.stat_in_parts : stat_parts(M, F), y.m1, y.r1);
                 RC(gemm(dt, g, s));
             } else {
                 RC(ln_fwd(x, ln1, y.xn1, y.m1, y.r1, all, s));
@@ -1019,7 +1031,7 @@ struct bltvqg_engine {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
                 if (fold) {
                     GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, y.q2, H, M, H, H);
-                    set_fold(g, y.x1, H, a2 + "query_linear.weight", y.st2, y.m2, y.r2);
+                    set_fold(g, y.x1, H, a2 + "query_linear.weight", y.st2, stat_parts(M, H), y.m2, y.r2);
                     RC(gemm(dt, g, s));
                 } else {
                     RC(ln_fwd(y.x1, ln2, y.xn2, y.m2, y.r2, rw, s));
@@ -1270,7 +1282,6 @@ struct bltvqg_engine {
         if (opt_is_pending() && !overlap_opt) { RC(sync_opt(s)); opt_mark_synced(); }
         // loss statistics [0..3]; [4] (gradient norm) belongs to the optimiser, which may still be reading it
         if (hipMemsetAsync(stats - 1, 0, 5 * sizeof(float), s) != hipSuccess) { blt_set_error("engine_forward: memset failed"); return BLT_ERR_HIP; }
-        RC(zero_stats(s));      // row statistics of the folded LayerNorms (every stream of this forward is forked from `s` behind this)
         if (overlap_opt) {
             // The frozen CNN does not depend on the update: it is enqueued first (unless it ran ahead: then the encoders' launches are),
             // everything else goes behind the optimiser — the token / encoder streams behind its FIRST stage only (embedding + encoder
@@ -1383,7 +1394,10 @@ struct bltvqg_engine {
             GemmArgs g = mk(emb_rows, Epad, 0, w, ldw, 0, X_all, H, Memb, H, E);
             g.bias = P("embedding.1.bias");
             g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
-            if (fold_on()) g.out_stat = stat_emb;      // the first LayerNorm of every stack is folded into its q|k|v projection
+            if (fold_on()) {      // the first LayerNorm of every stack is folded into its q|k|v projection
+                set_stat(g, stat_emb);
+                enc.stat_in_parts = renc.stat_in_parts = dec.stat_in_parts = stat_parts(Memb, E);
+            }
             RC(gemm(dt, g, se));
         }
         enc.x_in = X_all; enc.key_ids = ctx32;
@@ -1395,7 +1409,7 @@ struct bltvqg_engine {
     // target_embedding[:,0] += image_features (+ z) (decoder_transformer.py:31,34); with folded LayerNorms the row sums of those B rows
     // (left by the embedding GEMM) are replaced by those of the new rows
     int dec_row0_add(const void* z, hipStream_t s) {
-        if (fold_on()) return blt_rows_add_stat(dt, dec.x_in, (long)T * H, feats, H, z, H, B, H, 1, dec.stat_in, 2L * T, s);
+        if (fold_on()) return blt_rows_add_stat(dt, dec.x_in, (long)T * H, feats, H, z, H, B, H, 1, dec.stat_in, 2L * stat_slots * T, dec.stat_in_parts, s);
         return blt_rows_add(dt, dec.x_in, (long)T * H, feats, H, z, H, B, H, 1, s);
     }
 
@@ -1471,7 +1485,6 @@ struct bltvqg_engine {
     int decode_body(const float* images, const int64_t* ctx, const float* eps, int* tokens, int* top_idx, float* top_val, hipStream_t s) {
         if (dt == BLT_BF16) RC(blt_cast_rows(BLT_F32, train, (int)1, BLT_BF16, wshadow, 1, tsize, 1, s));
         RC(fold_prepare(3, s));
-        RC(zero_stats(s));
         if (wemb_pad) RC(blt_cast_rows(BLT_F32, P("embedding.1.weight"), E, dt, wemb_pad, ld_wemb, H, E, s));
         if (hipMemsetAsync(stats - 1, 0, sizeof(float), s) != hipSuccess) { blt_set_error("engine_decode_greedy: memset failed"); return BLT_ERR_HIP; }
         RC(blt_prep_decode((const long long*)ctx, B, Sa, T, ids_all, pos_all, ctx32, V, stats - 1, s));
@@ -1484,7 +1497,10 @@ struct bltvqg_engine {
             GemmArgs g = mk((char*)emb_rows + (size_t)row0 * Epad * es, Epad, 0, we, ldw, 0, (char*)X_all + (size_t)row0 * H * es, H, rows, H, E);
             g.bias = P("embedding.1.bias");
             g.rowtab = timing; g.rowidx = pos_all + row0; g.ldt = H;
-            if (fold_on()) g.out_stat = stat_emb + 2 * (size_t)row0;
+            if (fold_on()) {
+                set_stat(g, stat_emb + 2 * (size_t)stat_slots * row0);
+                (row0 == 0 ? enc : dec).stat_in_parts = stat_parts(rows, E);
+            }
             return gemm(dt, g, s);
         };
         RC(embed(0, Ma));
@@ -1501,7 +1517,6 @@ struct bltvqg_engine {
             RC(gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
         }
         for (int t = 0; t < T; ++t) {
-            RC(zero_stats(s));      // (every pass recomputes the decoder rows: their statistics start from zero again; the encoder's are dead by now)
             RC(embed(Ma, Mt));
             RC(dec_row0_add(phase2 ? zproj : nullptr, s));     // [:,0] += z + image_features
             RC(stack_fwd(dec, enc.out, ctx32, s));
@@ -2096,6 +2111,20 @@ int bltvqg_engine_conv_stream(bltvqg_engine* e, void** stream) {
     return BLT_OK;
 }
 
+int bltvqg_engine_side_stream(bltvqg_engine* e, int which, void** stream) {
+    BLT_REQUIRE(e && stream && (which == 0 || which == 1), "engine_side_stream: bad args");
+    BLT_REQUIRE(e->bound && e->side[which], "engine_side_stream: engine not bound");
+    *stream = (void*)e->side[which];
+    return BLT_OK;
+}
+
+int bltvqg_engine_conv_stream_wait(bltvqg_engine* e, void* stream) {
+    BLT_REQUIRE(e, "engine_conv_stream_wait: null engine");
+    if (!e->cnn_stream_used || !e->cnn_done[e->last_cnn_slot]) return BLT_OK;      // nothing ran ahead
+    if (hipStreamWaitEvent((hipStream_t)stream, e->cnn_done[e->last_cnn_slot], 0) != hipSuccess) { blt_set_error("engine_conv_stream_wait: wait failed"); return BLT_ERR_HIP; }
+    return BLT_OK;
+}
+
 int bltvqg_engine_image_input(bltvqg_engine* e, void** ptr, int* Hp, int* Wp, int* dtype) {
     BLT_REQUIRE(e && ptr && Hp && Wp && dtype, "engine_image_input: null argument");
     BLT_REQUIRE(e->bound && !e->regions, "engine_image_input: engine not bound / region mode has no image input");
@@ -2196,8 +2225,11 @@ int bltvqg_engine_profile_enable(bltvqg_engine* e, int mask) {
 }
 
 int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host) {
+    return bltvqg_engine_profile_read_streams(e, cls, total_ms_host, launches_host, flops_host, nullptr);
+}
+int bltvqg_engine_profile_read_streams(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host, double* per_stream_ms_host4) {
     BLT_REQUIRE(e && (cls == 0 || cls == 1) && total_ms_host && launches_host && flops_host, "engine_profile_read: bad args");
-    double total = 0.0, flops = 0.0;
+    double total = 0.0, flops = 0.0, by_stream[4] = {0.0, 0.0, 0.0, 0.0};
     int32_t n = 0;
     size_t keep = 0;
     for (size_t i = 0; i < e->prof_n; ++i) {
@@ -2207,7 +2239,9 @@ int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) { blt_set_error("engine_profile_read: elapsed failed"); return BLT_ERR_HIP; }
         total += (double)ms * r.w; flops += r.flops * r.w; n += r.w;
+        by_stream[r.sidx & 3] += (double)ms * r.w;
     }
+    if (per_stream_ms_host4) for (int k = 0; k < 4; ++k) per_stream_ms_host4[k] = by_stream[k];
     e->prof_n = keep;      // records of the other class stay queued (the swaps keep every event pair alive in the vector)
     *total_ms_host = total;
     *launches_host = n;

@@ -79,13 +79,17 @@ struct Nt2 {
     static constexpr int SLAB_ROWS = NWM * 16, CS = BN + 4, SLAB_BYTES = SLAB_ROWS * CS * 4;
     // a thread owns ONE group of 8 columns (tid % GPR; bias is loaded once) and every RPS-th slab row from tid / GPR on: IPP rows per pass
     static constexpr int GPR = BN / 8, RPS = NT / GPR, IPP = (SLAB_ROWS + RPS - 1) / RPS;
-    static constexpr int LDS = (RING + DUMP > 2 * SLAB_BYTES) ? RING + DUMP : 2 * SLAB_BYTES;
+    // (+ BM x {mean, rstd} behind the slabs: the folded-LayerNorm variant keeps its row statistics there during the epilogue)
+    static constexpr int ROWSTAT_OFF = 2 * SLAB_BYTES;
+    static constexpr int LDS = (RING + DUMP > ROWSTAT_OFF + BM * 8) ? RING + DUMP : ROWSTAT_OFF + BM * 8;
     static_assert(LDS <= NT2_LDS_CAP, "LDS budget");
 };
 
 // sum over the GPR (8, 16 or 32) consecutive lanes that hold one result row (all lanes of the wave take part)
 template <int GPR>
 __device__ __forceinline__ float rowgroup_sum(float v) {
+    static_assert(GPR >= 8, "column groups per row");
+    if (GPR != 8 && GPR != 16 && GPR != 32) return v;      // (BN = 192: 24 lanes per row; the planner never picks such a tile for a launch with out_stat)
     v += dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);                       // quad_perm [2,3,0,1]
     v += dpp_mov<0x141>(v);                      // row_half_mirror: the other quad of the 8
@@ -171,7 +175,7 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
     const bool fast = t_on && (nv == 8) && pre_ok && (p.ldc % 8 == 0) && (!p.C2 || p.ldc2 % 8 == 0) && (!p.rowtab || p.ldt % 4 == 0) &&
                       (!p.bias || (((uintptr_t)(p.bias + n)) & 15) == 0);
     float bias[8], fsn[FOLD ? 8 : 1];
-    float f_mu[FOLD ? TM : 1][FOLD ? IPP : 1], f_rs[FOLD ? TM : 1][FOLD ? IPP : 1];
+    float row_mu = 0.f, row_rs = 0.f;      // FOLD: thread t < BM owns the LayerNorm statistics of tile row t
 #pragma unroll
     for (int e = 0; e < 8; ++e) bias[e] = 0.f;
     {
@@ -194,23 +198,24 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
                 for (int e = 0; e < 8; ++e) if (e < nv) fsn[e] = p.fold_s[n + e];
             }
         }
-        // LayerNorm statistics of this thread's rows from the sums the producer of A left behind: mean = S1 / n, var = S2 / n - mean^2
-        // (fp32; biased, as nn.LayerNorm); the first column group of the first column tile also stores mean / rstd for the backward
+        // LayerNorm statistics of tile row `tid` (threads 0 .. BM-1) from the partial sums the producer of A left behind, added in slot
+        // order (reproducible): mean = S1 / n, var = S2 / n - mean^2 (fp32; biased, as nn.LayerNorm).  They go to LDS behind the K loop;
+        // the first column tile also stores them for the LayerNorm's backward.
+        if (tid < BM && m0 + tid < p.M) {
+            const int m = m0 + tid;
+            const float2* sp = reinterpret_cast<const float2*>(p.fold_stat) + (size_t)m * p.stat_slots;
+            float s1 = 0.f, s2 = 0.f;
+            for (int k0 = 0; k0 < p.fold_np; k0 += 8) {      // eight loads in flight, then added in slot order
+                float2 st[8];
 #pragma unroll
-        for (int pp = 0; pp < TM; ++pp)
+                for (int k = 0; k < 8; ++k) st[k] = (k0 + k < p.fold_np) ? sp[k0 + k] : make_float2(0.f, 0.f);
 #pragma unroll
-            for (int q = 0; q < IPP; ++q) {
-                const int sr = sr0 + q * RPS;
-                const int m = m0 + (sr >> 4) * C::WM + pp * 16 + (sr & 15);
-                float mu = 0.f, rs = 0.f;
-                if (sr < C::SLAB_ROWS && m < p.M) {
-                    const float2 st = *reinterpret_cast<const float2*>(p.fold_stat + 2 * (size_t)m);
-                    mu = st.x / p.fold_n;
-                    rs = rsqrtf(fmaxf(st.y / p.fold_n - mu * mu, 0.f) + p.fold_eps);
-                    if (tile_n == 0 && cg == 0 && p.fold_mean != nullptr) { p.fold_mean[m] = mu; p.fold_rstd[m] = rs; }
-                }
-                f_mu[pp][q] = mu; f_rs[pp][q] = rs;
+                for (int k = 0; k < 8; ++k) { s1 += st[k].x; s2 += st[k].y; }
             }
+            row_mu = s1 / p.fold_n;
+            row_rs = rsqrtf(fmaxf(s2 / p.fold_n - row_mu * row_mu, 0.f) + p.fold_eps);
+            if (tile_n == 0 && p.fold_mean != nullptr) { p.fold_mean[m] = row_mu; p.fold_rstd[m] = row_rs; }
+        }
     }
     if (!FOLD && fast) {
 #pragma unroll
@@ -274,6 +279,10 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
         st_nxt = (st_nxt + 1 == C::NST) ? 0 : st_nxt + 1;
     }
     __syncthreads();          // all MFMA reads of the ring are done (and every DMA has landed) before the slabs overwrite it
+    float* s_rowstat = reinterpret_cast<float*>(smem + C::ROWSTAT_OFF);
+    if constexpr (FOLD) {
+        if (tid < BM) { s_rowstat[2 * tid] = row_mu; s_rowstat[2 * tid + 1] = row_rs; }      // (visible behind the first slab barrier below)
+    }
 
     // ---- epilogue: same term order as gemm.hip::gemm_epilogue ----
     const uint32_t thresh = dropout_threshold(p.drop_p);
@@ -301,8 +310,9 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
                 v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
             }
             if constexpr (FOLD) {
+                const float2 mr = *reinterpret_cast<const float2*>(&s_rowstat[2 * (m - m0)]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = f_rs[pp][q] * (v[e] - f_mu[pp][q] * fsn[e]) + bias[e];
+                for (int e = 0; e < 8; ++e) v[e] = mr.y * (v[e] - mr.x * fsn[e]) + bias[e];
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + bias[e];
@@ -386,14 +396,11 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
             }
             }
             // row statistics for the LayerNorm that reads this result and is folded into ITS consumer: the GPR lanes that hold one row
-            // add up (every lane of the wave takes part, inactive ones with zeros), then one float atomic per row, statistic and column tile
+            // add up (every lane of the wave takes part, inactive ones with zeros; a fixed butterfly: reproducible), then column group 0
+            // (active whenever its row is) stores this column tile's partial into its own slot
             if (p.out_stat) {
-                if constexpr (GPR == 8 || GPR == 16 || GPR == 32) {
-                    st1 = rowgroup_sum<GPR>(st1); st2 = rowgroup_sum<GPR>(st2);
-                    if (act && cg == 0) { atomicAdd(p.out_stat + 2 * (size_t)m, st1); atomicAdd(p.out_stat + 2 * (size_t)m + 1, st2); }      // (column group 0 is active whenever its row is)
-                } else if (act) {
-                    atomicAdd(p.out_stat + 2 * (size_t)m, st1); atomicAdd(p.out_stat + 2 * (size_t)m + 1, st2);
-                }
+                st1 = rowgroup_sum<GPR>(st1); st2 = rowgroup_sum<GPR>(st2);
+                if (act && cg == 0) *reinterpret_cast<float2*>(p.out_stat + 2 * ((size_t)m * p.stat_slots + tile_n)) = make_float2(st1, st2);
             }
         }
     }
@@ -687,7 +694,7 @@ static int g_plan_cus = 256;
 void blt_set_plan_cus(int n) { g_plan_cus = (n > 0 && n <= 256) ? n : 256; }
 int blt_plan_cus() { return g_plan_cus; }
 
-int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn) {
+int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn, bool row_stat) {
     int best = -1;
     double best_cost = 1e30;
     const int nk = cdiv(K, 64);
@@ -695,6 +702,7 @@ int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn) {
     for (int i = 0; i < kNumTiles; ++i) {
         const TileOpt& t = kTiles[i];
         if (force_bm && (t.bm != force_bm || t.bn != force_bn)) continue;
+        if (row_stat && t.bn == 192) continue;      // 24 column groups per row: no butterfly for the row statistics
         const long tiles = (long)cdiv(M, t.bm) * cdiv(N, t.bn);
         const long rounds = (tiles + cus - 1) / cus;
         const double intake = (t.bm + t.bn) * 128.0 / 70e3;                   // us per K-step
@@ -706,7 +714,7 @@ int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn) {
     }
     // measured corrections of the model (scratch/mb_rep.py, un-profiled back-to-back launches on MI355X): at N ~ 1536 the 128 x 256
     // tile (240-252 workgroups, 64 x 64 per wave) beats the 160/192-row tiles the model prefers by 10-15 %
-    if (!force_bm && cus == 256 && M >= 4096 && N > 1024 && N < 2048)
+    if (!force_bm && !row_stat && cus == 256 && M >= 4096 && N > 1024 && N < 2048)
         for (int i = 0; i < kNumTiles; ++i)
             if (kTiles[i].bm == 128 && kTiles[i].bn == 256) return i;
     return best;
@@ -721,12 +729,15 @@ bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a) {
 }
 
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm, int force_bn) {
-    const int i = blt_gemm_nt2_plan(a.M, a.N, a.K, force_bm, force_bn);
-    BLT_REQUIRE(i >= 0, "gemm_nt2: no tile %dx%d compiled in", force_bm, force_bn);
+    const int i = blt_gemm_nt2_plan(a.M, a.N, a.K, force_bm, force_bn, a.out_stat != nullptr);
+    BLT_REQUIRE(i >= 0, "gemm_nt2: no tile %dx%d compiled in%s", force_bm, force_bn, a.out_stat ? " (row statistics: not with 192-column tiles)" : "");
+    BLT_REQUIRE(!a.out_stat || cdiv(a.N, kTiles[i].bn) <= a.stat_slots, "gemm_nt2: %d column tiles but only %d statistics slots per row",
+                cdiv(a.N, kTiles[i].bn), a.stat_slots);
+    BLT_REQUIRE(!a.fold_s || (a.fold_np >= 1 && a.fold_np <= a.stat_slots), "gemm_nt2: fold_np %d outside [1, stat_slots %d]", a.fold_np, a.stat_slots);
     return kTiles[i].launch(a, s);
 }
-void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn) {
-    const int i = blt_gemm_nt2_plan(M, N, K, 0, 0);
+void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat) {
+    const int i = blt_gemm_nt2_plan(M, N, K, 0, 0, row_stat);
     *bm = kTiles[i].bm; *bn = kTiles[i].bn;
 }
 

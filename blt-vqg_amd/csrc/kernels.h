@@ -84,13 +84,17 @@ struct GemmArgs {
     // form).  No bias / alpha (folded into fold_c), no residual / mask / second output / row table / accumulate with it.
     const float* fold_s = nullptr;      // [N]
     const float* fold_c = nullptr;      // [N]
-    const float* fold_stat = nullptr;   // [M][2]
+    const float* fold_stat = nullptr;   // [M][stat_slots][2]: the first fold_np slots of a row are partial {sum, sum of squares}, added in slot order
+    int fold_np = 1;
     float* fold_mean = nullptr;         // [M], written by the first column tile (the LayerNorm's backward reads them); may be null
     float* fold_rstd = nullptr;
     float fold_eps = 1e-5f;
     float fold_n = 0.f;                 // features per row the statistics cover (the LayerNorm's width)
-    // out_stat[m][0..1] += {sum, sum of squares} of result row m AS STORED (bf16-rounded), float atomics: zero it before the launch
+    // out_stat[m][tile_n][0..1] = {sum, sum of squares} of the columns of result row m AS STORED (bf16-rounded) that column tile tile_n of
+    // this launch owns (plain stores, one slot per column tile: the consumer adds the cdiv(N, tile columns) partials in a fixed order, so
+    // the folded LayerNorm is bit-reproducible; blt_gemm_nt2_tile tells the host how many there are).  stat_slots = slots per row (both).
     float* out_stat = nullptr;
+    int stat_slots = 1;
 };
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
 int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
@@ -101,7 +105,7 @@ int blt_gemm_splits(const GemmArgs& a, int dtype);
 // gemm2.hip: one-round-per-chip NT GEMM (bf16, k-contiguous operands, bf16 output): tile shape planned per problem
 bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a);
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm = 0, int force_bn = 0);
-void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn);
+void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat = false);      // row_stat: a launch with out_stat (no 192-column tiles)
 // CUs the launch planners size a "round" for: 256 (the chip) unless the dependent chain runs on a CU partition (engine_set_cu_masks)
 int blt_hw_id_probe(int* out, int n_wg, int spin_ticks, hipStream_t s);      // misc.hip
 void blt_set_plan_cus(int n);      // 0 = the whole chip
@@ -227,7 +231,7 @@ int blt_rows_add(int dtype, void* y, long ystride, const void* a, long astride, 
                  int accumulate, hipStream_t s);
 // same, one wave per row, and stat[b * stat_stride + 0..1] = {sum, sum of squares} of result row b as stored (GemmArgs::fold_stat)
 int blt_rows_add_stat(int dtype, void* y, long ystride, const void* a, long astride, const void* c, long cstride, int B, int n, int accumulate,
-                      float* stat, long stat_stride, hipStream_t s);
+                      float* stat, long stat_stride, int np, hipStream_t s);      // stat[b * stat_stride + 0..1] = the sums, slots 1 .. np-1 of the row zeroed
 // LayerNorm folded into its consumer Linear: W' = bf16(W diag(gamma)) at the weight's offset in wfold_bf16, fold_s / fold_c rows at
 // the entry's srow (misc.hip::FoldEnt table on the device, `row0` = prefix sum of rows)
 struct BltFoldEnt { long w_off, g_off, b_off, bias_off; int rows, K, srow, row0; };

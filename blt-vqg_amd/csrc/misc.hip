@@ -799,7 +799,7 @@ __global__ void dropout_mask_kernel(uint64_t seed, uint32_t stream_id, long rows
 // sums the embedding GEMM left for those rows are replaced here
 template <typename T>
 __global__ __launch_bounds__(256) void rows_add_stat_kernel(T* __restrict__ y, long ys, const T* __restrict__ a, long as, const T* __restrict__ c, long cs,
-                                                            int B, int n, int accumulate, float* __restrict__ stat, long stat_stride) {
+                                                            int B, int n, int accumulate, float* __restrict__ stat, long stat_stride, int np) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -814,7 +814,8 @@ __global__ __launch_bounds__(256) void rows_add_stat_kernel(T* __restrict__ y, l
         s1 += x; s2 += x * x;
     }
     s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { stat[(long)b * stat_stride] = s1; stat[(long)b * stat_stride + 1] = s2; }
+    // slot 0 of the row's partial-sum slots holds the whole row, the other np - 1 slots (the producer GEMM's column tiles) are zeroed
+    if (lane < 2 * np) stat[(long)b * stat_stride + lane] = lane == 0 ? s1 : (lane == 1 ? s2 : 0.f);
 }
 
 // LayerNorm folded into its consumer Linear (gemm2.hip, GemmArgs::fold_*): per output row n of the weight W [rows, K] (fp32 master)
@@ -915,11 +916,11 @@ int blt_rows_add(int dtype, void* y, long ys, const void* a, long as, const void
 }
 
 int blt_rows_add_stat(int dtype, void* y, long ys, const void* a, long as, const void* c, long cs, int B, int n, int accumulate, float* stat,
-                      long stat_stride, hipStream_t s) {
+                      long stat_stride, int np, hipStream_t s) {
     CHECK_DTYPE(dtype, "rows_add_stat");
-    BLT_REQUIRE(y && a && stat && B > 0 && n > 0 && stat_stride >= 2, "rows_add_stat: bad args");
-    if (dtype == BLT_F32) hipLaunchKernelGGL(rows_add_stat_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, s, (float*)y, ys, (const float*)a, as, (const float*)c, cs, B, n, accumulate, stat, stat_stride);
-    else hipLaunchKernelGGL(rows_add_stat_kernel<bf16>, dim3(cdiv(B, 4)), dim3(256), 0, s, (bf16*)y, ys, (const bf16*)a, as, (const bf16*)c, cs, B, n, accumulate, stat, stat_stride);
+    BLT_REQUIRE(y && a && stat && B > 0 && n > 0 && np >= 1 && np <= 32 && stat_stride >= 2 * np, "rows_add_stat: bad args");
+    if (dtype == BLT_F32) hipLaunchKernelGGL(rows_add_stat_kernel<float>, dim3(cdiv(B, 4)), dim3(256), 0, s, (float*)y, ys, (const float*)a, as, (const float*)c, cs, B, n, accumulate, stat, stat_stride, np);
+    else hipLaunchKernelGGL(rows_add_stat_kernel<bf16>, dim3(cdiv(B, 4)), dim3(256), 0, s, (bf16*)y, ys, (const bf16*)a, as, (const bf16*)c, cs, B, n, accumulate, stat, stat_stride, np);
     return blt_check_launch("rows_add_stat");
 }
 

@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
 // NCH = chunk groups per lane (cols <= 512 NCH), R = rows a wave keeps in flight per iteration: every load of the R rows is issued
 // before the first reduction, so a wave pays the memory round trip once per R rows (with R = 1 and ~2.5 serial iterations per wave the
 // [5120 x 512] launch took 13.4 us against 3 us of traffic).
-template <typename T, int NCH, int R>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+template <typename T, int NCH, int R, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
                                                            const float* __restrict__ rstd, const T* dres,
                                                            T* dx, float* __restrict__ dgamma,
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
             for (int e = 0; e < 8; ++e) vm[j] |= (((c * 8 + e) % pad_period) < pad_valid ? 1u : 0u) << e;
         }
     }
-    const long rstride = (long)gridDim.x * 4 * rpw;
-    for (long row0 = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * rpw + sub; row0 < rows; row0 += rstride * R) {
+    const long rstride = (long)gridDim.x * NW * rpw;
+    for (long row0 = ((long)blockIdx.x * NW + (threadIdx.x >> 6)) * rpw + sub; row0 < rows; row0 += rstride * R) {
         float d[R][NCH][8], xh[R][NCH][8], rr[R][NCH][8];
         float mu[R], rs[R];
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) { ag[0][e] += __shfl_xor(ag[0][e], 32, 64); ab[0][e] += __shfl_xor(ab[0][e], 32, 64); }
     }
     // combine the 4 waves of the block through LDS, then one partial row (or one atomic) per column per block
-    __shared__ float red[2][4][512];   // [gamma|beta][wave][512 columns of one chunk group]
+    __shared__ float red[2][NW][512];   // [gamma|beta][wave][512 columns of one chunk group]
     const int w = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -201,11 +201,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         for (int e = 0; e < 8; ++e) { red[0][w][lane * 8 + e] = ag[j][e]; red[1][w][lane * 8 + e] = ab[j][e]; }
         __syncthreads();
         // 512 columns of chunk-group j: column = (lane' + 64 j) * 8 + e  -> index lane'*8+e in red
-        for (int i = threadIdx.x; i < 1024; i += 256) {
+        for (int i = threadIdx.x; i < 1024; i += NW * 64) {
             const int pass = i >> 9, ii = i & 511;
             const int col = 64 * 8 * j + ii;
             if (col < cols) {
-                const float t = red[pass][0][ii] + red[pass][1][ii] + red[pass][2][ii] + red[pass][3][ii];
+                float t = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < NW; ++wv) t += red[pass][wv][ii];
                 // partials: one row of dgamma and one of dbeta per workgroup, summed later by ln_param_reduce_kernel (off the
                 // dependent chain) instead of gridDim.x same-address atomics per column at the tail of this launch
                 if (partials != nullptr) partials[((size_t)blockIdx.x * 2 + pass) * cols + col] = t;
@@ -571,11 +573,26 @@ int blt_layernorm_fwd(int dtype, const void* x, const float* gamma, const float*
 }
 
 static inline int ln_bwd_rows_in_flight(int cols) { return cols <= 512 ? 4 : (cols <= 1024 ? 2 : 1); }
+// workgroup form for cols <= 512 (debug key 24, A/B): 0 / 1 = 4 waves x 4 rows in flight, 2 = 8 waves x 2 rows, 3 = 16 waves x 1 row,
+// 4 = 8 waves x 4 rows (half the workgroups), 5 = 4 waves x 2 rows (twice the workgroups)
+static inline void ln_bwd_form(int cols, int* nw, int* r) {
+    *nw = 4; *r = ln_bwd_rows_in_flight(cols);
+    if (cols > 512) return;
+    switch (blt_debug_get(24)) {
+        case 2: *nw = 8; *r = 2; break;
+        case 3: *nw = 16; *r = 1; break;
+        case 4: *nw = 8; *r = 4; break;
+        case 5: *nw = 4; *r = 2; break;
+        default: break;
+    }
+}
 
 int blt_layernorm_bwd_grid(long rows, int cols) {
     const int rpw = (cols <= 256) ? 2 : 1;
-    int grid = cdiv(rows, 4 * rpw * ln_bwd_rows_in_flight(cols));      // one iteration per wave where that fits in 512 workgroups
-    if (grid > 512) grid = 512;
+    int nw, r;
+    ln_bwd_form(cols, &nw, &r);
+    int grid = cdiv(rows, nw * rpw * r);      // one iteration per wave where that fits in the cap
+    if (grid > 1024) grid = 1024;
     return grid < 1 ? 1 : grid;
 }
 
@@ -623,14 +640,21 @@ int blt_layernorm_bwd(int dtype, const void* dy, const void* x, const float* gam
     BLT_REQUIRE(dy && x && gamma && mean && rstd && dx && dgamma && dbeta, "layernorm_bwd: null pointer");
     int grid = blt_layernorm_bwd_grid(rows, cols);
     if (grid < 1) grid = 1;
-#define LN_BWD_LAUNCH(T_, NCH_, R_)                                                                                                         \
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NCH_, R_>), dim3(grid), dim3(256), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, \
+    int nw_, r_;
+    ln_bwd_form(cols, &nw_, &r_);
+#define LN_BWD_LAUNCH(T_, NCH_, R_, NW_)                                                                                                         \
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T_, NCH_, R_, NW_>), dim3(grid), dim3(NW_ * 64), 0, s, (const T_*)dy, (const T_*)x, gamma, mean, rstd, \
                        (const T_*)dres, (T_*)dx, dgamma, dbeta, rows, cols, (const T_*)maskY, mask_scale, (T_*)out2, partials, pad_period, pad_valid, ld, beta, (T_*)xn_out)
 #define LN_BWD_BY_COLS(T_)                                                                                                                 \
     do {                                                                                                                                    \
-        if (cols <= 512) LN_BWD_LAUNCH(T_, 1, 4);                                                                                           \
-        else if (cols <= 1024) LN_BWD_LAUNCH(T_, 2, 2);                                                                                     \
-        else LN_BWD_LAUNCH(T_, 4, 1);                                                                                                       \
+        if (cols <= 512) {                                                                                                                  \
+            if (nw_ == 8 && r_ == 2) LN_BWD_LAUNCH(T_, 1, 2, 8);                                                                            \
+            else if (nw_ == 16) LN_BWD_LAUNCH(T_, 1, 1, 16);                                                                                \
+            else if (nw_ == 8) LN_BWD_LAUNCH(T_, 1, 4, 8);                                                                                  \
+            else if (r_ == 2) LN_BWD_LAUNCH(T_, 1, 2, 4);                                                                                   \
+            else LN_BWD_LAUNCH(T_, 1, 4, 4);                                                                                                \
+        } else if (cols <= 1024) LN_BWD_LAUNCH(T_, 2, 2, 4);                                                                                \
+        else LN_BWD_LAUNCH(T_, 4, 1, 4);                                                                                                    \
     } while (0)
     if (dtype == BLT_F32) LN_BWD_BY_COLS(float);
     else LN_BWD_BY_COLS(bf16);

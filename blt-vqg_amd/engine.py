@@ -201,6 +201,11 @@ class StepEngine(object):
         check(self.lib.bltvqg_engine_conv_stream(self.h, ctypes.byref(p)), "engine_conv_stream")
         return torch.cuda.ExternalStream(p.value, device=self.device)
 
+    def conv_stream_wait(self):
+        """Orders the current stream behind everything enqueued on the engine's conv look-ahead stream (bltvqg_engine_conv_stream_wait):
+        before reading flat_frozen (BatchNorm2d running statistics) while a prefetched stack may still be running."""
+        check(self.lib.bltvqg_engine_conv_stream_wait(self.h, stream_ptr()), "engine_conv_stream_wait")
+
     def image_input(self):
         """(device pointer, Hp, Wp, dtype) of the engine's zero-bordered NHWC4 stem input (bltvqg_engine_image_input)."""
         p, hp, wp, dt = ctypes.c_void_p(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
@@ -290,7 +295,9 @@ class StepEngine(object):
         """(total kernel ms, launches, algorithmic flops) of class `cls` (0 = convolutions, 1 = Linear GEMMs) since the last read;
         synchronises on the recorded events."""
         ms, n, fl = ctypes.c_double(), ctypes.c_int32(), ctypes.c_double()
-        check(self.lib.bltvqg_engine_profile_read_class(self.h, int(cls), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl)), "profile_read")
+        by = (ctypes.c_double * 4)()
+        check(self.lib.bltvqg_engine_profile_read_streams(self.h, int(cls), ctypes.byref(ms), ctypes.byref(n), ctypes.byref(fl), by), "profile_read")
+        self.last_profile_by_stream_ms = [float(x) for x in by]      # [caller's stream, side 0, side 1, conv look-ahead stream]
         return ms.value, n.value, fl.value
 
     def set_bucket_flush(self, on=True):

@@ -238,6 +238,11 @@ class IQ(nn.Module):
             self._master = "engine"
 
     def state_dict(self, *a, **k):
+        # a conv stack that runs one batch ahead writes the BatchNorm2d running statistics on the engine's conv stream: order this
+        # stream behind it (the statistics then include that batch, whole)
+        for e in self._engines.values():
+            if hasattr(e, "conv_stream_wait") and e.bound and e.device.type == "cuda":
+                e.conv_stream_wait()
         self.sync_from_engine()
         return super().state_dict(*a, **k)
 

@@ -11,6 +11,7 @@ pytorch_lightning is not a dependency: when it is importable TrainIQ subclasses 
 import argparse
 import math
 import os
+import sys
 from types import SimpleNamespace
 
 import torch
@@ -146,11 +147,20 @@ class TrainIQ(_Base):
     def _images_on_device(self, batch):
         """The batch's image tensor as the engine takes it (device, fp32, contiguous) — cached per batch object, so that the tensor handed
         to the conv look-ahead as `next_batch` is the very one the next step passes."""
-        c = getattr(self, "_img_cache", None)
-        if c is not None and c[0] is batch:
-            return c[1]
-        t = batch["images"].to(self._device()).contiguous().float()
-        self._img_cache = (batch, t)
+        src = batch["images"]
+        # keyed on the SOURCE tensor and its version counter, not only on the dict: a loader that refills one dict / pinned buffer in
+        # place must not get the previous batch's device copy back
+        key = (id(batch), id(src), src.data_ptr(), int(getattr(src, "_version", 0)))
+        cache = getattr(self, "_img_cache", None)
+        if cache is None:
+            cache = self._img_cache = {}
+        hit = cache.get(key)
+        if hit is not None and hit[0] is src:
+            return hit[1]
+        t = src.to(self._device()).contiguous().float()
+        if len(cache) >= 2:      # the current batch and the look-ahead one
+            cache.pop(next(iter(cache)))
+        cache[key] = (src, t)
         return t
 
     def fused_training_step(self, batch, dist=None, next_batch=None):
@@ -171,6 +181,10 @@ class TrainIQ(_Base):
             if not hasattr(self, "_dps"):
                 self._dps = {}
             if id(eng) not in self._dps:
+                # padded widths: the module's parameters go into the engine's (padded) buffers BEFORE the rank-0 broadcast of the
+                # constructor, and the engine owns them from then on — a scatter after the broadcast would put every rank's local
+                # values back over rank 0's
+                self.model.sync_to_engine(for_fused=True)
                 self._dps[id(eng)] = DataParallelStep(eng, dist, broadcast=not self._dps, check_ids_every=100)
             self._dp = self._dps[id(eng)]
         if getattr(self, "_pending_adam", None) is not None:      # optimiser state of a loaded checkpoint (fused path)
@@ -195,7 +209,7 @@ class TrainIQ(_Base):
         if look_ahead and next_batch is not None and next_batch.get("images") is not None and \
                 tuple(next_batch["images"].shape) == tuple(images.shape):
             nxt = self._images_on_device(next_batch)
-        elif eng.prefetch_pending() and images is not None and self._dp._prefetched_ptr != images.data_ptr():
+        elif eng.prefetch_pending() and images is not None and self._dp._prefetched is not images:
             raise RuntimeError("fused_training_step: the engine holds the look-ahead conv stack of another batch than the one passed "
                                "(pass the batch that was given as next_batch to the previous call)")
         self._dp.run(images, context.contiguous(), posteriors.contiguous(),
@@ -221,12 +235,19 @@ class TrainIQ(_Base):
     # (torch.load(weights_only=True)): a file that needs arbitrary unpickling (e.g. an argparse.Namespace under "hyper_parameters") is
     # refused by torch with a message naming the offending global, and is not loaded any other way.
     def save_checkpoint(self, path):
+        eng0 = getattr(self, "_last_engine", None)
+        if eng0 is not None:
+            eng0.optimizer_wait()
+            eng0.conv_stream_wait()
         sd = {"model." + k: v.detach().float().cpu().clone() for k, v in self.model.state_dict().items()}
         ckpt = {"epoch": 0, "global_step": int(self.iter), "pytorch-lightning_version": "1.1.8", "state_dict": sd,
                 "blt_vqg": {"iter": int(self.iter), "kliter": int(self.kliter), "latent_transformer": bool(self.latent_transformer)}}
         eng = getattr(self, "_last_engine", None)
         if eng is not None:      # fused path: Adam moments of the flat buffer (the autograd path keeps them in its torch optimizer)
             eng.optimizer_wait()
+            # a conv stack that runs one batch ahead advances the BatchNorm2d running statistics on the conv stream: the statistics
+            # saved here INCLUDE that look-ahead batch (whole, not torn) — on resume that batch's stack runs again
+            eng.conv_stream_wait()
             ckpt["blt_vqg"]["adam"] = {"m": eng.adam_m.detach().cpu().clone(), "v": eng.adam_v.detach().cpu().clone(),
                                        "steps": [int(x) for x in eng.adam_steps()]}
         torch.save(ckpt, path)
@@ -344,25 +365,79 @@ class SyntheticVocabulary(object):
         return len(self.word2idx)
 
 
+def _init_distributed(args):
+    """Inside a rank (torch.distributed.run exported RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*): pick this rank's GPU and join the process
+    group.  backend `nccl` IS RCCL on ROCm; BLT_DIST_BACKEND=gloo runs the same step with gloo carrying the gradients (rehearsals on a
+    box with fewer GPUs than ranks: BLT_SHARE_GPU=1 maps every rank to LOCAL_RANK modulo the device count)."""
+    from .launch import rank_env
+    import torch.distributed as dist
+    rank, world, local = rank_env()
+    backend = os.environ.get("BLT_DIST_BACKEND", "nccl")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if torch.cuda.is_available() and args.use_gpu:
+        if os.environ.get("BLT_SHARE_GPU") == "1":
+            local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        args.device = torch.device("cuda", local)
+    else:
+        args.device = torch.device("cpu")
+    if backend == "nccl" and args.device.type == "cuda":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=args.device)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return dist, rank, world
+
+
+def _load_factory(spec):
+    """`module:callable` -> the callable (the trainer factory seam of main(): tests drive the launch + data-parallel path on CPU ranks
+    with a stand-in for the GPU engine; the product path has no CPU fallback)."""
+    import importlib
+    mod, _, fn = spec.partition(":")
+    return getattr(importlib.import_module(mod), fn)
+
+
 def main(argv=None):
-    from . import synthetic
+    """`python train_iq.py --synthetic [--num_gpus N] ...` (reference train_iq.py:313-374).  --num_gpus N > 1 is the reference's
+    `pl.Trainer(gpus=N)`: started plainly, this process spawns N ranks (one per GPU, `python -m torch.distributed.run`) BEFORE any GPU
+    call and relays their exit code; started by a launcher it IS one rank: it joins the process group, trains on its shard of every
+    global batch (seed = base + step * world + rank) and exchanges gradients through DataParallelStep (RCCL all-reduce per bucket)."""
+    from .launch import spawn_ranks, under_launcher
+    argv = list(sys.argv[1:] if argv is None else argv)
     args = build_parser().parse_args(argv)
-    args.device = torch.device("cuda" if torch.cuda.is_available() and args.use_gpu else "cpu")
+    if args.num_gpus > 1 and not under_launcher():
+        script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "train_iq.py")
+        return spawn_ranks(args.num_gpus, script, argv)
+    from . import synthetic
+    from .trainer import shard_seed
+    dist, rank, world = None, 0, 1
+    if under_launcher() and int(os.environ["WORLD_SIZE"]) > 1:
+        dist, rank, world = _init_distributed(args)
+        if args.num_gpus != world and rank == 0:
+            print("train_iq: --num_gpus %d but WORLD_SIZE %d (the launcher's world size is what runs)" % (args.num_gpus, world), file=sys.stderr)
+    else:
+        args.device = torch.device("cuda" if torch.cuda.is_available() and args.use_gpu else "cpu")
     args.root_dir = os.getcwd()
     if not args.synthetic:
-        raise SystemExit("only --synthetic batches are available here (the HDF5 loader is scope row N2, SURVEY §8f)")
+        raise SystemExit("only --synthetic batches are available here (the HDF5 container needs h5py, absent from this image; "
+                         "bltvqg_amd.batch.IQStore takes the six dataset arrays: TrainIQ.fit_from_producer)")
     if not os.path.exists(os.path.join(args.root_dir, args.emb_file)):
         args.emb_file = None
     vocab = SyntheticVocabulary(8000)
-    model = TrainIQ(vocab, args).to(args.device)
+    factory = os.environ.get("BLT_TRAINER_FACTORY")
+    model = _load_factory(factory)(vocab, args) if factory else TrainIQ(vocab, args).to(args.device)
 
     def loader():
         i = 0
-        while True:
-            yield synthetic.make_batch(args.batch_size, len(vocab), args.latent_dim, seed=1234 + i)
+        while True:      # global batch i is sharded by rank: every rank draws its own batch_size samples (weak scaling, like DDP)
+            yield synthetic.make_batch(args.batch_size, len(vocab), args.latent_dim, seed=shard_seed(1234 + i * world, rank))
             i += 1
-    model.fit(loader(), args.total_training_steps)
+    try:
+        model.fit(loader(), args.total_training_steps, dist=dist)
+    finally:
+        if dist is not None:
+            dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -79,7 +79,9 @@ def comm_plan(buckets, phase2):
     engine lists them in).  One collective per bucket: the engine closes a bucket at every weight-gradient flush point — groups of whole
     layers of >= ~32 MB — and records its event right behind the flush, so every collective but the last (embedding + CNN head, final
     with the end of backward) is enqueued while backward is still running and none exceeds a few layers (25-32 MB buckets
-    launched as they become final).  Buckets that become final at the same flush AND are adjacent in the flat buffer travel together."""
+    launched as they become final).  Every bucket is its own collective, also when several become final at one flush (no in-stack
+    flushes: all of a stack's buckets at its end) — what a collective costs on the exposed tail has not been measured with more than
+    one rank (no multi-GPU box was available to any round), so nothing is merged on a guess."""
     plan = []
     for i, off, n in active_buckets(buckets, phase2):
         plan.append(([i], off, n))
@@ -128,7 +130,7 @@ class DataParallelStep(object):
     forward(), loss_backward(), optimizer_step(), optimizer_wait() — tests/test_dp_gloo.py drives this class with a CPU stand-in over
     gloo).  On a CPU device there are no streams: the collectives run inline."""
 
-    def __init__(self, engine, dist=None, overlap_optimizer=False, broadcast=True, bf16_wire=False, check_ids_every=0):
+    def __init__(self, engine, dist=None, overlap_optimizer=False, broadcast=True, bf16_wire=False, check_ids_every=0, comm_stream="shared"):
         self.e = engine
         self.dist = dist
         self.rank = dist.get_rank() if dist is not None else 0
@@ -137,12 +139,24 @@ class DataParallelStep(object):
         # (StepEngine.optimizer_step(overlap=True)); call finish() before reading parameters
         self.overlap_optimizer = overlap_optimizer
         self.comm = torch.cuda.Stream(device=engine.device) if (dist is not None and self.cuda) else None
-        # The communication stream is idle from the start of a step until the first gradient bucket is final (~60 % of the step) — exactly
-        # where the NEXT batch's frozen conv stack runs when it is enqueued one batch ahead (run(next_images=...)).  One stream serves both,
-        # in order: conv stack of batch i+1, then the all-reduces of step i, then the optimiser fork; the step stays at four live streams
-        # (the command processor runs four queues side by side).
+        # comm_stream = "shared" (default): the communication stream is idle from the start of a step until the first gradient bucket is
+        # final (~60 % of the step) — exactly where the NEXT batch's frozen conv stack runs when it is enqueued one batch ahead
+        # (run(next_images=...)).  One stream serves both, in order: conv stack of batch i+1, then the all-reduces of step i, then the
+        # optimiser fork; the step stays at four live streams (the command processor runs four queues side by side).
+        # comm_stream = "own": the collectives get a stream to themselves and the conv look-ahead a second one (five live streams + RCCL's
+        # own): an in-order shared stream makes collective 1 of step i queue behind the whole conv stack of batch i+1, which the one-rank
+        # rehearsal cannot price — with real RCCL kernels on N > 1 GPUs one sweep of this switch (bench.py --comm-stream) decides it.
+        if comm_stream not in ("shared", "own"):
+            raise ValueError("comm_stream must be 'shared' or 'own'")
+        self.comm_stream_mode = comm_stream if self.comm is not None else "none"
+        self.conv_stream = None
         if self.comm is not None and hasattr(engine, "adopt_conv_stream") and engine.cfg.num_regions == 0:
-            engine.adopt_conv_stream(self.comm)
+            if comm_stream == "shared":
+                engine.adopt_conv_stream(self.comm)
+                self.conv_stream = self.comm
+            else:
+                self.conv_stream = torch.cuda.Stream(device=engine.device)
+                engine.adopt_conv_stream(self.conv_stream)
         self.buckets = engine.buckets()
         # with an exchange to overlap, the engine flushes weight gradients at every bucket boundary so that each bucket's all-reduce can
         # start under the rest of backward; on one GPU those extra launches only compete with the chain (+0.15 ms per step measured)
@@ -153,7 +167,7 @@ class DataParallelStep(object):
         if dist is not None and bf16_wire:
             self.wire = torch.empty(max(n for _, _, n in comm_plan(self.buckets, True)), dtype=torch.bfloat16, device=engine.flat_grad.device)
         self.steps_run = 0
-        self._prefetched_ptr = None
+        self._prefetched = None       # the tensor whose conv stack the engine holds (identity, not address: the allocator reuses addresses)
         # exposed communication: with measure_exposed on, every step records an event pair (end of backward on the step's stream, end of the
         # last all-reduce on the communication stream); exposed_ms() = how long the optimiser had to wait for the exchange after backward
         self.measure_exposed = False
@@ -199,7 +213,7 @@ class DataParallelStep(object):
         if hasattr(e, "trust_shadows"):
             e.trust_shadows(True)
         pending = e.prefetch_pending() if hasattr(e, "prefetch_pending") else 0
-        if pending and images is not None and images.data_ptr() != self._prefetched_ptr:
+        if pending and images is not None and images is not self._prefetched:
             raise RuntimeError("DataParallelStep.run: the engine holds the prefetched conv stack of another image batch than the one passed "
                                "(pass the tensor that was given as next_images to the previous run, or images=None)")
         if next_images is not None:
@@ -207,7 +221,7 @@ class DataParallelStep(object):
                 e.prefetch_images(images)
                 pending = 1
             e.prefetch_images(next_images)
-            self._prefetched_ptr = next_images.data_ptr()
+            self._prefetched = next_images
         e.forward(None if pending else images, context, posterior, target, eps, phase2, rank_dropout_seed(seed, self.rank))
         e.loss_backward(kl_weight)
         ev_a = None

@@ -68,19 +68,25 @@ int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int 
  * :356-358 -> FFN layer 0), so  LN(x) W^T + b = rstd_m (x W'^T - mean_m s_n) + c_n  with W' = W diag(gamma), s_n = sum_k W'[n,k],
  * c_n = sum_k beta[k] W[n,k] + b_n: the normalisation moves into the GEMM epilogue, the row sums come from the epilogue of the GEMM that
  * PRODUCED x, and the layernorm launch between the two disappears.
- * bltvqg_gemm_rowstat: bltvqg_gemm_ex's Linear (bias, relu, dropout, second output C2, residual R) that also ADDS the {sum, sum of squares}
- *   of every result row AS STORED (bf16-rounded) to out_stat[m][0..1] (float atomics: zero out_stat before the launch).
+ * bltvqg_gemm_rowstat: bltvqg_gemm_ex's Linear (bias, relu, dropout, second output C2, residual R) that also STORES, per result row m and
+ *   column tile t of the launch, the {sum, sum of squares} of the columns that tile owns, AS STORED (bf16-rounded), into
+ *   out_stat[m][t][0..1] (stat_slots slots per row; plain stores, no atomics: the consumer adds the parts in slot order, so the folded
+ *   LayerNorm is bit-reproducible).  bltvqg_gemm_rowstat_parts(M, N, K, tile_n) = how many parts that launch writes (tile_n = 0: the
+ *   planner's tile; row statistics never take a 192-column tile).
  * bltvqg_ln_fold_prepare: W'[N,K] (bf16), s[N] (of the ROUNDED W'), c[N] (fp32 W; bias may be NULL) from the fp32 parameters.
  * bltvqg_linear_ln_folded: Y = [dropout][relu](rstd_m (X Wf^T - mean_m s_n) + c_n) with mean_m / rstd_m from row_stat[m] = {sum, sum of
- *   squares} of row m of X over its K features (biased variance, eps inside the square root, as nn.LayerNorm); mean / rstd (both or
- *   neither) receive the statistics (the LayerNorm's backward reads them). */
+ *   squares} of row m of X over its K features, given as stat_parts partial sums in the first slots of row_stat[m][stat_slots][2]
+ *   (biased variance, eps inside the square root, as nn.LayerNorm); mean / rstd (both or neither) receive the statistics (the
+ *   LayerNorm's backward reads them). */
 int bltvqg_gemm_rowstat(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu, float drop_p,
-                        uint64_t seed, uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, float* out_stat, int tile_m, int tile_n, void* stream);
+                        uint64_t seed, uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, float* out_stat, int stat_slots, int tile_m, int tile_n,
+                        void* stream);
+int bltvqg_gemm_rowstat_parts(int M, int N, int K, int tile_n);
 int bltvqg_ln_fold_prepare(const float* W, int N, int K, const float* gamma, const float* beta, const float* bias, void* Wf_bf16, float* fold_s,
                            float* fold_c, void* stream);
 int bltvqg_linear_ln_folded(const void* X, int ldx, const void* Wf, int ldw, void* Y, int ldy, int M, int N, int K, const float* fold_s, const float* fold_c,
-                            const float* row_stat, float* mean, float* rstd, float eps, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
-                            int tile_m, int tile_n, void* stream);
+                            const float* row_stat, int stat_slots, int stat_parts, float* mean, float* rstd, float eps, int relu, float drop_p, uint64_t seed,
+                            uint32_t stream_id, int tile_m, int tile_n, void* stream);
 /* Weight gradients of n Linear layers in ONE launch (bf16 operands, fp32 results): dW_i[N_i, K_i] = dY_i[rows_i, N_i]^T X_i[rows_i, K_i]
  * and dbias_i[N_i] = column sums of dY_i (dbias_i may be NULL).  Results are STORED unless the launch is short of tiles and slices
  * the contraction (then they are atomically added: dW / dbias must be zero on entry, as the engine's gradient buffer is).  The
@@ -377,6 +383,13 @@ int bltvqg_engine_set_cu_masks(bltvqg_engine* e, const uint32_t* chain_mask_host
 int bltvqg_engine_chain_stream(bltvqg_engine* e, void** stream);
 /* the engine's prefetch (conv) stream, for diagnostics: which CUs its work lands on (bltvqg_hw_id_probe) */
 int bltvqg_engine_conv_stream(bltvqg_engine* e, void** stream);
+/* Orders `stream` behind the last conv stack enqueued on the look-ahead stream (no-op when none ran ahead): a prefetched stack advances
+ * the BatchNorm2d running statistics in the frozen buffer one batch ahead, so readers of that buffer (state_dict, checkpoints) wait here
+ * and see the statistics INCLUDING the look-ahead batch, whole. */
+int bltvqg_engine_conv_stream_wait(bltvqg_engine* e, void* stream);
+/* Diagnostic: the engine's two side streams (0: posterior encoder / branch work, 1: context encoder / deferred weight gradients / optimiser),
+ * for stream-ordering tests that delay one of them. */
+int bltvqg_engine_side_stream(bltvqg_engine* e, int which, void** stream);
 /* Run the prefetched conv stacks on a stream the CALLER owns (and outlives the engine with) instead of the engine's own: a feeder that
  * copies the next batch over PCIe enqueues copy and bltvqg_engine_prefetch_images on that one stream — one pipeline underneath the current
  * step, no extra stream.  Not combined with conv_mask_host (the caller's stream has the caller's CU mask). */
@@ -438,6 +451,11 @@ uint32_t bltvqg_engine_dropout_stream_id(int stack, int layer, int site);
 int bltvqg_engine_profile_enable(bltvqg_engine* e, int mask);
 int bltvqg_engine_profile_read(bltvqg_engine* e, double* total_ms_host, int32_t* launches_host, double* flops_host);
 int bltvqg_engine_profile_read_class(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host);
+/* same, plus the bracketed time split by the stream the launches sat on (per_stream_ms_host4: [0] the caller's stream, [1] / [2] the engine's
+ * two side streams, [3] the conv look-ahead stream; may be NULL): the step's streams run side by side, so the SUM over streams can exceed the
+ * step's wall time while every single stream's share fits inside it */
+int bltvqg_engine_profile_read_streams(bltvqg_engine* e, int cls, double* total_ms_host, int32_t* launches_host, double* flops_host,
+                                       double* per_stream_ms_host4);
 /* Diagnostic (bltvqg_debug_set(12, 1)): milliseconds from the start of the last forward to the phase boundaries of the step on the
  * caller's stream — [1] CNN + encoders joined, [2] decoder starts, [3] decoder done, [4] end of forward, [5] losses, [6] decoder backward
  * starts, [7] decoder backward done, [8] encoder backward starts, [9] done, [10] end of backward, [11] image feature done on the CNN's

@@ -103,3 +103,45 @@ def test_two_rank_engine_gradients_are_the_mean_of_the_single_rank_gradients():
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
     assert dict(out) == {0: "ok", 1: "ok"}
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_in_stack_flush_waits_for_the_branch_stream(dtype):
+    """with in-stack weight-gradient flushes (the data-parallel mode) the decoder's FIRST flush carries the image
+    reconstructor's and z_classifier's weight gradients, whose operands are written on the branch stream (side 0).  The weight-gradient
+    stream must order itself behind that branch: with the branch delayed by a long kernel, the flushed run must still give the
+    gradients of the unflushed one.  BASELINE configs[2] widths (the in-stack bucket boundaries exist from ~32 MB of layers on)."""
+    import ctypes
+    import bltvqg_amd.synthetic as synthetic
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import init_reference_style
+    B, hw = 4, 64
+    c = make_config(B, 512, 2048, 512, 300, 6, 8, 8000, image_hw=(hw, hw), dtype=dtype, attention_dropout=0.0, relu_dropout=0.0)
+    # a DIFFERENT batch every repetition: operands left over from the previous step must not pass for the current ones
+    ds = [{k: v.cuda() for k, v in synthetic.make_batch(B, 8000, 512, seed=11 + r, image_hw=hw).items() if torch.is_tensor(v)} for r in range(3)]
+    grads = {}
+    for flush in (0, 1):
+        e = StepEngine(c)
+        e.allocate()
+        init_reference_style(e, seed=3)
+        assert any(late == 0 for _, _, late in e.buckets()[:3])
+        e.set_bucket_flush(bool(flush))
+        for rep in range(3):
+            d = ds[rep]
+            e.forward(d["images"], d["answers"], d["posteriors"], d["questions"], d["eps"], True, 5)
+            if flush:      # delay the branch stream: a few ms of sleep in front of the loss kernels it runs
+                p = ctypes.c_void_p()
+                assert e.lib.bltvqg_engine_side_stream(e.h, 0, ctypes.byref(p)) == 0
+                with torch.cuda.stream(torch.cuda.ExternalStream(p.value)):
+                    torch.cuda._sleep(8_000_000)
+            e.loss_backward(0.4)
+            torch.cuda.synchronize()
+        grads[flush] = e.flat_grad.clone()
+        info = dict(e.train_info)
+        del e
+    for n in ("image_reconstructor.layers.fc1.weight", "image_reconstructor.layers.fc0.weight", "image_reconstructor.layers.fc0.bias",
+              "decoder.z_classifier.weight", "decoder.z_classifier.bias", "decoder.output.weight"):
+        i = info[n]
+        a, b = grads[0][i.offset:i.offset + i.numel], grads[1][i.offset:i.offset + i.numel]
+        assert float(a.abs().max()) > 0.0
+        assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()), n

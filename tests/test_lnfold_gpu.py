@@ -14,7 +14,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-TILES = [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (160, 64), (160, 128), (160, 192), (160, 256), (192, 64), (192, 128), (192, 192),
+# (row statistics never take a 192-column tile: 24 column groups per row have no butterfly)
+TILES = [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (160, 64), (160, 128), (160, 256), (192, 64), (192, 128),
          (192, 256), (128, 256), (256, 128), (96, 64), (32, 64)]
 
 
@@ -26,11 +27,15 @@ def _rowstat(A, W, M, N, K, tile, bias=None, relu=False, R=None, C2=None):
     import gpu_ops as G
     from bltvqg_amd._lib import check, stream_ptr
     C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
-    st = torch.zeros(M, 2, dtype=torch.float32, device="cuda")
+    parts = int(G.lib().bltvqg_gemm_rowstat_parts(M, N, K, tile[1]))
+    slots = parts + 2
+    st = torch.full((M, slots, 2), 7.0, dtype=torch.float32, device="cuda")      # slots beyond `parts` must stay untouched
     check(G.lib().bltvqg_gemm_rowstat(G.ptr(A), A.stride(0), G.ptr(W), W.stride(0), G.ptr(C), C.stride(0), M, N, K, G.ptr(bias), int(relu), 0.0, 0, 0,
-                                      G.ptr(C2), 0 if C2 is None else C2.stride(0), G.ptr(R), 0 if R is None else R.stride(0), G.ptr(st), tile[0], tile[1],
-                                      stream_ptr()), "gemm_rowstat")
-    return C, st
+                                      G.ptr(C2), 0 if C2 is None else C2.stride(0), G.ptr(R), 0 if R is None else R.stride(0), G.ptr(st), slots, tile[0],
+                                      tile[1], stream_ptr()), "gemm_rowstat")
+    torch.cuda.synchronize()
+    assert float((st[:, parts:, :] - 7.0).abs().max()) == 0.0
+    return C, st[:, :parts, :].double().sum(1).float()
 
 
 @pytest.mark.parametrize("tile", TILES)
@@ -93,7 +98,7 @@ def test_fold_preparation(with_bias):
     assert float((fc.double() - ref_c).abs().max()) < 1e-4
 
 
-def _folded(X, Wf, fs, fc, st, tile, relu=False, drop_p=0.0, seed=0, sid=0, eps=1e-5):
+def _folded(X, Wf, fs, fc, st, tile, relu=False, drop_p=0.0, seed=0, sid=0, eps=1e-5, parts=3):
     import gpu_ops as G
     from bltvqg_amd._lib import check, stream_ptr
     M, K = X.shape
@@ -101,10 +106,29 @@ def _folded(X, Wf, fs, fc, st, tile, relu=False, drop_p=0.0, seed=0, sid=0, eps=
     Y = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
     mean = torch.zeros(M, dtype=torch.float32, device="cuda")
     rstd = torch.zeros(M, dtype=torch.float32, device="cuda")
-    check(G.lib().bltvqg_linear_ln_folded(G.ptr(X), X.stride(0), G.ptr(Wf), Wf.stride(0), G.ptr(Y), Y.stride(0), M, N, K, G.ptr(fs), G.ptr(fc), G.ptr(st),
-                                          G.ptr(mean), G.ptr(rstd), eps, int(relu), float(drop_p), int(seed), int(sid), tile[0], tile[1], stream_ptr()),
-          "linear_ln_folded")
+    # the row sums as `parts` partial sums in the first slots of a wider slot array (as a producer GEMM with that many column tiles leaves them)
+    slots = parts + 1
+    w = torch.rand(M, parts, 1, device="cuda", dtype=torch.float64) + 0.1
+    sp = torch.full((M, slots, 2), 1e9, dtype=torch.float32, device="cuda")
+    sp[:, :parts, :] = (st.double()[:, None, :] * w / w.sum(1, keepdim=True)).float()
+    check(G.lib().bltvqg_linear_ln_folded(G.ptr(X), X.stride(0), G.ptr(Wf), Wf.stride(0), G.ptr(Y), Y.stride(0), M, N, K, G.ptr(fs), G.ptr(fc), G.ptr(sp),
+                                          slots, parts, G.ptr(mean), G.ptr(rstd), eps, int(relu), float(drop_p), int(seed), int(sid), tile[0], tile[1],
+                                          stream_ptr()), "linear_ln_folded")
     return Y, mean, rstd
+
+
+def test_row_statistics_are_bit_reproducible():
+    g = torch.Generator().manual_seed(4)
+    M, N, K = 5120, 512, 512
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+    R = torch.randn(M, N, generator=g).bfloat16().cuda()
+    ref = None
+    for _ in range(20):
+        _, st = _rowstat(A, W, M, N, K, (0, 0), R=R)
+        if ref is None:
+            ref = st.clone()
+        assert torch.equal(st, ref)
 
 
 @pytest.mark.parametrize("tile", [(0, 0), (160, 64), (160, 256), (128, 256), (192, 192), (64, 64), (32, 64)])
@@ -131,7 +155,7 @@ def test_folded_linear_matches_layernorm_then_linear(tile, relu):
         ref = torch.relu(ref)
     err = float((Y.double() - ref).abs().max() / ref.abs().max())
     assert err < 6e-3, err                      # one bf16 rounding of the result
-    assert float((mean.double() - mu).abs().max()) < 1e-5 and float(((rstd.double() - rs) / rs).abs().max()) < 1e-5
+    assert float((mean.double() - mu).abs().max()) < 2e-5 and float(((rstd.double() - rs) / rs).abs().max()) < 2e-4
     # (b) against torch: LayerNorm (fp32) -> Linear
     xn = torch.nn.functional.layer_norm(X.float(), (K,), gamma, beta, 1e-5)
     ref2 = xn @ W.t() + bias
@@ -153,8 +177,8 @@ def test_folded_linear_dropout_uses_the_exported_mask():
     Wf, fs, fc = _prepare(W, gamma, beta, None)
     xd = X.double()
     st = torch.stack([xd.sum(1), (xd * xd).sum(1)], 1).float().contiguous()
-    Y0, _, _ = _folded(X, Wf, fs, fc, st, (0, 0), relu=True)
-    Y1, _, _ = _folded(X, Wf, fs, fc, st, (0, 0), relu=True, drop_p=0.25, seed=77, sid=5)
+    Y0, _, _ = _folded(X, Wf, fs, fc, st, (0, 0), relu=True, parts=1)
+    Y1, _, _ = _folded(X, Wf, fs, fc, st, (0, 0), relu=True, drop_p=0.25, seed=77, sid=5, parts=1)
     mask = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
     check(G.lib().bltvqg_dropout_mask(77, 5, M, N, (N + 7) // 8 * 8, 0.25, G.ptr(mask), stream_ptr()), "dropout_mask")
     torch.cuda.synchronize()

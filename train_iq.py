@@ -11,4 +11,4 @@ import bltvqg_amd  # noqa: E402,F401
 from bltvqg_amd.train_iq import TrainIQ, SyntheticVocabulary, build_parser, main  # noqa: E402,F401
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

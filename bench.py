@@ -37,11 +37,17 @@ CONFIGS = {
     # BASELINE.json configs[4]: bottom-up features (36 x 2048 regions, no CNN), 6-layer transformer, global batch 512 = 8 x 64
     "regions": dict(hidden_dim=512, pwffn_dim=2048, latent_dim=512, emb_dim=300, num_layers=6, num_heads=8, vocab_size=8000, batch=64,
                     num_regions=36, region_dim=2048),
+    # the one launch the reference documents (run.sh:1-10): hidden / latent 1024, FFN 2048, 6 layers, 8 heads of 128, batch 64, --input_mode cat
+    "runsh": dict(hidden_dim=1024, pwffn_dim=2048, latent_dim=1024, emb_dim=300, num_layers=6, num_heads=8, vocab_size=8000, batch=64, len_context=3),
+    # the reference's CLI defaults (train_iq.py:315-339): hidden 300 = 4 heads of 75, latent 300, FFN 600, 4 layers, batch 128 — on the padded
+    # engine layout (heads in slots of 80 columns: hidden 320, latent 304; blt-vqg_amd/padded.py)
+    "default300": dict(hidden_dim=300, pwffn_dim=600, latent_dim=300, emb_dim=300, num_layers=4, num_heads=4, vocab_size=8000, batch=128),
 }
-CONFIG_NAMES = {"small": "BASELINE configs[1]", "big": "BASELINE configs[2]", "regions": "BASELINE configs[4], one GPU's shard"}
+CONFIG_NAMES = {"small": "BASELINE configs[1]", "big": "BASELINE configs[2]", "regions": "BASELINE configs[4], one GPU's shard",
+                "runsh": "the reference's documented launch (run.sh:1-10)", "default300": "the reference's CLI defaults (train_iq.py:315-339)"}
 # algorithmic FLOP per pair per train step: CNN fwd x1 + everything trainable x3; regions: the projection runs on the
 # region mean (the mean commutes with the Linear), 2.1 MFLOP per pair instead of the survey's 75.5
-FLOP_PER_PAIR = {"small": 4.25e9, "big": 9.95e9, "regions": 6.33e9}
+FLOP_PER_PAIR = {"small": 4.25e9, "big": 9.95e9, "regions": 6.33e9, "runsh": 20.0e9, "default300": 4.89e9}      # (SURVEY §8d formulas)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 HP = dict(kl_weight=0.5, lr=1e-4, max_norm=5.0)
 
@@ -133,6 +139,8 @@ def cpu_baseline(cfg, phase2, batch, steps):
     opt = torch.optim.Adam([P[n] for n in names], lr=1e-4)
     hp = O.default_hp()
     b = synthetic.make_batch(batch, ns.vocab_size, ns.latent_dim, seed=1234, image_hw=32 if ns.num_regions else 224)
+    if cfg.get("len_context", 5) == 3:      # --input_mode cat
+        b["answers"] = b["answer_types_for_input"]
     if ns.num_regions:
         b["images"] = region_features(batch, ns.num_regions, ns.region_dim, 1234)
     gen = torch.Generator().manual_seed(7)
@@ -158,16 +166,14 @@ def cpu_baseline(cfg, phase2, batch, steps):
                                                                                                  "on" if phase2 else "off"))
 
 
-def loss_vs_oracle(eng, cfg, a, B, phase2, batch, rank):
+def loss_vs_oracle(eng, cfg, a, B, phase2, batch, rank, engine_config=None, eZ=None):
     """One dropout-off step of the BENCHED dtype / config / batch on the GPU (an engine of the same shape with dropout 0 that shares the
     timed engine's current parameters) against the CPU oracle's forward + losses on the same inputs and parameters."""
     import torch
     from bltvqg_amd.engine import StepEngine, make_config
     from oracle import iq_oracle as O
     dev = eng.device
-    c = make_config(B, cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"], cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"],
-                    cfg["vocab_size"], dtype=1 if a.dtype == "bf16" else 0, attention_dropout=0.0, relu_dropout=0.0,
-                    num_regions=cfg.get("num_regions", 0), region_dim=cfg.get("region_dim", 0))
+    c = engine_config(1 if a.dtype == "bf16" else 0, attention_dropout=0.0, relu_dropout=0.0)
     e0 = StepEngine(c, dev)
     e0.allocate(share_from=eng)
     ns = oracle_namespace(cfg)
@@ -276,20 +282,47 @@ def main():
     cfg = dict(CONFIGS[a.config])
     B = a.batch or cfg.pop("batch")
     cfg.pop("batch", None)
-    c = make_config(B, cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"], cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"],
-                    cfg["vocab_size"], dtype=1 if a.dtype == "bf16" else 0, num_regions=cfg.get("num_regions", 0),
-                    region_dim=cfg.get("region_dim", 0))
+    len_context = cfg.get("len_context", 5)
+    # widths the kernels do not tile directly (the reference's default 300 = 4 heads of 75) run on the padded layout: the engine gets the
+    # padded widths + the true head width, the pad positions of every parameter are zero and stay zero (blt-vqg_amd/padded.py)
+    from bltvqg_amd.padded import PaddedLayout, needs_padding
+    pad = PaddedLayout(cfg["hidden_dim"], cfg["latent_dim"], cfg["pwffn_dim"], cfg["num_heads"]) \
+        if needs_padding(cfg["hidden_dim"], cfg["latent_dim"], cfg["pwffn_dim"], cfg["num_heads"]) else None
+    eH, eF, eZ = (pad.Hp, pad.Fp, pad.Zp) if pad else (cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"])
+
+    def engine_config(dtype, **kw):
+        return make_config(B, eH, eF, eZ, cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"], cfg["vocab_size"], len_context=len_context,
+                           dtype=dtype, num_regions=cfg.get("num_regions", 0), region_dim=cfg.get("region_dim", 0),
+                           head_dim_true=pad.dh if pad else 0, **kw)
+
+    def init_engine(e):
+        init_reference_style(e, seed=0)                    # same weights on every rank
+        if pad:                                            # zeros at the pad positions
+            for flat, infos in ((e.flat_train, e.train_info), (e.flat_frozen, e.frozen_info)):
+                _, index, _ = pad.build(infos)
+                keep = torch.zeros(flat.numel(), dtype=torch.bool, device=flat.device)
+                keep[index.to(flat.device)] = True
+                flat.mul_(keep)
+            e.params_changed()
+    c = engine_config(1 if a.dtype == "bf16" else 0)
     eng = StepEngine(c, dev)
     eng.allocate()
-    init_reference_style(eng, seed=0)                      # same weights on every rank
+    init_engine(eng)
     step = DataParallelStep(eng, dist, overlap_optimizer=True, bf16_wire=a.bf16_wire, comm_stream=a.comm_stream)
     batch = synthetic.make_batch(B, cfg["vocab_size"], cfg["latent_dim"], seed=shard_seed(1234, rank),
                                  image_hw=32 if cfg.get("num_regions") else 224)
     if cfg.get("num_regions"):
         batch["images"] = region_features(B, cfg["num_regions"], cfg["region_dim"], shard_seed(1234, rank))
+    if len_context == 3:      # --input_mode cat (train_iq.py:72-75): the context is [<start>, category, <end>]
+        batch["answers"] = batch["answer_types_for_input"]
     keys = ("images", "answers", "posteriors", "questions")
     d = {k: batch[k].to(dev) for k in keys}
     gen = torch.Generator(device=dev).manual_seed(99 + rank)
+
+    def draw_eps():
+        """Latent noise [B, engine latent width]: N(0, 1) in the real columns, zeros in the pad columns of a padded layout."""
+        e_ = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen)
+        return e_ if eZ == cfg["latent_dim"] else torch.nn.functional.pad(e_, (0, eZ - cfg["latent_dim"]))
 
     # The conv stack runs one batch ahead on the step's FOURTH stream: the command processor runs at most four queues truly side by side
     # (profiles/r03_queues_exp.py: a fifth stream's kernels are time-sliced even with GPU_MAX_HW_QUEUES=8) and the step already uses the
@@ -335,7 +368,7 @@ def main():
         if feed["kind"] == kind:
             return
         while use_prefetch and eng.prefetch_pending():
-            eps0 = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+            eps0 = draw_eps() if phase2 else None
             step.run(None, d["answers"], d["posteriors"], d["questions"], eps0, phase2, seed=998, kl_weight=HP["kl_weight"], lr=HP["lr"],
                      max_norm=HP["max_norm"])
         feed["kind"] = kind
@@ -344,7 +377,7 @@ def main():
             upload(first % 2)
 
     def one_step(i, phase2, h2d=False):
-        eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+        eps = draw_eps() if phase2 else None
         switch_feed("h2d" if h2d else "resident", phase2, i)
         if h2d:
             slot = i % 2
@@ -446,7 +479,7 @@ def main():
         switch_feed("resident", phase2, 0)
         tc, tch = [], []
         for i in range(10):
-            eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+            eps = draw_eps() if phase2 else None
             if eng.prefetch_pending() == 0:
                 eng.prefetch_images(d["images"])
             torch.cuda.synchronize()
@@ -487,15 +520,14 @@ def main():
                                                       "all-reduce (communication stream); 0 = the exchange finished under backward"}
     if world == 1 and a.f32_steps > 0 and not a.no_extras and a.dtype == "bf16":
         # reference-precision leg: the SAME step on the fp32 engine (fp32 storage, exact-fp32 MFMA) — the engine that meets the 1e-3 parity bar
-        c32 = make_config(B, cfg["hidden_dim"], cfg["pwffn_dim"], cfg["latent_dim"], cfg["emb_dim"], cfg["num_layers"], cfg["num_heads"],
-                          cfg["vocab_size"], dtype=0, num_regions=cfg.get("num_regions", 0), region_dim=cfg.get("region_dim", 0))
+        c32 = engine_config(0)
         e32 = StepEngine(c32, dev)
         e32.allocate()
-        init_reference_style(e32, seed=0)
+        init_engine(e32)
         s32 = DataParallelStep(e32, None, overlap_optimizer=True)
 
         def step32(i):
-            eps = torch.randn(B, cfg["latent_dim"], device=dev, generator=gen) if phase2 else None
+            eps = draw_eps() if phase2 else None
             s32.run(d["images"], d["answers"], d["posteriors"], d["questions"], eps, phase2, seed=1000 + i, kl_weight=HP["kl_weight"],
                     lr=HP["lr"], max_norm=HP["max_norm"], next_images=d["images"] if use_prefetch else None)
         for i in range(3):
@@ -638,7 +670,9 @@ def main():
             out["dist"] = comm
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, phase2, a.cpu_batch, a.cpu_steps)
-            out["loss_vs_oracle"] = loss_vs_oracle(eng, cfg, a, B, phase2, batch, rank)
+            out["loss_vs_oracle"] = loss_vs_oracle(eng, cfg, a, B, phase2, batch, rank, engine_config) if pad is None else {
+                "skipped": "padded engine layout (parameters live at padded positions): this configuration is held to the oracle by "
+                           "tests/test_fullsize_gpu.py::test_reference_cli_defaults_at_their_own_depth_and_batch"}
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)

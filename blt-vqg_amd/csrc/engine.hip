@@ -60,6 +60,10 @@ struct Stack {
     // only row 0 of every sample of this stack's output is read (the posterior encoder: encoder_transformer.py:35 takes
     // response_encoder_outputs[:, 0]): everything behind the TOP layer's attention core is row-wise, so it runs on those B rows only
     bool row0 = false;
+    // ... its backward writes B strided rows of d(attention context) and d(sub-layer output) into buffers of their own whose other rows
+    // are zero from the bind-time memset and are never written by anything else (the attention core and the first LayerNorm's backward
+    // read ALL rows; the all-rows A/B form, debug key 23 bit 1, uses the ordinary buffers): no per-step memset.
+    void *gA_top = nullptr, *dx1_top = nullptr;
     const int* key_ids = nullptr;
     void* x_in = nullptr;
     float* stat_in = nullptr;   // row statistics of x_in (the embedding GEMM's epilogue; rows_add_stat for the decoder's row 0)
@@ -666,6 +670,7 @@ struct bltvqg_engine {
             }
             s.out = AT((int64_t)s.M * H);
             s.mF = AF(s.M); s.rF = AF(s.M);
+            if (s.row0) { s.gA_top = AT((int64_t)s.M * H); s.dx1_top = AT((int64_t)s.M * H); }
         };
         lay_stack(enc); lay_stack(renc); lay_stack(dec);
         if (fold_ok) {      // one contiguous pool: a single memset per forward
@@ -1560,14 +1565,10 @@ struct bltvqg_engine {
             const std::string a1 = lp + (st.dec ? "multi_head_attention_dec." : "multi_head_attention.");
             const std::string ln1 = lp + (st.dec ? "layer_norm_mha_dec" : "layer_norm_mha");
             const Rows rw = rows_of(st, l);
-            if (rw.sub) {
-                // row-0-only top layer: its row-wise backward touches B strided rows; the attention core below and the residual gradient of
-                // the first LayerNorm's backward read ALL rows, whose gradient is zero everywhere else
-                if (hipMemsetAsync(y.dx1, 0, (size_t)M * H * es, s) != hipSuccess || hipMemsetAsync(gA, 0, (size_t)M * H * es, s) != hipSuccess) {
-                    blt_set_error("backward: memset failed");
-                    return BLT_ERR_HIP;
-                }
-            }
+            // row-0-only top layer: its row-wise backward touches B strided rows of d(sub-layer output) / d(attention context); the attention
+            // core below and the residual term of the first LayerNorm's backward read ALL rows, zero everywhere else (Stack::gA_top)
+            void* dx1 = rw.sub ? st.dx1_top : y.dx1;
+            void* gAo = rw.sub ? st.gA_top : gA;      // d(self-attention context)
             if (st.dec) {
                 RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn3, y.x1b, y.m3, y.r3, lp + "layer_norm_ffn", y, cur, y.dx1, rw, st.scr, s));
                 cur = y.dx1;
@@ -1592,13 +1593,13 @@ struct bltvqg_engine {
                 RC(wgrad_later(y.gQ, H, y.xn2, H, a2 + "query_linear.weight", nullptr, M, s));
                 cur = y.dx2;
             } else {
-                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, cur, y.dx1, rw, st.scr, s));
-                cur = y.dx1;
+                RC(ffn_bwd(lp + "positionwise_feed_forward.", y.xn2, y.x1, y.m2, y.r2, lp + "layer_norm_ffn", y, cur, dx1, rw, st.scr, s));
+                cur = dx1;
             }
             // self attention: output projection over the rows of `rw`, the attention core and the q|k|v projection over all rows
             RC(wgrad_later(cur, rw.ldH, y.ctx, rw.ldH, a1 + "output_linear.weight", nullptr, rw.M, s));
-            RC(gemm(dt, dgrad(cur, rw.ldH, a1 + "output_linear.weight", gA, rw.ldH, rw.M), s));
-            RC(attn_bwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, gA, y.gQKV, 3 * H,
+            RC(gemm(dt, dgrad(cur, rw.ldH, a1 + "output_linear.weight", gAo, rw.ldH, rw.M), s));
+            RC(attn_bwd(y.qkv, 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, gAo, y.gQKV, 3 * H,
                         (char*)y.gQKV + (size_t)H * es, (char*)y.gQKV + (size_t)2 * H * es, 3 * H, st.key_ids, S, S, st.dec ? 1 : 0, sid(st.id, l, 0), s));
             RC(gemm(dt, dgrad_rows(y.gQKV, 3 * H, a1 + "query_linear.weight", 3 * H, gB, H, M), s));
             // the last sub-layer of the stack writes d(stack input) back into the caller's buffer (its old content is dead by now:

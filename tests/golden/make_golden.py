@@ -109,7 +109,7 @@ def build_reference(cfg):
     return model
 
 
-def run_reference(model, state, batch, phase2, hp, kliter):
+def run_reference(model, state, batch, phase2, hp, kliter, context_key="answers"):
     """One reference forward + loss (train_iq.py:81-103 formulas with torch's own criteria) + backward."""
     import models.transformer_layers as TL
     missing = model.load_state_dict(state, strict=False)
@@ -121,7 +121,8 @@ def run_reference(model, state, batch, phase2, hp, kliter):
     real_randn = torch.randn
     TL.torch.randn = lambda *a, **k: eps.clone()     # inject eps at transformer_layers.py:45
     try:
-        output, z_logit, kld, (feats, recon) = model(batch["images"], batch["answers"], batch["posteriors"], batch["questions"])
+        # (TrainIQ.forward, train_iq.py:72-75: the context is `answers`, or `answer_types_for_input` under --input_mode cat)
+        output, z_logit, kld, (feats, recon) = model(batch["images"], batch[context_key], batch["posteriors"], batch["questions"])
     finally:
         TL.torch.randn = real_randn
     target = batch["questions"]
@@ -163,6 +164,15 @@ CONFIGS = {
                                        vocab_size=211), B=4, hw=64, seed=15, full=False, decode=True, keep=(
         "decoder.output.bias", "embedding.1.bias", "decoder.decoder.dec.0.multi_head_attention_dec.query_linear.weight",
         "answer_encoder.encoder.enc.0.layer_norm_mha.weight", "latent_layer.mean_logvar_posterior.0.weight", "encoder_cnn.bn.weight")),
+    # ref300l4: the reference's CLI defaults at their own DEPTH too (train_iq.py:315-325: 4 layers of hidden 300 / FFN 600 / 4 heads)
+    "ref300l4": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=300, latent_dim=300, pwffn_dim=600, num_layers=4, num_heads=4,
+                                         vocab_size=211), B=4, hw=64, seed=17, full=False, keep=(
+        "decoder.output.bias", "embedding.1.bias", "decoder.decoder.dec.3.multi_head_attention_enc_dec.query_linear.weight",
+        "answer_encoder.r_encoder.enc.0.layer_norm_mha.weight", "latent_layer.mean_logvar_prior.0.weight")),
+    # runsh: the one launch the reference documents (run.sh:1-10): hidden 1024 / latent 1024 / FFN 2048, 6 layers, 8 heads of 128,
+    # --input_mode cat (the 3-token [<start>, category, <end>] context), at B=4, 224x224: summaries only
+    "runsh": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=1024, latent_dim=1024, pwffn_dim=2048, num_layers=6, num_heads=8,
+                                      vocab_size=8000), B=4, hw=224, seed=16, full=False, context="answer_types_for_input"),
     # small = BASELINE.json configs[0] model (2-layer, d_model 256) at B=8, 224x224: summaries only
     "small": dict(cfg=SimpleNamespace(emb_dim=300, hidden_dim=256, latent_dim=256, pwffn_dim=512, num_layers=2, num_heads=4,
                                       vocab_size=8000), B=8, hw=224, seed=13, full=False),
@@ -198,11 +208,12 @@ def main():
             full_state[k] = state[base]
         assert set(spec.keys()) <= set(full_state.keys()), set(spec.keys()) - set(full_state.keys())
         out = {"meta_cfg": np.array([cfg.emb_dim, cfg.hidden_dim, cfg.latent_dim, cfg.pwffn_dim, cfg.num_layers,
-                                     cfg.num_heads, cfg.vocab_size, c["B"], c["hw"], c["seed"]], dtype=np.int64)}
+                                     cfg.num_heads, cfg.vocab_size, c["B"], c["hw"], c["seed"]], dtype=np.int64),
+               "meta_cat": np.array(1 if c.get("context") else 0, dtype=np.int64)}
         for phase2 in (False, True):
             tag = "p2" if phase2 else "p1"
             kliter = 5000 if phase2 else 0
-            res = run_reference(model, full_state, batch, phase2, hp, kliter)
+            res = run_reference(model, full_state, batch, phase2, hp, kliter, c.get("context", "answers"))
             out[tag + ".kliter"] = np.array(kliter)
             for k in ("loss", "loss_rec", "loss_img", "kld", "loss_aux"):
                 if k in res:

@@ -20,6 +20,10 @@ def load_golden(name):
     B, hw, seed = int(m[7]), int(m[8]), int(m[9])
     state = synth_state(O.iq_spec(cfg), seed=seed)
     batch = synthetic.make_batch(B, cfg.vocab_size, cfg.latent_dim, seed=seed, image_hw=hw)
+    # the context the fixture was produced with: `answers`, or `answer_types_for_input` for --input_mode cat fixtures (train_iq.py:72-75)
+    cat = "meta_cat" in z.files and int(z["meta_cat"]) == 1
+    batch["context"] = batch["answer_types_for_input"] if cat else batch["answers"]
+    cfg.input_mode = "cat" if cat else "ans"
     return z, cfg, state, batch
 
 
@@ -29,7 +33,7 @@ def oracle_run(cfg, state, batch, phase2, kliter=0, hp=None, masks=None, p_drop=
     P = O.clone_params(state)
     bufs = {}
     out, z_logit, kld, (feats, recon), extras = O.iq_forward(
-        P, cfg, batch["images"], batch["answers"], batch["posteriors"], batch["questions"], phase2,
+        P, cfg, batch["images"], batch.get("context", batch["answers"]), batch["posteriors"], batch["questions"], phase2,
         batch["eps"], masks, p_drop, True, bufs)
     loss, stats = O.calculate_losses(out, (feats, recon), kld, z_logit, batch["questions"], phase2, kliter, hp)
     loss.backward()

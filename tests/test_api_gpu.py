@@ -318,13 +318,15 @@ def test_fused_step_then_torch_optimizer_never_reads_a_stale_weight_shadow():
     assert float((got - output.detach()).abs().max()) > 1e-3      # and the torch step really moved the model
 
 
+@pytest.mark.parametrize("fixture", ["ref300", "ref300l4"])
 @pytest.mark.parametrize("phase2", [False, True])
-def test_reference_default_widths_match_the_reference(phase2):
+def test_reference_default_widths_match_the_reference(phase2, fixture):
     """The reference's CLI default widths (train_iq.py:315-325: hidden 300 = 4 heads of 75, latent 300, FFN 600) through the padded engine
-    layout (blt-vqg_amd/padded.py), fp32 engine, against the fixture the reference itself produced (tests/golden/make_golden.py ref300):
-    loss within 1e-3 (north_star), argmax token ids bit-exact, gradients of the reference-shaped parameters <= 3e-3."""
+    layout (blt-vqg_amd/padded.py), fp32 engine, against the fixtures the reference itself produced (tests/golden/make_golden.py ref300: one
+    layer; ref300l4: the CLI's own depth, 4 layers): loss within 1e-3 (north_star), argmax token ids bit-exact, gradients of the
+    reference-shaped parameters <= 3e-3."""
     from train_iq import SyntheticVocabulary, TrainIQ
-    z, cfg, state, batch = load_golden("ref300")
+    z, cfg, state, batch = load_golden(fixture)
     assert (cfg.hidden_dim, cfg.latent_dim, cfg.pwffn_dim, cfg.num_heads) == (300, 300, 600, 4)
     tag = "p2" if phase2 else "p1"
     t = TrainIQ(SyntheticVocabulary(cfg.vocab_size), _args(cfg))

@@ -14,8 +14,10 @@ pytestmark = pytest.mark.gpu
 
 def _engine(cfg, B, hw, dtype, p_attn=0.0, p_relu=0.0):
     from bltvqg_amd.engine import StepEngine, make_config
+    # --input_mode cat fixtures (run.sh): the context is the 3-token [<start>, category, <end>] row (train_iq.py:72-75)
+    len_context = 3 if getattr(cfg, "input_mode", "ans") == "cat" else 5
     c = make_config(B, cfg.hidden_dim, cfg.pwffn_dim, cfg.latent_dim, cfg.emb_dim, cfg.num_layers, cfg.num_heads, cfg.vocab_size,
-                    image_hw=(hw, hw), dtype=dtype, attention_dropout=p_attn, relu_dropout=p_relu)
+                    len_context=len_context, image_hw=(hw, hw), dtype=dtype, attention_dropout=p_attn, relu_dropout=p_relu)
     e = StepEngine(c)
     e.allocate()
     return e
@@ -23,7 +25,7 @@ def _engine(cfg, B, hw, dtype, p_attn=0.0, p_relu=0.0):
 
 def _run(e, batch, phase2, kl_w, seed=0):
     dev = "cuda"
-    e.forward(batch["images"].to(dev), batch["answers"].to(dev), batch["posteriors"].to(dev), batch["questions"].to(dev),
+    e.forward(batch["images"].to(dev), batch.get("context", batch["answers"]).to(dev), batch["posteriors"].to(dev), batch["questions"].to(dev),
               batch["eps"].to(dev) if phase2 else None, phase2, seed)
     out = dict(output=e.read(0).cpu(), feats=e.read(2).cpu(), recon=e.read(3).cpu())
     if phase2:
@@ -134,10 +136,11 @@ def test_engine_bf16_within_stated_tolerance(name, phase2):
     assert worst[0] < 0.35, worst
 
 
-@pytest.mark.parametrize("name", ["small", "big"])
+@pytest.mark.parametrize("name", ["small", "big", "runsh"])
 def test_engine_small_cfg_fp32_matches_reference_golden(name):
-    """BASELINE.json configs[0..1] model (2-layer, d_model 256, 224x224 images, V=8000) at B=8 and configs[2..3] model (6-layer,
-    d_model 512, 8 heads, F 2048) at B=4: summary fixtures produced by the reference."""
+    """BASELINE.json configs[0..1] model (2-layer, d_model 256, 224x224 images, V=8000) at B=8, configs[2..3] model (6-layer,
+    d_model 512, 8 heads, F 2048) at B=4, and the launch the reference documents (run.sh:1-10: hidden / latent 1024, FFN 2048, 6 layers,
+    8 heads of 128, --input_mode cat) at B=4: summary fixtures produced by the reference."""
     from oracle import iq_oracle as O
     z, cfg, state, batch = load_golden(name)
     B, hw = int(z["meta_cfg"][7]), int(z["meta_cfg"][8])
@@ -164,7 +167,7 @@ def test_engine_small_cfg_fp32_matches_reference_golden(name):
             assert abs(got - g) <= 3e-3 * max(g, 1e-6) + 1e-6, (n, got, g)
 
 
-@pytest.mark.parametrize("name", ["small", "big"])
+@pytest.mark.parametrize("name", ["small", "big", "runsh"])
 def test_engine_small_cfg_bf16_within_stated_tolerance(name):
     """bf16 engine on the 224x224 fixtures: loss within 2 % (relative) of the reference, sampled logits within 5 %."""
     from oracle import iq_oracle as O

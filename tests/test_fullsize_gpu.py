@@ -20,6 +20,8 @@ SHAPES = {
     "small": dict(B=128, H=256, F=512, Z=256, E=300, L=2, NH=4, V=8000, hw=224, regions=0),
     "big": dict(B=256, H=512, F=2048, Z=512, E=300, L=6, NH=8, V=8000, hw=224, regions=0),
     "regions": dict(B=64, H=512, F=2048, Z=512, E=300, L=6, NH=8, V=8000, hw=32, regions=36),
+    # the one launch the reference documents (run.sh:1-10): hidden / latent 1024, FFN 2048, 6 layers, 8 heads of 128, batch 64, --input_mode cat
+    "runsh": dict(B=64, H=1024, F=2048, Z=1024, E=300, L=6, NH=8, V=8000, hw=224, regions=0, cat=True),
 }
 GRAD_NAMES = ["decoder.output.weight", "decoder.decoder.dec.0.multi_head_attention_dec.query_linear.weight",
               "decoder.decoder.dec.0.multi_head_attention_enc_dec.key_linear.weight", "decoder.decoder.dec.0.positionwise_feed_forward.layers.0.weight",
@@ -42,6 +44,8 @@ def _case(name):
     if s["regions"]:
         g = torch.Generator().manual_seed(99)
         batch["images"] = torch.relu(torch.randn(s["B"], s["regions"], 2048, generator=g) + 0.3 * torch.randn(s["B"], 1, 2048, generator=g)).contiguous()
+    # --input_mode cat (train_iq.py:72-75): the context is the 3-token [<start>, category, <end>] row
+    batch["context"] = batch["answer_types_for_input"] if s.get("cat") else batch["answers"]
     return s, cfg, state, batch
 
 
@@ -51,7 +55,7 @@ def _oracle_step(cfg, state, batch, kliter):
     torch.set_num_threads(min(16, torch.get_num_threads() if torch.get_num_threads() > 0 else 16))
     t0 = time.time()
     P = O.clone_params(state)
-    out, z_logit, kld, recon, _ = O.iq_forward(P, cfg, batch["images"], batch["answers"], batch["posteriors"], batch["questions"], True,
+    out, z_logit, kld, recon, _ = O.iq_forward(P, cfg, batch["images"], batch["context"], batch["posteriors"], batch["questions"], True,
                                                batch["eps"], None, 0.0, True, {})
     loss, st = O.calculate_losses(out, recon, kld, z_logit, batch["questions"], True, kliter, O.default_hp())
     loss.backward()
@@ -62,13 +66,13 @@ def _oracle_step(cfg, state, batch, kliter):
 
 def _engine_step(s, cfg, state, batch, dtype, kl_w):
     from bltvqg_amd.engine import StepEngine, make_config
-    c = make_config(s["B"], s["H"], s["F"], s["Z"], s["E"], s["L"], s["NH"], s["V"], image_hw=(s["hw"], s["hw"]), dtype=dtype, attention_dropout=0.0,
-                    relu_dropout=0.0, num_regions=s["regions"], region_dim=2048 if s["regions"] else 0)
+    c = make_config(s["B"], s["H"], s["F"], s["Z"], s["E"], s["L"], s["NH"], s["V"], len_context=3 if s.get("cat") else 5, image_hw=(s["hw"], s["hw"]),
+                    dtype=dtype, attention_dropout=0.0, relu_dropout=0.0, num_regions=s["regions"], region_dim=2048 if s["regions"] else 0)
     e = StepEngine(c)
     e.allocate()
     e.load_state(state)
-    d = {k: batch[k].cuda() for k in ("images", "answers", "posteriors", "questions", "eps")}
-    e.forward(d["images"], d["answers"], d["posteriors"], d["questions"], d["eps"], True, 0)
+    d = {k: batch[k].cuda() for k in ("images", "context", "posteriors", "questions", "eps")}
+    e.forward(d["images"], d["context"], d["posteriors"], d["questions"], d["eps"], True, 0)
     out = e.read(0).cpu()
     e.loss_backward(kl_w)
     st = e.stats()
@@ -78,7 +82,7 @@ def _engine_step(s, cfg, state, batch, dtype, kl_w):
     return out, total, st, gn
 
 
-@pytest.mark.parametrize("name", ["small", "big", "regions"])
+@pytest.mark.parametrize("name", ["small", "big", "regions", "runsh"])
 def test_full_size_step_matches_one_oracle_step(name):
     from oracle import iq_oracle as O
     s, cfg, state, batch = _case(name)
@@ -114,3 +118,68 @@ def test_full_size_step_matches_one_oracle_step(name):
     assert abs(total - ref_loss) < 2e-3 * abs(ref_loss)
     assert err < 4e-2
     assert worst < 0.02
+
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_reference_cli_defaults_at_their_own_depth_and_batch(precision):
+    """The reference's CLI defaults as a user launches them (train_iq.py:315-339: hidden 300 = 4 heads of 75, latent 300, FFN 600, 4 layers,
+    batch 128, 224x224) through `TrainIQ` on the padded engine layout (blt-vqg_amd/padded.py) against ONE oracle step on the same inputs:
+    fp32 engine: loss 1e-3, argmax bit-exact on every clear row, gradient norms 3e-3; bf16 engine: loss 0.2 %, sampled logits 4 %,
+    gradient norms 2 %."""
+    from types import SimpleNamespace
+    import bltvqg_amd.synthetic as synthetic
+    from synth import synth_state
+    from oracle import iq_oracle as O
+    from train_iq import SyntheticVocabulary, TrainIQ
+    B, V = 128, 8000
+    cfg = SimpleNamespace(emb_dim=300, hidden_dim=300, latent_dim=300, pwffn_dim=600, num_layers=4, num_heads=4, vocab_size=V)
+    state = synth_state(O.iq_spec(cfg), seed=21)
+    batch = synthetic.make_batch(B, V, 300, seed=77, image_hw=224)
+    batch["context"] = batch["answers"]
+    kliter = 6000
+    ref_out, ref_loss, ref_st, ref_gn = _oracle_step(cfg, state, batch, kliter)
+    flat_ref = ref_out.reshape(-1, V)
+    top2 = flat_ref.topk(2, dim=-1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-4
+    idx = torch.randint(0, flat_ref.numel(), (4096,), generator=torch.Generator().manual_seed(1))
+    args = SimpleNamespace(emb_dim=300, hidden_dim=300, latent_dim=300, pwffn_dim=600, num_layers=4, num_heads=4, lr=3e-5,
+                           num_pretraining_steps=0, full_kl_step=15000, kl_ceiling=0.5, aux_ceiling=1.0, image_recon_lambda=0.1, batch_size=B,
+                           emb_file=None, root_dir=".", device=torch.device("cuda"), input_mode="ans", print_note="", precision=precision,
+                           attention_dropout=0.0, relu_dropout=0.0)
+    t = TrainIQ(SyntheticVocabulary(V), args)
+    full = dict(state)
+    for k in t.model.state_dict().keys():      # aliases of the shared embedding / latent layer
+        base = k
+        for alias in ("answer_encoder.embedding.", "decoder.embedding."):
+            if k.startswith(alias):
+                base = "embedding." + k[len(alias):]
+        if k.startswith("answer_encoder.latent_layer."):
+            base = k[len("answer_encoder."):]
+        full[k] = state[base]
+    t.model.load_state_dict(full)
+    t = t.to("cuda")
+    t.latent_transformer = True
+    t.model.switch_GVT_train_mode(True)
+    t.kliter = kliter
+    b = {k: v.cuda() for k, v in batch.items()}
+    output, z_logit, kld, recon = t(b)
+    loss = t.calculate_losses(output, recon, kld, z_logit, b["questions"])[0]
+    loss.backward()
+    out = output.detach().cpu()
+    total = float(loss)
+    gn = {n: float(t.model.get_parameter(n).grad.double().norm()) for n in ref_gn}
+    err = rel_err(out.reshape(-1)[idx], ref_out.reshape(-1)[idx])
+    worst = max(abs(gn[n] - g) / max(g, 1e-9) for n, g in ref_gn.items() if g > 1e-6)
+    agree = float((out.reshape(-1, V).argmax(-1)[clear] == flat_ref.argmax(-1)[clear]).float().mean())
+    print("default300 %s: loss %.6f vs oracle %.6f, sampled logits rel %.5f, argmax agreement %.5f, worst gradient-norm rel %.5f" % (
+        precision, total, ref_loss, err, agree, worst))
+    if precision == "fp32":
+        assert abs(total - ref_loss) < 1e-3
+        assert err < 3e-4
+        assert agree == 1.0
+        assert worst < 3e-3
+    else:
+        assert abs(total - ref_loss) < 2e-3 * abs(ref_loss)
+        assert err < 4e-2
+        assert worst < 0.02

@@ -53,7 +53,7 @@ def test_bn_running_stats_match_reference():
     assert n > 50
 
 
-@pytest.mark.parametrize("name", ["small", "big", "ref300"])
+@pytest.mark.parametrize("name", ["small", "big", "ref300", "ref300l4", "runsh"])
 @pytest.mark.parametrize("phase2", [False, True])
 def test_oracle_matches_reference_small_cfg(name, phase2):
     """BASELINE.json configs[0..1] model (2-layer d_model 256, 224x224 images) at B=8, configs[2..3] model (6-layer d_model 512,

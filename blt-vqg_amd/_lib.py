@@ -48,11 +48,7 @@ SIGNATURES = {
     "bltvqg_ln_fold_prepare": (I, [P, I, I, P, P, P, P, P, P, P]),
     "bltvqg_linear_ln_folded": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, P, P, F, I, F, U64, U32, I, I, P]),
     "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
-    "bltvqg_gemm_repeat": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P]),
-    "bltvqg_gemm_rotate": (I, [I, P, I, I, L, P, I, I, L, P, I, I, L, I, I, I, I, I, P]),
     "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
-    "bltvqg_layernorm_linear": (I, [P, I, P, P, F, P, P, P, P, I, P, I, F, U64, U32, P, I, P, I, I, I, I, P]),
-    "bltvqg_linear_layernorm": (I, [P, I, P, I, P, I, F, U64, U32, P, I, P, I, P, I, P, P, F, P, P, P, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
     "bltvqg_conv2d_stat_rows": (I, [I, I, I, I, I, I, I, I]),
     "bltvqg_pp_pixels": (L, [I, I, I]),
@@ -83,7 +79,6 @@ SIGNATURES = {
     "bltvqg_bn1d_fwd": (I, [I, P, P, P, P, P, P, P, P, I, I, F, F, P]),
     "bltvqg_bn1d_bwd": (I, [I, P, P, P, P, P, P, P, P, I, I, P]),
     "bltvqg_attn_fwd": (I, [I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
-    "bltvqg_attn_out_fwd": (I, [P, I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
     "bltvqg_attn_bwd": (I, [I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
     "bltvqg_embed_gather": (I, [I, P, P, P, L, I, I, P]),
     "bltvqg_embed_scatter": (I, [I, P, I, P, P, L, I, I, P]),
@@ -95,7 +90,6 @@ SIGNATURES = {
     "bltvqg_sumsq": (I, [P, L, P, P]),
     "bltvqg_adam_step": (I, [P, P, P, P, L, P, F, F, F, F, F, I, P]),
     "bltvqg_dropout_mask": (I, [U64, U32, L, I, I, F, P, P]),
-    "bltvqg_hw_id_probe": (I, [P, I, I, P]),
     "bltvqg_cast": (I, [I, P, I, I, P, I, L, I, P]),
     "bltvqg_image_store_u8": (I, [P, P, L, P]),
     "bltvqg_batch_rows": (I, [P, P, P, P, I, L, P, I, I, I, P, P, P, P, P, P]),
@@ -147,6 +141,39 @@ SIGNATURES = {
     "bltvqg_engine_bucket_info": (I, [P, I, ctypes.POINTER(L), ctypes.POINTER(L), ctypes.POINTER(ctypes.c_int32)]),
     "bltvqg_engine_bucket_wait": (I, [P, I, P]),
 }
+
+# include/bltvqg_hip_experiments.h: entry points that exist only in the experiments build (make -C blt-vqg_amd/csrc experiments ->
+# libbltvqg_hip_exp.so, -DBLT_EXPERIMENTS).  Never loaded by the product; tests load it NEXT TO the product library (load_experiments()).
+EXPERIMENT_SIGNATURES = {
+    "bltvqg_gemm_repeat": (I, [I, P, I, P, I, P, I, I, I, I, P, I, P, I, I, P]),
+    "bltvqg_gemm_rotate": (I, [I, P, I, I, L, P, I, I, L, P, I, I, L, I, I, I, I, I, P]),
+    "bltvqg_layernorm_linear": (I, [P, I, P, P, F, P, P, P, P, I, P, I, F, U64, U32, P, I, P, I, I, I, I, P]),
+    "bltvqg_linear_layernorm": (I, [P, I, P, I, P, I, F, U64, U32, P, I, P, I, P, I, P, P, F, P, P, P, I, I, I, P]),
+    "bltvqg_attn_out_fwd": (I, [P, I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
+    "bltvqg_hw_id_probe": (I, [P, I, I, P]),
+}
+EXP_LIB_PATH = os.environ.get("BLTVQG_EXP_LIB") or os.path.join(_HERE, "libbltvqg_hip_exp.so")
+_exp_lib = None
+
+
+def load_experiments():
+    """The experiments build as a SECOND library in this process (its own copy of the kernels and of the process-wide switches), or None
+    when it has not been built.  It carries every product entry point too, so an operator test can run wholly inside it."""
+    global _exp_lib
+    if _exp_lib is not None:
+        return _exp_lib
+    if not os.path.exists(EXP_LIB_PATH):
+        return None
+    import torch  # noqa: F401  (one HIP runtime per process: torch's, see load())
+    lib = ctypes.CDLL(EXP_LIB_PATH)
+    for table in (SIGNATURES, EXPERIMENT_SIGNATURES):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+    _exp_lib = lib
+    return lib
+
 
 _lib = None
 

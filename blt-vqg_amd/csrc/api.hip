@@ -2,6 +2,9 @@
 #include <vector>
 #include "kernels.h"
 #include "../../include/bltvqg_hip.h"
+#ifdef BLT_EXPERIMENTS
+#include "../../include/bltvqg_hip_experiments.h"
+#endif
 
 static inline int ilog2i(int x) { int l = 0; while ((1 << l) < x) ++l; return l; }
 
@@ -113,6 +116,7 @@ int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, 
     return blt_wgrad_group_launch((const blt_wg_problem*)table_dev, (const int*)((char*)table_dev + pb_al), n, nwg, bm, (hipStream_t)stream);
 }
 
+#ifdef BLT_EXPERIMENTS
 int bltvqg_gemm_repeat(int dtype, const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias, int relu,
                        const void* R, int ldr, int reps, void* stream) {
     GemmArgs g;
@@ -123,7 +127,9 @@ int bltvqg_gemm_repeat(int dtype, const void* A, int lda, const void* B, int ldb
     }
     return BLT_OK;
 }
+#endif
 
+#ifdef BLT_EXPERIMENTS
 int bltvqg_gemm_rotate(int dtype, const void* A, int lda, int a_copies, int64_t a_stride_bytes, const void* B, int ldb, int b_copies,
                        int64_t b_stride_bytes, void* C, int ldc, int c_copies, int64_t c_stride_bytes, int M, int N, int K, int chain, int reps,
                        void* stream) {
@@ -144,6 +150,7 @@ int bltvqg_gemm_rotate(int dtype, const void* A, int lda, int a_copies, int64_t 
     }
     return BLT_OK;
 }
+#endif
 
 int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int ldx, float* dW, int ldw, float* dbias, int rows, int N, int K,
                         int split_k, void* stream) {
@@ -154,6 +161,7 @@ int bltvqg_linear_wgrad(int dtype, const void* dY, int ldy, const void* X, int l
     return blt_gemm(dtype, g, (hipStream_t)stream);
 }
 
+#ifdef BLT_EXPERIMENTS
 int bltvqg_linear_layernorm(const void* X, int ldx, const void* W, int ldw, const float* bias, int relu, float drop_p, uint64_t seed,
                             uint32_t stream_id, void* C2, int ldc2, const void* R, int ldr, void* C, int ldc, const float* ln_gamma,
                             const float* ln_beta, float ln_eps, void* ln_out, float* ln_mean, float* ln_rstd, int M, int N, int K, void* stream) {
@@ -164,7 +172,9 @@ int bltvqg_linear_layernorm(const void* X, int ldx, const void* W, int ldw, cons
     g.ln_gamma = ln_gamma; g.ln_beta = ln_beta; g.ln_eps = ln_eps; g.ln_out = ln_out; g.ln_mean = ln_mean; g.ln_rstd = ln_rstd;
     return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
 }
+#endif
 
+#ifdef BLT_EXPERIMENTS
 int bltvqg_layernorm_linear(const void* X, int ldx, const float* ln_gamma, const float* ln_beta, float ln_eps, void* Xn, float* ln_mean,
                             float* ln_rstd, const void* W, int ldw, const float* bias, int relu, float drop_p, uint64_t seed, uint32_t stream_id,
                             const void* R, int ldr, void* C, int ldc, int M, int N, int K, void* stream) {
@@ -175,6 +185,7 @@ int bltvqg_layernorm_linear(const void* X, int ldx, const float* ln_gamma, const
     g.lnA_gamma = ln_gamma; g.lnA_beta = ln_beta; g.lnA_eps = ln_eps; g.lnA_out = Xn; g.lnA_mean = ln_mean; g.lnA_rstd = ln_rstd;
     return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
 }
+#endif
 
 static GemmArgs conv_args(const void* x, const void* w, void* y, int N, int Hi, int Wi, int Cin, int Cout, int KH, int KW, int stride, int pad) {
     GemmArgs g;
@@ -338,6 +349,7 @@ int bltvqg_attn_fwd(int dtype, const void* Q, int ldq, const void* K, int ldk, c
     a.Tq = Tq; a.Tk = Tk; a.d = d; a.causal = causal; a.scale = scale; a.drop_p = drop_p; a.seed = seed; a.stream_id = stream_id;
     return blt_attn_fwd(dtype, a, (hipStream_t)stream);
 }
+#ifdef BLT_EXPERIMENTS
 int bltvqg_attn_out_fwd(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, const void* Wo, int ldwo,
                         const void* R, int ldr, void* Y, int ldy, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal,
                         float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream) {
@@ -348,6 +360,7 @@ int bltvqg_attn_out_fwd(const void* Q, int ldq, const void* K, int ldk, const vo
     BLT_REQUIRE(Y && Wo && ldy >= heads * d && (!R || ldr >= heads * d) && ldwo >= heads * d, "attn_out_fwd: bad output / weight operands");
     return blt_attn_out_fwd(BLT_BF16, a, (hipStream_t)stream);
 }
+#endif
 int bltvqg_attn_bwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo, void* dQ, int lddq,
                     void* dK, int lddk, void* dV, int lddv, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal, float scale,
                     float drop_p, uint64_t seed, uint32_t stream_id, void* stream) {
@@ -391,9 +404,11 @@ int bltvqg_adam_step(float* p, const float* g, float* m, float* v, int64_t n, co
 int bltvqg_dropout_mask(uint64_t seed, uint32_t stream_id, int64_t rows, int cols, int ld_index, float p, uint8_t* out, void* stream) {
     return blt_dropout_mask(seed, stream_id, (long)rows, cols, ld_index, p, out, (hipStream_t)stream);
 }
+#ifdef BLT_EXPERIMENTS
 int bltvqg_hw_id_probe(int32_t* out, int n_workgroups, int spin_ticks, void* stream) {
     return blt_hw_id_probe((int*)out, n_workgroups, spin_ticks, (hipStream_t)stream);
 }
+#endif
 int bltvqg_cast(int dtype_src, const void* src, int ld_src, int dtype_dst, void* dst, int ld_dst, int64_t rows, int cols, void* stream) {
     return blt_cast_rows(dtype_src, src, ld_src, dtype_dst, dst, ld_dst, (long)rows, cols, (hipStream_t)stream);
 }

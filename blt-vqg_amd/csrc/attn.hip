@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     }
 }
 
+#ifdef BLT_EXPERIMENTS      // (built, tested bit-identical, measured +0.27 ms per step, not adopted: DESIGN.md 5c.9)
 // ---------------------------------------------------------------------------------------------------------------
 // Attention + output projection + residual in one launch.  One workgroup per BATCH ELEMENT, wave h = head h: the attention part is the
 // one-wave kernel above; every wave then owns 64 output columns of Y = O Wo^T + R.  The A operand (the [Tq, H] context of this batch
@@ -549,6 +550,7 @@ __global__ __launch_bounds__(MAXT) void attn_out_fwd_kernel(const AttnArgs a) {
             }
         }
 }
+#endif      // BLT_EXPERIMENTS
 
 template <int D>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
@@ -753,6 +755,7 @@ int set_lds(K kern, size_t bytes, const char* what) {
 
 }  // namespace
 
+#ifdef BLT_EXPERIMENTS
 bool blt_attn_out_fwd_ok(int dtype, const AttnArgs& a) {
     return dtype == BLT_BF16 && a.d == 64 && a.heads >= 1 && a.heads <= 8 && a.Tq <= 32 && a.Tk <= 32 && mfma_ok(dtype, a, false) && a.Wo && a.Y &&
            a.ldwo % 8 == 0 && (((uintptr_t)a.Wo) & 15) == 0 && a.ldo >= a.heads * 64;
@@ -774,6 +777,7 @@ int blt_attn_out_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((attn_out_fwd_kernel<64, 512>), dim3((unsigned)a.B), dim3((unsigned)a.heads * 64), lds, s, a);
     return blt_check_launch("attn_out_fwd");
 }
+#endif
 
 int blt_attn_fwd(int dtype, const AttnArgs& a, hipStream_t s) {
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "attn_fwd: bad dtype");

@@ -720,6 +720,7 @@ extern "C" int bltvqg_debug_read_stamps(unsigned long long* host, int n) {
 }
 #endif
 
+#ifdef BLT_EXPERIMENTS      // (operators measured in the step and not adopted: include/bltvqg_hip_experiments.h)
 // ---------------------------------------------------------------------------------------------------------------
 // Linear (+ bias / ReLU / dropout / residual) with the FOLLOWING LayerNorm fused in: tile 32 rows x 256 columns, so that a workgroup
 // owns complete rows (N <= 256); the four waves sit side by side (each 32 x 64), same LDS-DMA ring as above (3 stages of 4 KB A +
@@ -1063,6 +1064,8 @@ int launch_dma_ln(const GemmArgs& a, hipStream_t stream) {
     return blt_check_launch("gemm_dma_ln");
 }
 
+#endif      // BLT_EXPERIMENTS
+
 template <int BM, int BN, int LOADER, int NST>
 int launch_dma(const GemmArgs& a, hipStream_t stream) {
     typedef DmaCfg<BM, BN, LOADER, NST> C;
@@ -1277,6 +1280,7 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
                 (!a.rowtab || ((uintptr_t)a.rowtab % 16) == 0), "gemm: epilogue operands must be 16-byte aligned");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
     BLT_REQUIRE(!a.a_rowsum || (a.transA && !a.is_conv), "gemm: a_rowsum needs the transA (weight-gradient) form");
+#ifdef BLT_EXPERIMENTS
     if (a.lnA_out != nullptr) {
         BLT_REQUIRE(dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv, "gemm: LayerNorm on A needs bf16 k-contiguous operands");
         BLT_REQUIRE(a.K <= 256 && a.K % 8 == 0 && a.lnA_gamma && a.lnA_beta && a.lnA_mean && a.lnA_rstd, "gemm: LayerNorm on A needs K <= 256, K %% 8 == 0 (K=%d)", a.K);
@@ -1291,6 +1295,9 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
                     ((uintptr_t)a.ln_gamma % 16) == 0 && ((uintptr_t)a.ln_beta % 16) == 0 && ((uintptr_t)a.ln_out % 16) == 0, "gemm: fused LayerNorm operands must be 16-byte aligned");
         return launch_dma_ln(a, stream);
     }
+#else
+    BLT_REQUIRE(a.lnA_out == nullptr && a.ln_out == nullptr, "gemm: the LayerNorm-in-GEMM experiments are not part of this build (make experiments)");
+#endif
     if ((!g_debug[8] || a.fold_s || a.out_stat) && !a.force_tile && !a.no_dma && blt_gemm_nt2_ok(dtype, a))
         return blt_gemm_nt2(a, stream, a.nt2_bm ? a.nt2_bm : g_debug[9], a.nt2_bm ? a.nt2_bn : g_debug[10]);
     BLT_REQUIRE(!a.fold_s && !a.out_stat, "gemm: the LayerNorm-fold / row-statistics epilogue needs the planned-tile bf16 NT kernel (bf16, k-contiguous "

@@ -678,8 +678,10 @@ const TileOpt kTiles[] = {
 #if NT2_LDS_CAP >= 160 * 1024      // (the co-residency experiment build caps a workgroup at 79 KB: two ring stages of <= 39 KB)
     NT2(160, 192, 2, 4), NT2(160, 256, 2, 4), NT2(192, 128, 2, 4), NT2(192, 192, 2, 4), NT2(192, 256, 2, 4),
     NT2(128, 256, 2, 4), NT2(256, 128, 4, 2),
+#endif
+#if NT2_LDS_CAP >= 160 * 1024 && defined(BLT_EXPERIMENTS)
     // one-round tile of the 2048-column problems when the chain runs on a 192-CU partition (engine_set_cu_masks): 23 x 8 / 24 x 8 workgroups
-    // (239 VGPRs; 256 x 256 spills)
+    // (239 VGPRs; 256 x 256 spills).  Experiments build only: the partition lost to the unpartitioned step
     NT2(224, 256, 2, 4),
 #endif
 };

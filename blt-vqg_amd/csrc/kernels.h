@@ -107,7 +107,7 @@ bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a);
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm = 0, int force_bn = 0);
 void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat = false);      // row_stat: a launch with out_stat (no 192-column tiles)
 // CUs the launch planners size a "round" for: 256 (the chip) unless the dependent chain runs on a CU partition (engine_set_cu_masks)
-int blt_hw_id_probe(int* out, int n_wg, int spin_ticks, hipStream_t s);      // misc.hip
+int blt_hw_id_probe(int* out, int n_wg, int spin_ticks, hipStream_t s);      // misc.hip (experiments build)
 void blt_set_plan_cus(int n);      // 0 = the whole chip
 int blt_plan_cus();
 // gemm2.hip: grouped weight gradients (one launch for a table of dW = dY^T X problems; GemmArgs in the transA/transB weight-gradient

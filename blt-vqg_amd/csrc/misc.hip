@@ -1168,6 +1168,7 @@ int blt_region_attn_bwd(int dtype, const void* P, const float* w, const float* a
 }
 
 // ---- hardware-id probe: which XCD / CU a stream's workgroups land on (tests of the CU partition, bltvqg_engine_set_cu_masks) ----
+#ifdef BLT_EXPERIMENTS
 namespace {
 __global__ void __launch_bounds__(64) hw_id_probe_kernel(int* __restrict__ out, int spin) {
     unsigned hw, xcc;
@@ -1187,3 +1188,4 @@ int blt_hw_id_probe(int* out, int n_wg, int spin_ticks, hipStream_t s) {
     hipLaunchKernelGGL(hw_id_probe_kernel, dim3((unsigned)n_wg), dim3(64), 0, s, out, spin_ticks);
     return blt_check_launch("hw_id_probe");
 }
+#endif      // BLT_EXPERIMENTS

@@ -24,7 +24,7 @@ for (M, N, K) in [(5120, 512, 512), (5120, 2048, 512), (5120, 512, 2048)]:
     C = torch.zeros(max(na, 2), M, N, device="cuda", dtype=torch.bfloat16)
     sa, sb, sc = M * K * 2, N * K * 2, M * N * 2
     def run(ac, bc, cc, chain):
-        return lambda n: check(lib.bltvqg_gemm_rotate(1, ptr(A), K, ac, sa, ptr(B), K, bc, sb, ptr(C), N, cc, sc, M, N, K, chain, n, stream_ptr()), "rot")
+        return lambda n: check(_lib.load_experiments().bltvqg_gemm_rotate(1, ptr(A), K, ac, sa, ptr(B), K, bc, sb, ptr(C), N, cc, sc, M, N, K, chain, n, stream_ptr()), "rot")
     res = [("hot", t(run(1, 1, 1, 0))), ("B x8 (L2-sized set)", t(run(1, 8, 1, 0))), ("B x64 (fits the Infinity Cache)", t(run(1, 64, 1, 0))),
            ("B x600 (HBM)", t(run(1, nb, 1, 0))), ("A x48 + C x48", t(run(na, 1, na, 0))), ("A x48 + B x600 + C x48", t(run(na, nb, na, 0)))]
     if N == K:

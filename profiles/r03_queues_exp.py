@@ -22,7 +22,7 @@ for kind in ("hip", "torch"):
         for rep in range(2):
             t0 = time.perf_counter()
             for s in streams[:k]:
-                check(lib.bltvqg_hw_id_probe(ptr(out), 1, 30000, ctypes.c_void_p(s.cuda_stream)), "probe")
+                check(_lib.load_experiments().bltvqg_hw_id_probe(ptr(out), 1, 30000, ctypes.c_void_p(s.cuda_stream)), "probe")
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) * 1e6
         print("%s streams: %2d x 300 us kernels -> %.0f us" % (kind, k, dt), flush=True)

@@ -27,6 +27,15 @@ def lib():
     return _lib.load()
 
 
+def exp_lib():
+    """The experiments build (include/bltvqg_hip_experiments.h); the calling test is skipped when it has not been built."""
+    import pytest
+    e = _lib.load_experiments()
+    if e is None:
+        pytest.skip("experiments build absent (make -C blt-vqg_amd/csrc experiments)")
+    return e
+
+
 def gemm(A, B, M, N, K, transA=False, transB=False, bias=None, relu=False, drop_p=0.0, seed=0, stream_id=0, maskY=None,
          mask_scale=1.0, R=None, C=None, accumulate=False, out_f32=False, force_tile=0, ldc=None, split_k=0):
     dt = DT[A.dtype]
@@ -118,7 +127,7 @@ def attn_out_fwd(Q, K, V, Wo, R, key_ids, B, heads, Tq, Tk, d, causal, scale, dr
     """fused attention + output Linear + residual: returns (O, Y)"""
     O = torch.zeros(B * Tq, heads * d, dtype=Q.dtype, device=Q.device)
     Y = torch.zeros(B * Tq, heads * d, dtype=Q.dtype, device=Q.device)
-    check(lib().bltvqg_attn_out_fwd(ptr(Q), Q.stride(0), ptr(K), K.stride(0), ptr(V), V.stride(0), ptr(O), O.stride(0), ptr(Wo), Wo.stride(0),
+    check(exp_lib().bltvqg_attn_out_fwd(ptr(Q), Q.stride(0), ptr(K), K.stride(0), ptr(V), V.stride(0), ptr(O), O.stride(0), ptr(Wo), Wo.stride(0),
                                     ptr(R), 0 if R is None else R.stride(0), ptr(Y), Y.stride(0), ptr(key_ids), B, heads, Tq, Tk, d, int(causal),
                                     float(scale), float(drop_p), int(seed), int(stream_id), stream_ptr()), "attn_out_fwd")
     return O, Y

@@ -11,8 +11,11 @@ from bltvqg_amd import _lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    src = open(os.path.join(ROOT, "include", "bltvqg_hip.h")).read()
+HEADER = os.path.join(ROOT, "include", "bltvqg_hip.h")
+
+
+def _header_functions(path=None):
+    src = open(path or HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     out = {}
     for m in re.finditer(r"\b(bltvqg_\w+)\s*\(([^)]*)\)\s*;", src):
@@ -29,6 +32,24 @@ def test_library_is_built_and_exports_every_declared_symbol():
     assert len(decl) >= 45
     for name in decl:
         assert hasattr(lib, name), "missing export " + name
+
+
+def test_experiment_surface_is_not_in_the_product_library():
+    """The timing aids, the hardware-id probe and the fused operators that were measured and not adopted live in
+    include/bltvqg_hip_experiments.h and the -DBLT_EXPERIMENTS build only: the shipped library exports none of them,
+    the product header declares none of them."""
+    lib = _lib.load()
+    decl = _header_functions()
+    exp = _header_functions(os.path.join(os.path.dirname(HEADER), "bltvqg_hip_experiments.h"))
+    assert set(exp) == set(_lib.EXPERIMENT_SIGNATURES), set(exp) ^ set(_lib.EXPERIMENT_SIGNATURES)
+    for name, n in exp.items():
+        assert name not in decl
+        assert not hasattr(lib, name), "experiment entry point exported by the product library: " + name
+        assert len(_lib.EXPERIMENT_SIGNATURES[name][1]) == n, (name, n)
+    e = _lib.load_experiments()
+    if e is not None:      # when built: it exports both surfaces
+        for name in list(exp) + list(decl):
+            assert hasattr(e, name), name
 
 
 def test_ctypes_table_matches_header():

@@ -175,9 +175,9 @@ def _wgrad_strided_cases():
 def test_gemm_rotate_computes_every_copy_and_the_chain():
     """bltvqg_gemm_rotate (timing aid with cold operands): launch i uses copy i % copies of A / B / C; chain = 1 feeds launch i-1's output to
     launch i.  Every copy must hold the plain GEMM's result (integer operands: exact)."""
-    from bltvqg_amd import _lib
+    import gpu_ops as G
     from bltvqg_amd._lib import ptr, stream_ptr, check
-    lib = _lib.load()
+    lib = G.exp_lib()      # (experiments build: include/bltvqg_hip_experiments.h)
     M, N, K = 512, 128, 128
     g = torch.Generator().manual_seed(3)
     A = torch.randint(-3, 4, (3, M, K), generator=g).float().bfloat16().cuda()

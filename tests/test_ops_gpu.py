@@ -11,6 +11,12 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+def G_exp():
+    import gpu_ops
+    return gpu_ops.exp_lib()
+
+
 DTYPES = [torch.float32, torch.bfloat16]
 
 
@@ -824,7 +830,7 @@ def test_linear_with_fused_layernorm(shape):
     out = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
     mean, rstd = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
     gd, btd = gamma.cuda(), beta.cuda()
-    check(lib.bltvqg_linear_layernorm(ptr(Xd), K, ptr(Wd), K, ptr(bd), 0, 0.0, 0, 0, None, 0, ptr(Rd), N, ptr(C), N, ptr(gd), ptr(btd), 1e-5,
+    check(G_exp().bltvqg_linear_layernorm(ptr(Xd), K, ptr(Wd), K, ptr(bd), 0, 0.0, 0, 0, None, 0, ptr(Rd), N, ptr(C), N, ptr(gd), ptr(btd), 1e-5,
                                       ptr(out), ptr(mean), ptr(rstd), M, N, K, stream_ptr()), "linear_layernorm")
     torch.cuda.synchronize()
     ref = X @ W.t()
@@ -860,7 +866,7 @@ def test_layernorm_folded_into_consumer_linear(shape):
     Xn = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
     C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
     mean, rstd = torch.zeros(M, device="cuda"), torch.zeros(M, device="cuda")
-    check(lib.bltvqg_layernorm_linear(ptr(Xd), K, ptr(gamma.cuda()), ptr(beta.cuda()), 1e-5, ptr(Xn), ptr(mean), ptr(rstd), ptr(Wd), K, ptr(bd),
+    check(G_exp().bltvqg_layernorm_linear(ptr(Xd), K, ptr(gamma.cuda()), ptr(beta.cuda()), 1e-5, ptr(Xn), ptr(mean), ptr(rstd), ptr(Wd), K, ptr(bd),
                                       0, 0.0, 0, 0, None, 0, ptr(C), N, M, N, K, stream_ptr()), "layernorm_linear")
     torch.cuda.synchronize()
     ln = F.layer_norm(X.float(), (K,), gamma, beta, 1e-5)

@@ -70,8 +70,15 @@ def test_prefetched_step_is_bit_identical_to_inline(dtype, mode, split):
         # (a look-ahead run has already folded batch i+1 into the running statistics when step i ends: compare once no batch is ahead)
         if i == len(ref) - 1:
             assert torch.equal(r[2], g[2]), ("BatchNorm running statistics", i)
-        # the losses and the update go through fp32 atomics (split-K, loss sums): reproducible to accumulation order, like test_determinism_gpu
-        assert float((r[1] - g[1]).abs().max()) < 1e-4, ("losses", i, r[1].tolist(), g[1].tolist())
+        # the losses and the update go through fp32 atomics (split-K, loss sums): reproducible to accumulation order, like
+        # test_determinism_gpu.  From the third step on the bound is relative: at this test's lr = 1e-3 Adam turns the sign of a
+        # near-zero gradient element — which the atomics' order decides — into a 2e-3 parameter difference, and two fresh INLINE runs of the
+        # bf16 engine were seen to land on either of two trajectories 3e-4 apart in the KL term (round 4; scratch/bistable.py).  What a
+        # mis-ordered look-ahead would break — image feature, BatchNorm statistics — is held tight above and below.
+        if i < 2:
+            assert float((r[1] - g[1]).abs().max()) < 1e-4, ("losses", i, r[1].tolist(), g[1].tolist())
+        else:
+            assert float(((r[1] - g[1]).abs() / r[1].abs().clamp(min=1.0)).max()) < 1e-3, ("losses", i, r[1].tolist(), g[1].tolist())
         # Adam turns a gradient of either sign into a step of +-lr: elements whose tiny gradient differs in the last bits may move apart by
         # 2 lr from the second step on, so the bound there is on the mean
         if i == 0:
@@ -107,7 +114,8 @@ def test_prefetch_misuse_is_refused():
 def _cu_set(lib, stream, n=4096):
     from bltvqg_amd._lib import check, ptr
     out = torch.zeros(n * 2, dtype=torch.int32, device="cuda")
-    check(lib.bltvqg_hw_id_probe(ptr(out), n, 2000, ctypes.c_void_p(stream.cuda_stream)), "probe")
+    import gpu_ops
+    check(gpu_ops.exp_lib().bltvqg_hw_id_probe(ptr(out), n, 2000, ctypes.c_void_p(stream.cuda_stream)), "probe")
     torch.cuda.synchronize()
     o = out.view(n, 2).cpu()
     hw, xcc = o[:, 0], o[:, 1]

@@ -58,9 +58,11 @@ typedef __attribute__((ext_vector_type(8))) short s16x8b;
 // NT GEMM
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int cmin(int a, int b) { return a < b ? a : b; }
-template <int BM_, int BN_, int NWM_, int NWN_>
+// CAP: LDS budget of one workgroup (the whole CU by default: one workgroup per CU with as deep a ring as fits; a half-CU budget lets TWO
+// 4-wave workgroups share a CU, so that one's prologue / epilogue latency runs under the other's K loop)
+template <int BM_, int BN_, int NWM_, int NWN_, int CAP_ = NT2_LDS_CAP>
 struct Nt2 {
-    static constexpr int BM = BM_, BN = BN_, NWM = NWM_, NWN = NWN_;
+    static constexpr int BM = BM_, BN = BN_, NWM = NWM_, NWN = NWN_, CAP = CAP_;
     static constexpr int NW = NWM * NWN, NT = NW * 64, BK = 64;
     static constexpr int WM = BM / NWM, WN = BN / NWN, TM = WM / 16, TN = WN / 16;
     static_assert(BM % (16 * NWM) == 0 && BN % (16 * NWN) == 0 && BM % 8 == 0 && BN % 8 == 0, "tile / wave layout mismatch");
@@ -71,7 +73,7 @@ struct Nt2 {
     static constexpr int DUMP = 1024;          // ONE slot for every wave's beyond-the-tile DMA (zeros over zeros)
     // ring depth: as many stages as LDS holds (<= 8), so that NST - 1 K-steps (>= ~96 KB for the big tiles) are in flight per CU;
     // (AHEAD - 1) * PER_STAGE must fit the 6-bit vmcnt
-    static constexpr int NST = cmin(cmin(8, (NT2_LDS_CAP - DUMP) / STAGE), 63 / PER_STAGE + 2);
+    static constexpr int NST = cmin(cmin(8, (CAP - DUMP) / STAGE), 63 / PER_STAGE + 2);
     static constexpr int RING = NST * STAGE;
     static constexpr int AHEAD = NST - 1;
     static_assert(NST >= 2 && (AHEAD - 1) * PER_STAGE <= 63, "vmcnt is a 6-bit counter");
@@ -82,7 +84,7 @@ struct Nt2 {
     // (+ BM x {mean, rstd} behind the slabs: the folded-LayerNorm variant keeps its row statistics there during the epilogue)
     static constexpr int ROWSTAT_OFF = 2 * SLAB_BYTES;
     static constexpr int LDS = (RING + DUMP > ROWSTAT_OFF + BM * 8) ? RING + DUMP : ROWSTAT_OFF + BM * 8;
-    static_assert(LDS <= NT2_LDS_CAP, "LDS budget");
+    static_assert(LDS <= CAP, "LDS budget");
 };
 
 // sum over the GPR (8, 16 or 32) consecutive lanes that hold one result row (all lanes of the wave take part)
@@ -672,6 +674,7 @@ __global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem
 // tile shapes compiled in: BM x BN, 8 waves as NWM x NWN, ring depth
 struct TileOpt { int bm, bn; int (*launch)(const GemmArgs&, hipStream_t); };
 #define NT2(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN>>}
+#define NT2H(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN, 79 * 1024>>}      // half-CU workgroups (two per CU)
 const TileOpt kTiles[] = {
     NT2(64, 64, 2, 4),   NT2(64, 128, 2, 4),  NT2(128, 64, 4, 2),  NT2(128, 128, 2, 4),
     NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(192, 64, 4, 2),  NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
@@ -679,6 +682,9 @@ const TileOpt kTiles[] = {
     NT2(160, 192, 2, 4), NT2(160, 256, 2, 4), NT2(192, 128, 2, 4), NT2(192, 192, 2, 4), NT2(192, 256, 2, 4),
     NT2(128, 256, 2, 4), NT2(256, 128, 4, 2),
 #endif
+    // (round 4: half-CU forms — 4 waves, <= 79 KB of LDS, two workgroups per CU so that one's prologue / epilogue runs under the other's
+    // K loop: NT2H(80, 64, 1, 4) 10.3 us against 10.1 for (160, 64) on [5120 x 512] x 512, 24.2 against 20.7 at K = 2048, NT2H(80, 128)
+    // 22.3 against 16.9 for (128, 256) on N = 1536 — measured, not kept)
 #if NT2_LDS_CAP >= 160 * 1024 && defined(BLT_EXPERIMENTS)
     // one-round tile of the 2048-column problems when the chain runs on a 192-CU partition (engine_set_cu_masks): 23 x 8 / 24 x 8 workgroups
     // (239 VGPRs; 256 x 256 spills).  Experiments build only: the partition lost to the unpartitioned step

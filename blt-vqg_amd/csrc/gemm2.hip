@@ -448,7 +448,7 @@ struct WgCfgT {
     static constexpr int CH_A = BK * (BM / 8) / NT, CH_B = BK * (BN / 8) / NT, PER_STAGE = CH_A + CH_B;      // DMA wave-instructions per wave per stage
     static constexpr int NST = (BM == 256 && BN == 256) ? (BK == 32 ? 4 : 2) : (BM == 256) ? 3 : 4, AHEAD = NST - 1;
     static constexpr int LDS = NST * STAGE + 1024;       // + the table's workgroup offsets
-    static_assert(CH_A >= 1 && CH_B >= 1 && ((TM == 2 && TN == 2) || (TM == 4 && TN == 2) || (TM == 4 && TN == 8)) && LDS <= 160 * 1024, "wave layout");
+    static_assert(CH_A >= 1 && CH_B >= 1 && ((TM == 2 && TN == 2) || (TM == 4 && TN == 2) || (TM == 4 && TN == 8) || (TM == 4 && TN == 4)) && LDS <= 160 * 1024, "wave layout");
 };
 // The 256 x 256 form (8 waves as 4 x 2, wave tile 64 x 128, four 32 KB stages of 32 tokens): the 256 x 128 form measured 363-405 us for the
 // decoder's set with 331 us of it explained by L2->LDS intake alone (48 KB per K-step per CU at ~70 GB/s; ablation: without the DMA
@@ -457,6 +457,9 @@ struct WgCfgT {
 // per lane allow only 8 waves per CU, and with two waves per SIMD the read -> wait -> MFMA phases of a wave are no longer covered by its
 // neighbours: 361 us, the same.  Kept as a tested option (tile form 512), not selected.
 typedef WgCfgT<256, 256, 4, 2, 32> WgCfgSq;      // 32-token K-steps: four 32 KB stages, three in flight
+// the square tile with SIXTEEN waves (4 x 4, wave tile 64 x 64: 64 accumulator registers per lane, 0.5 fragments per MFMA) — round 4: what
+// the 8-wave form lacked was waves to cover its read -> wait -> MFMA chain; tile form 1024 (debug key 13)
+typedef WgCfgT<256, 256, 4, 4, 32> WgCfgSq16;
 typedef WgCfgT<128> WgCfg;
 
 __device__ __forceinline__ int wg_swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -571,7 +574,8 @@ __global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem
                 const int f0 = wg_swz(r0), f1 = wg_swz(r0 + 4);
                 // B fragments in groups of JG (all of them for TN = 2; two groups of 4 for the square tile, whose 8 + 4 fragments and
                 // 128 accumulator registers would not fit otherwise); the A fragments are read once with the first group
-                constexpr int JG = C::TN > 4 ? 4 : C::TN, NJG = C::TN / JG;
+                // (the 16-wave square tile, TM = TN = 4 under a 128-register budget: B fragments two at a time)
+                constexpr int JG = (C::TN == 4 && C::TM == 4) ? 2 : (C::TN > 4 ? 4 : C::TN), NJG = C::TN / JG;
                 bf16x8 af[C::TM];
                 s16x4 alo[C::TM], ahi[C::TM];
 #pragma unroll
@@ -603,10 +607,13 @@ __global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem
                                          : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(blo[2]), "+v"(bhi[2]), "+v"(blo[3]), "+v"(bhi[3])
                                          :: "memory");
                     } else if constexpr (C::TM == 4) {
-                        asm volatile("s_waitcnt lgkmcnt(0)"
-                                     : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]),
-                                       "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3])
-                                     :: "memory");
+                        if (jg == 0)
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]), "+v"(alo[0]), "+v"(ahi[0]), "+v"(alo[1]), "+v"(ahi[1]), "+v"(alo[2]),
+                                           "+v"(ahi[2]), "+v"(alo[3]), "+v"(ahi[3])
+                                         :: "memory");
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(blo[0]), "+v"(bhi[0]), "+v"(blo[1]), "+v"(bhi[1]) :: "memory");
                     } else {
                         static_assert(C::TM == 2 || C::TM == 4, "lds_tr wait lists");
                         asm volatile("s_waitcnt lgkmcnt(0)"
@@ -763,9 +770,13 @@ int blt_wgrad_group_plan(const std::vector<GemmArgs>& g, std::vector<blt_wg_prob
     long t256 = 0, tsq = 0;
     for (const GemmArgs& a : g) { t256 += (long)cdiv(a.M, 256) * cdiv(a.N, 128); tsq += (long)cdiv(a.M, 256) * cdiv(a.N, 256); }
     const int forced = blt_debug_get(13);
-    (void)tsq;      // the square form is selectable (debug key 13 = 512) but not chosen: measured 361 us vs 363 us for the 256 x 128 form on the decoder's set
-    const int bm = (forced == 128 || forced == 256 || forced == 512) ? forced : (t256 >= 256 ? 256 : 128);
-    const int tm = bm == 128 ? 128 : 256, tn = bm == 512 ? 256 : 128;
+    // The square 256 x 256 form (8 waves) wherever it still gives every CU a tile.  Alone it measures the same as 256 x 128 (361 vs 363 us
+    // for the decoder's set, round 2: its 8 waves do not cover their own read -> wait -> MFMA chain) — but in the STEP the grouped launches
+    // run beside the encoder chains, and there half the workgroups and a third less L2 -> LDS intake per flop is what counts: 6.84 ms
+    // against 6.93 per step (round 4, A/B by debug key 13 on one box).  (A 16-wave square form — 64 accumulator + fragment registers
+    // over the 128-register budget, 21 spilled — 7.57 ms: tile form 1024, kept selectable for the record.)
+    const int bm = (forced == 128 || forced == 256 || forced == 512 || forced == 1024) ? forced : (tsq >= 256 ? 512 : (t256 >= 256 ? 256 : 128));
+    const int tm = bm == 128 ? 128 : 256, tn = bm >= 512 ? 256 : 128;
     long tiles = 0;
     for (const GemmArgs& a : g) tiles += (long)cdiv(a.M, tm) * cdiv(a.N, tn);
     probs.clear(); wg0.clear();
@@ -810,7 +821,8 @@ static int launch_wg(const blt_wg_problem* probs_dev, const int* wg0_dev, int np
     return blt_check_launch("wgrad_group");
 }
 int blt_wgrad_group_launch(const blt_wg_problem* probs_dev, const int* wg0_dev, int nprob, int nwg, int bm, hipStream_t s) {
-    BLT_REQUIRE(probs_dev && wg0_dev && nprob > 0 && nprob < 250 && nwg > 0 && (bm == 128 || bm == 256 || bm == 512), "wgrad_group: bad table");
+    BLT_REQUIRE(probs_dev && wg0_dev && nprob > 0 && nprob < 250 && nwg > 0 && (bm == 128 || bm == 256 || bm == 512 || bm == 1024), "wgrad_group: bad table");
     if (bm == 512) return launch_wg<WgCfgSq>(probs_dev, wg0_dev, nprob, nwg, s);
+    if (bm == 1024) return launch_wg<WgCfgSq16>(probs_dev, wg0_dev, nprob, nwg, s);
     return bm == 256 ? launch_wg<WgCfgT<256>>(probs_dev, wg0_dev, nprob, nwg, s) : launch_wg<WgCfgT<128>>(probs_dev, wg0_dev, nprob, nwg, s);
 }

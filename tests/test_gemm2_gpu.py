@@ -111,7 +111,7 @@ def _wgrad_group(problems, table_bytes=1 << 16):
     return outs
 
 
-@pytest.mark.parametrize("tile_rows", [128, 256, 512])      # 512 = the 256 x 256 (square) tile form
+@pytest.mark.parametrize("tile_rows", [128, 256, 512, 1024])      # 512 = the 256 x 256 (square) tile form
 def test_wgrad_group_exact_stored_and_split(tile_rows):
     import gpu_ops as G
     G.lib().bltvqg_debug_set(13, tile_rows)          # force the 128- / 256-row tile variant (the planner picks by launch size)
@@ -146,7 +146,7 @@ def _wgrad_group_cases():
     assert torch.equal(b.cpu().double(), y.double().cpu().sum(0))
 
 
-@pytest.mark.parametrize("tile_rows", [128, 256, 512])      # 512 = the 256 x 256 (square) tile form
+@pytest.mark.parametrize("tile_rows", [128, 256, 512, 1024])      # 512 = the 256 x 256 (square) tile form
 def test_wgrad_group_strided_views_like_the_engine(tile_rows):
     """The engine's fused q|k|v gradient [rows, 3H] against xn [rows, H], and the embedding's [rows, 320]-pitched operand with K = 300."""
     import gpu_ops as G

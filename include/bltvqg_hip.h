@@ -322,8 +322,11 @@ int bltvqg_engine_image_input(bltvqg_engine* e, void** ptr, int* Hp, int* Wp, in
  * BatchNorm2d, average pool) of batch i+1 depend on nothing step i updates: this call enqueues them on the engine's own conv stream, ordered
  * behind everything enqueued on `stream` so far (the producer of `images`), and the NEXT bltvqg_engine_forward — called with images = NULL —
  * waits for the pooled feature and starts at the trainable head (fc + BatchNorm1d).  images fp32 NCHW [B,3,h,w], or NULL when the caller
- * filled the stem input itself (bltvqg_engine_image_input).  Results are bit-identical to the inline forward: same kernels, same order of
- * BatchNorm2d running-statistics updates (one in-order stream).  At most two batches may be pending; the second one may only be enqueued
+ * filled the stem input itself (bltvqg_engine_image_input).  The conv stack's results (pooled feature, BatchNorm2d running statistics) are
+ * bit-identical to the inline forward's: same kernels, same order of running-statistics updates (one in-order stream); a whole training STEP is
+ * bit-identical to the inline step in its first step only — from the second step on the parameters have been through float-atomic
+ * gradient sums, whose order differs between any two runs (tests/test_prefetch_gpu.py states the bars).  The statistics in the frozen buffer
+ * run one batch AHEAD of the step while a stack is pending: readers order themselves with bltvqg_engine_conv_stream_wait.  At most two batches may be pending; the second one may only be enqueued
  * after the backward of the step that consumed the previous batch (the pooled feature is double-buffered).  Image mode, train-mode
  * BatchNorm only.  bltvqg_engine_prefetch_pending: number of prefetched batches not yet consumed by a forward. */
 int bltvqg_engine_prefetch_images(bltvqg_engine* e, const float* images, void* stream);

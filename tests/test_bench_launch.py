@@ -69,24 +69,29 @@ def test_shipped_library_has_no_work_skipping_switch():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r03_bench_default.json is the bench line of a default `python bench.py` run on an MI355X box: the driver's contract fields, the
+    """profiles/r04_bench_default.json is the bench line of a default `python bench.py` run on an MI355X box: the driver's contract fields, the
     roofline block of the dominant kernel family and the CPU baseline must all be there (a schema check, not a performance check)."""
     import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    d = json.load(open(os.path.join(root, "profiles", "r03_bench_default.json")))
+    d = json.load(open(os.path.join(root, "profiles", "r04_bench_default.json")))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "median_ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "debug_keys", "loss_vs_oracle", "overlap", "f32"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "debug_keys", "loss_vs_oracle", "overlap", "f32", "phase1"):
         assert k in d, k
     assert d["unit"] == "pairs/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16"
     assert "configs[2]" in d["config"]["workload"] and "model" not in d["config"]
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_sum_of_launch_durations", "per_stream_kernel_ms", "fits_in_step", "step_ms"):
         assert k in r, k
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["frac"] < 1.0
-    assert "static" in r["traffic_source"]
+    # VERDICT r3 item 7: the fraction the contract reads is bounded by the step's clock — no stream's bracketed time exceeds the step,
+    # and `frac` uses no more time than the step has (the plain flops / sum-of-durations figure stays beside it)
+    assert r["fits_in_step"] is True and all(x <= r["step_ms"] * 1.02 for x in r["per_stream_kernel_ms"])
+    assert r["frac"] >= r["frac_sum_of_launch_durations"] - 1e-9
+    assert r["gflop_per_step"] * 1e9 / (r["frac"] * r["peak"] * 1e12) <= r["step_ms"] * 1e-3 * 1.001
+    assert "static" in r["traffic_source"] and "r04_pmc_traffic.json" in r["traffic_source"]
     c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample", "s_per_step"):
+    for k in ("value", "unit", "cores", "threads", "affinity_cpus", "os_cpu_count", "threads_tried_s_per_step", "kind", "sample", "s_per_step"):
         assert k in c, k
-    assert c["kind"] == "port" and d["debug_keys"] == {}
+    assert c["kind"] == "port" and d["debug_keys"] == {} and c["cores"] == c["threads"] <= min(c["affinity_cpus"], 64)
     assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) / d["value"] < 1e-3

@@ -687,16 +687,11 @@ const TileOpt kTiles[] = {
     NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(192, 64, 4, 2),  NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
 #if NT2_LDS_CAP >= 160 * 1024      // (the co-residency experiment build caps a workgroup at 79 KB: two ring stages of <= 39 KB)
     NT2(160, 192, 2, 4), NT2(160, 256, 2, 4), NT2(192, 128, 2, 4), NT2(192, 192, 2, 4), NT2(192, 256, 2, 4),
-    NT2(128, 256, 2, 4), NT2(256, 128, 4, 2),
+    NT2(128, 256, 2, 4), NT2(256, 128, 4, 2), NT2(256, 64, 4, 2), NT2(224, 256, 2, 4),
 #endif
     // (round 4: half-CU forms — 4 waves, <= 79 KB of LDS, two workgroups per CU so that one's prologue / epilogue runs under the other's
     // K loop: NT2H(80, 64, 1, 4) 10.3 us against 10.1 for (160, 64) on [5120 x 512] x 512, 24.2 against 20.7 at K = 2048, NT2H(80, 128)
     // 22.3 against 16.9 for (128, 256) on N = 1536 — measured, not kept)
-#if NT2_LDS_CAP >= 160 * 1024 && defined(BLT_EXPERIMENTS)
-    // one-round tile of the 2048-column problems when the chain runs on a 192-CU partition (engine_set_cu_masks): 23 x 8 / 24 x 8 workgroups
-    // (239 VGPRs; 256 x 256 spills).  Experiments build only: the partition lost to the unpartitioned step
-    NT2(224, 256, 2, 4),
-#endif
 };
 #undef NT2
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);

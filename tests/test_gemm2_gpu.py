@@ -14,7 +14,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 TILES = [(64, 64), (64, 128), (128, 64), (128, 128), (160, 64), (160, 128), (160, 192), (160, 256), (192, 64), (192, 128), (192, 192), (192, 256),
-         (128, 256), (256, 128), (96, 64), (32, 64)]
+         (128, 256), (256, 128), (256, 64), (224, 256), (96, 64), (32, 64)]
 
 
 def _ints(shape, lo, hi, g):

@@ -34,6 +34,16 @@ class Config(ctypes.Structure):
     ]
 
 
+class LinearDesc(ctypes.Structure):
+    """struct bltvqg_linear_desc (include/bltvqg_hip.h): one problem of bltvqg_linear_pair."""
+    _fields_ = [
+        ("A", ctypes.c_void_p), ("lda", ctypes.c_int32), ("W", ctypes.c_void_p), ("ldw", ctypes.c_int32), ("C", ctypes.c_void_p), ("ldc", ctypes.c_int32),
+        ("M", ctypes.c_int32), ("bias", ctypes.c_void_p), ("maskY", ctypes.c_void_p), ("ldm", ctypes.c_int32), ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int32),
+        ("R", ctypes.c_void_p), ("ldr", ctypes.c_int32), ("stream_id", ctypes.c_uint32), ("fold_s", ctypes.c_void_p), ("fold_c", ctypes.c_void_p),
+        ("row_stat", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p), ("out_stat", ctypes.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes) ; must list every function the header declares (tests/test_abi.py checks this)
 SIGNATURES = {
     "bltvqg_version": (I, []),
@@ -47,6 +57,7 @@ SIGNATURES = {
     "bltvqg_gemm_rowstat_parts": (I, [I, I, I, I]),
     "bltvqg_ln_fold_prepare": (I, [P, I, I, P, P, P, P, P, P, P]),
     "bltvqg_linear_ln_folded": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, P, P, F, I, F, U64, U32, I, I, P]),
+    "bltvqg_linear_pair": (I, [P, P, I, I, I, F, U64, F, I, I, F, I, I, P]),
     "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
     "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),

@@ -38,8 +38,10 @@ int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int 
     g.bias = bias; g.rowtab = rowtab; g.rowidx = rowidx; g.ldt = ldt; g.relu = relu; g.drop_p = drop_p; g.seed = seed; g.stream_id = stream_id;
     g.maskY = maskY; g.ldm = ldm; g.mask_scale = mask_scale; g.C2 = C2; g.ldc2 = ldc2; g.R = R; g.ldr = ldr; g.accumulate = accumulate;
     if (tile_m < 0) { g.no_dma = 0; g.force_tile = 64; return blt_gemm(BLT_BF16, g, (hipStream_t)stream); }      // round-1 kernel (64x64 ring)
-    BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g), "gemm_ex: operands do not fit the planned-tile kernel (bf16 NT, lda/ldb %% 8 == 0, M >= 256)");
     BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "gemm_ex: tile_m / tile_n must both be 0 or both be a compiled tile shape");
+    g.nt2_bm = tile_m; g.nt2_bn = tile_n;
+    BLT_REQUIRE(blt_gemm_nt2_ok(BLT_BF16, g),
+                "gemm_ex: operands do not fit the planned-tile kernel (bf16 NT, lda/ldb %% 8 == 0, M >= 256 unless a tile shape is given)");
     // through blt_gemm: the same operand validation as every other entry point (pitches >= round8(K), 16-byte aligned epilogue operands,
     // rowtab needs rowidx, dropout range); a bad call is BLT_ERR_ARG, not an out-of-bounds LDS-DMA read on the device
     g.nt2_bm = tile_m; g.nt2_bn = tile_n;
@@ -87,6 +89,31 @@ int bltvqg_linear_ln_folded(const void* X, int ldx, const void* Wf, int ldw, voi
     BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "linear_ln_folded: tile_m / tile_n must both be 0 or both be a compiled tile shape");
     g.nt2_bm = tile_m; g.nt2_bn = tile_n;
     return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
+}
+
+int bltvqg_linear_pair(const bltvqg_linear_desc* p1, const bltvqg_linear_desc* p2, int N, int K, int relu, float drop_p, uint64_t seed, float mask_scale,
+                       int stat_slots, int stat_parts, float eps, int tile_m, int tile_n, void* stream) {
+    BLT_REQUIRE(p1 && p2 && N > 0 && K > 0, "linear_pair: null descriptor / bad shape");
+    BLT_REQUIRE((tile_m == 0 && tile_n == 0) || (tile_m > 0 && tile_n > 0), "linear_pair: tile_m / tile_n must both be 0 or both be a compiled tile shape");
+    GemmArgs g[2];
+    const bltvqg_linear_desc* d[2] = {p1, p2};
+    for (int i = 0; i < 2; ++i) {
+        GemmArgs& a = g[i];
+        const bltvqg_linear_desc& q = *d[i];
+        BLT_REQUIRE(q.A && q.W && q.C && q.M > 0, "linear_pair: problem %d: null operand / no rows", i + 1);
+        BLT_REQUIRE((q.mean == nullptr) == (q.rstd == nullptr), "linear_pair: problem %d: mean and rstd go together", i + 1);
+        a.A = q.A; a.lda = q.lda; a.B = q.W; a.ldb = q.ldw; a.C = q.C; a.ldc = q.ldc; a.M = q.M; a.N = N; a.K = K;
+        a.bias = q.bias; a.maskY = q.maskY; a.ldm = q.ldm; a.mask_scale = mask_scale; a.C2 = q.C2; a.ldc2 = q.ldc2; a.R = q.R; a.ldr = q.ldr;
+        a.relu = relu; a.drop_p = drop_p; a.seed = seed; a.stream_id = q.stream_id;
+        a.fold_s = q.fold_s; a.fold_c = q.fold_c; a.fold_stat = q.row_stat; a.fold_mean = q.mean; a.fold_rstd = q.rstd; a.fold_eps = eps; a.fold_n = (float)K;
+        a.fold_np = stat_parts > 0 ? stat_parts : 1; a.out_stat = q.out_stat; a.stat_slots = stat_slots > 0 ? stat_slots : 1;
+        a.nt2_bm = tile_m; a.nt2_bn = tile_n;
+        const int rc = blt_gemm_validate(BLT_BF16, a);
+        if (rc != BLT_OK) return rc;
+    }
+    BLT_REQUIRE(blt_gemm_nt2_pair_ok(BLT_BF16, g[0], g[1]),
+                "linear_pair: the two problems must both fit the planned-tile kernel (bf16 NT, ld %% 8 == 0) and carry the same epilogue terms");
+    return blt_gemm_nt2_pair(g[0], g[1], (hipStream_t)stream);
 }
 
 int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, const void* const* X, const int32_t* ldx, float* const* dW,

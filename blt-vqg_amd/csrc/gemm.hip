@@ -1243,14 +1243,8 @@ static int autotune(int dtype, const GemmArgs& a, hipStream_t stream) {
     return BLT_OK;
 }
 
-int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
-    GemmArgs a = a_in;
-    if (a.is_conv == 1) {      // plain NHWC defaults of the PP generalisation
-        if (a.cg.in_rows == 0) a.cg.in_rows = a.cg.Hi;
-        if (a.cg.in_pitch == 0) a.cg.in_pitch = a.cg.Wi;
-        if (a.cg.Hov == 0) a.cg.Hov = a.cg.Ho;
-        if (a.cg.Wov == 0) a.cg.Wov = a.cg.Wo;
-    }
+// operand validation shared by every launch path: a bad call is BLT_ERR_ARG, not an out-of-bounds LDS-DMA read on the device
+int blt_gemm_validate(int dtype, const GemmArgs& a) {
     BLT_REQUIRE(dtype == BLT_F32 || dtype == BLT_BF16, "gemm: bad dtype %d", dtype);
     BLT_REQUIRE(a.A && a.B && a.C, "gemm: null operand");
     BLT_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
@@ -1280,6 +1274,18 @@ int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
                 (!a.rowtab || ((uintptr_t)a.rowtab % 16) == 0), "gemm: epilogue operands must be 16-byte aligned");
     BLT_REQUIRE(!(a.rowtab && !a.rowidx), "gemm: rowtab without rowidx");
     BLT_REQUIRE(!a.a_rowsum || (a.transA && !a.is_conv), "gemm: a_rowsum needs the transA (weight-gradient) form");
+    return BLT_OK;
+}
+
+int blt_gemm(int dtype, const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    if (a.is_conv == 1) {      // plain NHWC defaults of the PP generalisation
+        if (a.cg.in_rows == 0) a.cg.in_rows = a.cg.Hi;
+        if (a.cg.in_pitch == 0) a.cg.in_pitch = a.cg.Wi;
+        if (a.cg.Hov == 0) a.cg.Hov = a.cg.Ho;
+        if (a.cg.Wov == 0) a.cg.Wov = a.cg.Wo;
+    }
+    { const int rc = blt_gemm_validate(dtype, a); if (rc != BLT_OK) return rc; }
 #ifdef BLT_EXPERIMENTS
     if (a.lnA_out != nullptr) {
         BLT_REQUIRE(dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv, "gemm: LayerNorm on A needs bf16 k-contiguous operands");

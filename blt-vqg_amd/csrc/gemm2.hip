@@ -104,15 +104,12 @@ __device__ __forceinline__ float rowgroup_sum(float v) {
 // rstd_m * (acc - mean_m * s_n) + c_n.  Those launches (q|k|v, cross-attention query, first FFN layer) carry no bias / residual / mask /
 // second output / row table, so the variant reuses their registers.
 template <typename C, bool FOLD>
-__global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
+__device__ __forceinline__ void nt2_body(const GemmArgs& p, const int tile_m, const int tile_n) {
     constexpr int BM = C::BM, BN = C::BN, BK = C::BK, NW = C::NW, TM = C::TM, TN = C::TN, CS = C::CS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::NWN, wn = wave % C::NWN;
-    // consecutive workgroups walk down a column of tiles: they share the B (weight) panel, and A panels are re-read tiles_n times from L2
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int tile_n = blockIdx.x / tiles_m, tile_m = blockIdx.x % tiles_m;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const bf16* __restrict__ Ag = (const bf16*)p.A;
     const bf16* __restrict__ Bg = (const bf16*)p.B;
@@ -409,6 +406,55 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
 }
 
 template <typename C, bool FOLD>
+__global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
+    // consecutive workgroups walk down a column of tiles: they share the B (weight) panel, and A panels are re-read tiles_n times from L2
+    const int tiles_m = (p.M + C::BM - 1) / C::BM;
+    nt2_body<C, FOLD>(p, blockIdx.x % tiles_m, blockIdx.x / tiles_m);
+}
+
+// Two problems in one launch (GemmPair: the encoder stack's and the posterior encoder stack's Linear of the same layer position — same
+// N, K, tile shape and epilogue terms, their own operands, weights and row counts): a column of the launch holds problem 1's row tiles,
+// then problem 2's.  One launch fills the CUs with both problems' tiles instead of two launches sharing them by time-slicing, and the
+// smaller problem's partial last round disappears into the bigger one's.
+template <typename C, bool FOLD>
+__global__ __launch_bounds__(C::NT) void gemm_nt2_pair_kernel(const GemmArgs p1, const GemmPair d) {
+    const int tiles_m = d.tiles1 + (d.M + C::BM - 1) / C::BM;
+    int tile_m = blockIdx.x % tiles_m;
+    const int tile_n = blockIdx.x / tiles_m;
+    GemmArgs p = p1;
+    if (tile_m >= d.tiles1) {      // (workgroup-uniform: scalar selects)
+        tile_m -= d.tiles1;
+        p.M = d.M; p.A = d.A; p.lda = d.lda; p.B = d.B; p.ldb = d.ldb; p.C = d.C; p.ldc = d.ldc;
+        p.bias = d.bias; p.maskY = d.maskY; p.ldm = d.ldm; p.C2 = d.C2; p.ldc2 = d.ldc2; p.R = d.R; p.ldr = d.ldr;
+        p.stream_id = d.stream_id; p.fold_s = d.fold_s; p.fold_c = d.fold_c; p.fold_stat = d.fold_stat; p.fold_mean = d.fold_mean;
+        p.fold_rstd = d.fold_rstd; p.out_stat = d.out_stat;
+    }
+    nt2_body<C, FOLD>(p, tile_m, tile_n);
+}
+
+template <typename C, bool FOLD>
+int launch_nt2_pair_(const GemmArgs& a, const GemmPair& d, hipStream_t s) {
+    static BltDevFlag attr_set;
+    auto kern = gemm_nt2_pair_kernel<C, FOLD>;
+    if (!attr_set.get()) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
+            blt_set_error("gemm_nt2_pair: hipFuncSetAttribute(%d) failed", C::LDS);
+            return BLT_ERR_HIP;
+        }
+        attr_set.set();
+    }
+    GemmPair dd = d;
+    dd.tiles1 = cdiv(a.M, C::BM);
+    const long tiles = (long)(dd.tiles1 + cdiv(d.M, C::BM)) * cdiv(a.N, C::BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(C::NT), C::LDS, s, a, dd);
+    return blt_check_launch("gemm_nt2_pair");
+}
+template <typename C>
+int launch_nt2_pair(const GemmArgs& a, const GemmPair& d, hipStream_t s) {
+    return a.fold_s ? launch_nt2_pair_<C, true>(a, d, s) : launch_nt2_pair_<C, false>(a, d, s);
+}
+
+template <typename C, bool FOLD>
 int launch_nt2_(const GemmArgs& a, hipStream_t s) {
     static BltDevFlag attr_set;
     auto kern = gemm_nt2_kernel<C, FOLD>;
@@ -679,9 +725,8 @@ __global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem
 }
 
 // tile shapes compiled in: BM x BN, 8 waves as NWM x NWN, ring depth
-struct TileOpt { int bm, bn; int (*launch)(const GemmArgs&, hipStream_t); };
-#define NT2(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN>>}
-#define NT2H(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN, 79 * 1024>>}      // half-CU workgroups (two per CU)
+struct TileOpt { int bm, bn; int (*launch)(const GemmArgs&, hipStream_t); int (*launch_pair)(const GemmArgs&, const GemmPair&, hipStream_t); };
+#define NT2(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN>>, launch_nt2_pair<Nt2<BM, BN, NWM, NWN>>}
 const TileOpt kTiles[] = {
     NT2(64, 64, 2, 4),   NT2(64, 128, 2, 4),  NT2(128, 64, 4, 2),  NT2(128, 128, 2, 4),
     NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(192, 64, 4, 2),  NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
@@ -704,7 +749,7 @@ static int g_plan_cus = 256;
 void blt_set_plan_cus(int n) { g_plan_cus = (n > 0 && n <= 256) ? n : 256; }
 int blt_plan_cus() { return g_plan_cus; }
 
-int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn, bool row_stat) {
+int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn, bool row_stat, int M2 = 0) {
     int best = -1;
     double best_cost = 1e30;
     const int nk = cdiv(K, 64);
@@ -713,7 +758,7 @@ int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn, bool row_
         const TileOpt& t = kTiles[i];
         if (force_bm && (t.bm != force_bm || t.bn != force_bn)) continue;
         if (row_stat && t.bn == 192) continue;      // 24 column groups per row: no butterfly for the row statistics
-        const long tiles = (long)cdiv(M, t.bm) * cdiv(N, t.bn);
+        const long tiles = (long)(cdiv(M, t.bm) + (M2 > 0 ? cdiv(M2, t.bm) : 0)) * cdiv(N, t.bn);      // (M2: the second problem of a paired launch)
         const long rounds = (tiles + cus - 1) / cus;
         const double intake = (t.bm + t.bn) * 128.0 / 70e3;                   // us per K-step
         const double mfma = (double)t.bm * t.bn * 128.0 / 9.8e6;               // us per K-step
@@ -724,18 +769,18 @@ int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn, bool row_
     }
     // measured corrections of the model (scratch/mb_rep.py, un-profiled back-to-back launches on MI355X): at N ~ 1536 the 128 x 256
     // tile (240-252 workgroups, 64 x 64 per wave) beats the 160/192-row tiles the model prefers by 10-15 %
-    if (!force_bm && !row_stat && cus == 256 && M >= 4096 && N > 1024 && N < 2048)
+    if (!force_bm && !row_stat && cus == 256 && M + M2 >= 4096 && N > 1024 && N < 2048)
         for (int i = 0; i < kNumTiles; ++i)
             if (kTiles[i].bm == 128 && kTiles[i].bn == 256) return i;
     return best;
 }
 
-bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a) {
-    // (the LayerNorm-fold / row-statistics forms exist only here: they take this kernel at any row count)
+bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a, bool any_rows) {
+    // (the LayerNorm-fold / row-statistics forms exist only here: they take this kernel at any row count; so do a forced tile and a pair)
     const bool fold_ok = !a.fold_s || (a.fold_c && a.fold_stat && a.fold_n > 0.f && !a.bias && a.alpha == 1.f && !a.R && !a.maskY && !a.C2 && !a.rowtab &&
                                        !a.accumulate);
     return dtype == BLT_BF16 && !a.transA && !a.transB && !a.is_conv && !a.out_f32 && a.split_k == 0 && !a.stat_sum && !a.ln_out && !a.lnA_out &&
-           !a.a_rowsum && a.lda % 8 == 0 && a.ldb % 8 == 0 && fold_ok && (a.M >= 256 || a.fold_s || a.out_stat);
+           !a.a_rowsum && a.lda % 8 == 0 && a.ldb % 8 == 0 && fold_ok && (a.M >= 256 || a.fold_s || a.out_stat || a.nt2_bm > 0 || any_rows);
 }
 
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm, int force_bn) {
@@ -746,9 +791,31 @@ int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm, int force_bn) {
     BLT_REQUIRE(!a.fold_s || (a.fold_np >= 1 && a.fold_np <= a.stat_slots), "gemm_nt2: fold_np %d outside [1, stat_slots %d]", a.fold_np, a.stat_slots);
     return kTiles[i].launch(a, s);
 }
-void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat) {
-    const int i = blt_gemm_nt2_plan(M, N, K, 0, 0, row_stat);
+void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat, int M2) {
+    const int i = blt_gemm_nt2_plan(M, N, K, 0, 0, row_stat, M2);
     *bm = kTiles[i].bm; *bn = kTiles[i].bn;
+}
+
+// Paired launch: a and b are the same Linear position of two stacks — equal N, K and epilogue terms (checked), their own operands.
+bool blt_gemm_nt2_pair_ok(int dtype, const GemmArgs& a, const GemmArgs& b) {
+    auto same_null = [](const void* x, const void* y) { return (x == nullptr) == (y == nullptr); };
+    return blt_gemm_nt2_ok(dtype, a, true) && blt_gemm_nt2_ok(dtype, b, true) && a.N == b.N && a.K == b.K && a.alpha == b.alpha && a.relu == b.relu &&
+           a.drop_p == b.drop_p && a.seed == b.seed && a.mask_scale == b.mask_scale && a.accumulate == b.accumulate && !a.rowtab && !b.rowtab &&
+           same_null(a.bias, b.bias) && same_null(a.maskY, b.maskY) && same_null(a.C2, b.C2) && same_null(a.R, b.R) && same_null(a.fold_s, b.fold_s) &&
+           same_null(a.fold_mean, b.fold_mean) && same_null(a.out_stat, b.out_stat) && a.stat_slots == b.stat_slots && a.fold_np == b.fold_np &&
+           a.fold_n == b.fold_n && a.fold_eps == b.fold_eps && a.nt2_bm == b.nt2_bm && a.nt2_bn == b.nt2_bn;
+}
+int blt_gemm_nt2_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
+    const int i = blt_gemm_nt2_plan(a.M, a.N, a.K, a.nt2_bm, a.nt2_bn, a.out_stat != nullptr, b.M);
+    BLT_REQUIRE(i >= 0, "gemm_nt2_pair: no tile %dx%d compiled in", a.nt2_bm, a.nt2_bn);
+    BLT_REQUIRE(!a.out_stat || cdiv(a.N, kTiles[i].bn) <= a.stat_slots, "gemm_nt2_pair: %d column tiles but only %d statistics slots per row",
+                cdiv(a.N, kTiles[i].bn), a.stat_slots);
+    BLT_REQUIRE(!a.fold_s || (a.fold_np >= 1 && a.fold_np <= a.stat_slots), "gemm_nt2_pair: fold_np %d outside [1, stat_slots %d]", a.fold_np, a.stat_slots);
+    GemmPair d;
+    d.M = b.M; d.A = b.A; d.lda = b.lda; d.B = b.B; d.ldb = b.ldb; d.C = b.C; d.ldc = b.ldc; d.bias = b.bias; d.maskY = b.maskY; d.ldm = b.ldm;
+    d.C2 = b.C2; d.ldc2 = b.ldc2; d.R = b.R; d.ldr = b.ldr; d.stream_id = b.stream_id; d.fold_s = b.fold_s; d.fold_c = b.fold_c;
+    d.fold_stat = b.fold_stat; d.fold_mean = b.fold_mean; d.fold_rstd = b.fold_rstd; d.out_stat = b.out_stat;
+    return kTiles[i].launch_pair(a, d, s);
 }
 
 // ---- grouped weight gradients ----------------------------------------------------------------------------------------------

@@ -55,6 +55,7 @@ struct GemmArgs {
     int no_dma = 0;              // 1 = force the register-staged kernel (A/B testing of the LDS-DMA ring)
     int split_k = 0;             // max K-splits (fp32 atomic accumulation) for the weight-gradient form; 0 = off
     ConvGeom cg = {};
+
     int force_tile = 0;          // 0 = heuristic, 64 or 128
     float* a_rowsum = nullptr;   // transA only: a_rowsum[m] += sum_k op(A)[m,k]  (bias gradient of the weight-gradient form, float atomics)
     // Fused LayerNorm of the result rows (bf16, k-contiguous operands, N <= 256 so that one workgroup owns whole rows): after the
@@ -96,16 +97,37 @@ struct GemmArgs {
     float* out_stat = nullptr;
     int stat_slots = 1;
 };
+
+// The second problem of a paired planned-tile launch (gemm2.hip: gemm_nt2_pair_kernel): same N, K, tile shape and epilogue terms as the
+// GemmArgs it rides with; its own operands, leading dimensions, row count and dropout stream.
+struct GemmPair {
+    int tiles1 = 0;      // row tiles of problem 1 (filled in by the launcher)
+    int M = 0;
+    const void* A = nullptr; int lda = 0;
+    const void* B = nullptr; int ldb = 0;
+    void* C = nullptr; int ldc = 0;
+    const float* bias = nullptr;
+    const void* maskY = nullptr; int ldm = 0;
+    void* C2 = nullptr; int ldc2 = 0;
+    const void* R = nullptr; int ldr = 0;
+    uint32_t stream_id = 0;
+    const float* fold_s = nullptr; const float* fold_c = nullptr; const float* fold_stat = nullptr;
+    float* fold_mean = nullptr; float* fold_rstd = nullptr;
+    float* out_stat = nullptr;
+};
 int blt_gemm(int dtype, const GemmArgs& a, hipStream_t stream);
+int blt_gemm_validate(int dtype, const GemmArgs& a);      // the operand checks of blt_gemm alone
 int blt_gemm_stat_rows(const GemmArgs& a, int dtype);   // number of partial rows written to stat_sum/stat_sq (2*tiles_m)
 int blt_gemm_tile(const GemmArgs& a, int dtype);
 void blt_debug_set(int key, int value);
 int blt_debug_get(int key);      // keys 4..6: A/B switches of conv_pp.hip (4 = force BN 64/128, 5 = XCD mapping 1 chunked / 2 round-robin, 6 = ring 1 deep / 2 shallow)
 int blt_gemm_splits(const GemmArgs& a, int dtype);
 // gemm2.hip: one-round-per-chip NT GEMM (bf16, k-contiguous operands, bf16 output): tile shape planned per problem
-bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a);
+bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a, bool any_rows = false);
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm = 0, int force_bn = 0);
-void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat = false);      // row_stat: a launch with out_stat (no 192-column tiles)
+void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat = false, int M2 = 0);      // row_stat: a launch with out_stat (no 192-column tiles); M2: rows of a paired launch's second problem
+bool blt_gemm_nt2_pair_ok(int dtype, const GemmArgs& a, const GemmArgs& b);
+int blt_gemm_nt2_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 // CUs the launch planners size a "round" for: 256 (the chip) unless the dependent chain runs on a CU partition (engine_set_cu_masks)
 int blt_hw_id_probe(int* out, int n_wg, int spin_ticks, hipStream_t s);      // misc.hip (experiments build)
 void blt_set_plan_cus(int n);      // 0 = the whole chip

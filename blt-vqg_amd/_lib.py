@@ -35,7 +35,7 @@ class Config(ctypes.Structure):
 
 
 class LinearDesc(ctypes.Structure):
-    """struct bltvqg_linear_desc (include/bltvqg_hip.h): one problem of bltvqg_linear_pair."""
+    """struct bltvqg_linear_desc (include/bltvqg_hip_experiments.h): one problem of bltvqg_linear_pair."""
     _fields_ = [
         ("A", ctypes.c_void_p), ("lda", ctypes.c_int32), ("W", ctypes.c_void_p), ("ldw", ctypes.c_int32), ("C", ctypes.c_void_p), ("ldc", ctypes.c_int32),
         ("M", ctypes.c_int32), ("bias", ctypes.c_void_p), ("maskY", ctypes.c_void_p), ("ldm", ctypes.c_int32), ("C2", ctypes.c_void_p), ("ldc2", ctypes.c_int32),
@@ -57,7 +57,6 @@ SIGNATURES = {
     "bltvqg_gemm_rowstat_parts": (I, [I, I, I, I]),
     "bltvqg_ln_fold_prepare": (I, [P, I, I, P, P, P, P, P, P, P]),
     "bltvqg_linear_ln_folded": (I, [P, I, P, I, P, I, I, I, I, P, P, P, I, I, P, P, F, I, F, U64, U32, I, I, P]),
-    "bltvqg_linear_pair": (I, [P, P, I, I, I, F, U64, F, I, I, F, I, I, P]),
     "bltvqg_linear_wgrad_group": (I, [I, P, P, P, P, P, P, P, P, P, P, P, L, P]),
     "bltvqg_linear_wgrad": (I, [I, P, I, P, I, P, I, P, I, I, I, I, P]),
     "bltvqg_conv2d": (I, [I, P, P, P, I, I, I, I, I, I, I, I, I, P, P, P]),
@@ -162,6 +161,7 @@ EXPERIMENT_SIGNATURES = {
     "bltvqg_linear_layernorm": (I, [P, I, P, I, P, I, F, U64, U32, P, I, P, I, P, I, P, P, F, P, P, P, I, I, I, P]),
     "bltvqg_attn_out_fwd": (I, [P, I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
     "bltvqg_hw_id_probe": (I, [P, I, I, P]),
+    "bltvqg_linear_pair": (I, [P, P, I, I, I, F, U64, F, I, I, F, I, I, P]),
 }
 EXP_LIB_PATH = os.environ.get("BLTVQG_EXP_LIB") or os.path.join(_HERE, "libbltvqg_hip_exp.so")
 _exp_lib = None

@@ -91,6 +91,7 @@ int bltvqg_linear_ln_folded(const void* X, int ldx, const void* Wf, int ldw, voi
     return blt_gemm(BLT_BF16, g, (hipStream_t)stream);
 }
 
+#ifdef BLT_EXPERIMENTS
 int bltvqg_linear_pair(const bltvqg_linear_desc* p1, const bltvqg_linear_desc* p2, int N, int K, int relu, float drop_p, uint64_t seed, float mask_scale,
                        int stat_slots, int stat_parts, float eps, int tile_m, int tile_n, void* stream) {
     BLT_REQUIRE(p1 && p2 && N > 0 && K > 0, "linear_pair: null descriptor / bad shape");
@@ -115,6 +116,7 @@ int bltvqg_linear_pair(const bltvqg_linear_desc* p1, const bltvqg_linear_desc* p
                 "linear_pair: the two problems must both fit the planned-tile kernel (bf16 NT, ld %% 8 == 0) and carry the same epilogue terms");
     return blt_gemm_nt2_pair(g[0], g[1], (hipStream_t)stream);
 }
+#endif
 
 int bltvqg_linear_wgrad_group(int n, const void* const* dY, const int32_t* ldy, const void* const* X, const int32_t* ldx, float* const* dW,
                               const int32_t* ldw, float* const* dbias, const int32_t* rows, const int32_t* N, const int32_t* K, void* table_dev,

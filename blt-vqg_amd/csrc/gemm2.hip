@@ -412,6 +412,7 @@ __global__ __launch_bounds__(C::NT) void gemm_nt2_kernel(const GemmArgs p) {
     nt2_body<C, FOLD>(p, blockIdx.x % tiles_m, blockIdx.x / tiles_m);
 }
 
+#ifdef BLT_EXPERIMENTS
 // Two problems in one launch (GemmPair: the encoder stack's and the posterior encoder stack's Linear of the same layer position — same
 // N, K, tile shape and epilogue terms, their own operands, weights and row counts): a column of the launch holds problem 1's row tiles,
 // then problem 2's.  One launch fills the CUs with both problems' tiles instead of two launches sharing them by time-slicing, and the
@@ -453,6 +454,7 @@ template <typename C>
 int launch_nt2_pair(const GemmArgs& a, const GemmPair& d, hipStream_t s) {
     return a.fold_s ? launch_nt2_pair_<C, true>(a, d, s) : launch_nt2_pair_<C, false>(a, d, s);
 }
+#endif
 
 template <typename C, bool FOLD>
 int launch_nt2_(const GemmArgs& a, hipStream_t s) {
@@ -725,8 +727,13 @@ __global__ __launch_bounds__(C::NT) void wgrad_group_kernel(const blt_wg_problem
 }
 
 // tile shapes compiled in: BM x BN, 8 waves as NWM x NWN, ring depth
+#ifdef BLT_EXPERIMENTS
 struct TileOpt { int bm, bn; int (*launch)(const GemmArgs&, hipStream_t); int (*launch_pair)(const GemmArgs&, const GemmPair&, hipStream_t); };
 #define NT2(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN>>, launch_nt2_pair<Nt2<BM, BN, NWM, NWN>>}
+#else
+struct TileOpt { int bm, bn; int (*launch)(const GemmArgs&, hipStream_t); };
+#define NT2(BM, BN, NWM, NWN) {BM, BN, launch_nt2<Nt2<BM, BN, NWM, NWN>>}
+#endif
 const TileOpt kTiles[] = {
     NT2(64, 64, 2, 4),   NT2(64, 128, 2, 4),  NT2(128, 64, 4, 2),  NT2(128, 128, 2, 4),
     NT2(160, 64, 2, 4),  NT2(160, 128, 2, 4), NT2(192, 64, 4, 2),  NT2(96, 64, 2, 4),   NT2(32, 64, 2, 4),
@@ -796,6 +803,8 @@ void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat, int
     *bm = kTiles[i].bm; *bn = kTiles[i].bn;
 }
 
+#ifdef BLT_EXPERIMENTS
+// (experiments build: measured in the train step and not adopted — DESIGN.md 9; profiles/r04_pair_*)
 // Paired launch: a and b are the same Linear position of two stacks — equal N, K and epilogue terms (checked), their own operands.
 bool blt_gemm_nt2_pair_ok(int dtype, const GemmArgs& a, const GemmArgs& b) {
     auto same_null = [](const void* x, const void* y) { return (x == nullptr) == (y == nullptr); };
@@ -817,6 +826,7 @@ int blt_gemm_nt2_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     d.fold_stat = b.fold_stat; d.fold_mean = b.fold_mean; d.fold_rstd = b.fold_rstd; d.out_stat = b.out_stat;
     return kTiles[i].launch_pair(a, d, s);
 }
+#endif
 
 // ---- grouped weight gradients ----------------------------------------------------------------------------------------------
 bool blt_wgrad_group_ok(int dtype, const GemmArgs& a) {

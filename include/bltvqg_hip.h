@@ -87,28 +87,6 @@ int bltvqg_ln_fold_prepare(const float* W, int N, int K, const float* gamma, con
 int bltvqg_linear_ln_folded(const void* X, int ldx, const void* Wf, int ldw, void* Y, int ldy, int M, int N, int K, const float* fold_s, const float* fold_c,
                             const float* row_stat, int stat_slots, int stat_parts, float* mean, float* rstd, float eps, int relu, float drop_p, uint64_t seed,
                             uint32_t stream_id, int tile_m, int tile_n, void* stream);
-/* Two Linear problems in ONE launch of the planned-tile kernel (round 4).  The encoder stack and the posterior encoder stack of the reference
- * (models/iq.py:31-34: two Encoder instances of the same shape, run one after the other in IQ.forward, iq.py:66-78) execute the same Linear
- * positions on different rows with different weights; paired, a launch fills the chip with both problems' tiles instead of two launches
- * time-slicing it.  The two problems share N, K, the tile shape and the epilogue terms (relu, dropout p / seed, mask_scale, and WHICH
- * optional operands are present: bias, maskY, C2, R, fold_*, mean / rstd, out_stat must be NULL in both or in neither); operands, leading
- * dimensions, row counts and dropout streams are their own.  Results are bit-identical to the two separate launches at the same tile shape.
- * fold_s != NULL selects bltvqg_linear_ln_folded's form (row_stat / stat_parts / mean / rstd / eps), out_stat != NULL bltvqg_gemm_rowstat's. */
-typedef struct bltvqg_linear_desc {
-    const void* A; int32_t lda;          /* [M, lda] bf16 rows */
-    const void* W; int32_t ldw;          /* [N, ldw] bf16 weight (the gamma-scaled shadow for the folded form) */
-    void* C; int32_t ldc;                /* [M, ldc] bf16 result */
-    int32_t M;
-    const float* bias;
-    const void* maskY; int32_t ldm;
-    void* C2; int32_t ldc2;
-    const void* R; int32_t ldr;
-    uint32_t stream_id;
-    const float* fold_s; const float* fold_c; const float* row_stat; float* mean; float* rstd;
-    float* out_stat;
-} bltvqg_linear_desc;
-int bltvqg_linear_pair(const bltvqg_linear_desc* p1, const bltvqg_linear_desc* p2, int N, int K, int relu, float drop_p, uint64_t seed, float mask_scale,
-                       int stat_slots, int stat_parts, float eps, int tile_m, int tile_n, void* stream);
 /* Weight gradients of n Linear layers in ONE launch (bf16 operands, fp32 results): dW_i[N_i, K_i] = dY_i[rows_i, N_i]^T X_i[rows_i, K_i]
  * and dbias_i[N_i] = column sums of dY_i (dbias_i may be NULL).  Results are STORED unless the launch is short of tiles and slices
  * the contraction (then they are atomically added: dW / dbias must be zero on entry, as the engine's gradient buffer is).  The

@@ -50,6 +50,31 @@ int bltvqg_attn_out_fwd(const void* Q, int ldq, const void* K, int ldk, const vo
                         const void* R, int ldr, void* Y, int ldy, const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal,
                         float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);
 
+/* Two Linear problems in ONE launch of the planned-tile kernel (round 4).  The encoder stack and the posterior encoder stack of the reference
+ * (models/iq.py:31-34: two Encoder instances of the same shape, run one after the other in IQ.forward, iq.py:66-78) execute the same Linear
+ * positions on different rows with different weights; paired, a launch fills the chip with both problems' tiles instead of two launches
+ * time-slicing it.  The two problems share N, K, the tile shape and the epilogue terms (relu, dropout p / seed, mask_scale, and WHICH
+ * optional operands are present: bias, maskY, C2, R, fold_*, mean / rstd, out_stat must be NULL in both or in neither); operands, leading
+ * dimensions, row counts and dropout streams are their own.  Results are bit-identical to the two separate launches at the same tile shape.
+ * fold_s != NULL selects bltvqg_linear_ln_folded's form (row_stat / stat_parts / mean / rstd / eps), out_stat != NULL bltvqg_gemm_rowstat's.
+ * The train-step engine does NOT use it: run in lockstep on one stream the two stacks lose the overlap two streams give them — the launch
+ * gaps of one chain are the other chain's run time (forward: 6.79 against 6.79 ms / step, backward: 7.12 against 6.79, profiles/r04_pair_ab_*;
+ * the engine side of the experiment is profiles/r04_pair_engine.patch). */
+typedef struct bltvqg_linear_desc {
+    const void* A; int32_t lda;          /* [M, lda] bf16 rows */
+    const void* W; int32_t ldw;          /* [N, ldw] bf16 weight (the gamma-scaled shadow for the folded form) */
+    void* C; int32_t ldc;                /* [M, ldc] bf16 result */
+    int32_t M;
+    const float* bias;
+    const void* maskY; int32_t ldm;
+    void* C2; int32_t ldc2;
+    const void* R; int32_t ldr;
+    uint32_t stream_id;
+    const float* fold_s; const float* fold_c; const float* row_stat; float* mean; float* rstd;
+    float* out_stat;
+} bltvqg_linear_desc;
+int bltvqg_linear_pair(const bltvqg_linear_desc* p1, const bltvqg_linear_desc* p2, int N, int K, int relu, float drop_p, uint64_t seed, float mask_scale,
+                       int stat_slots, int stat_parts, float eps, int tile_m, int tile_n, void* stream);
 /* Diagnostic: n_workgroups one-wave workgroups each write {HW_REG_HW_ID, XCC id} to out[2 * workgroup] after spinning spin_ticks of the
  * 100 MHz wall clock (so that they spread over every CU the stream may use): which CUs a (CU-masked) stream's work lands on. */
 int bltvqg_hw_id_probe(int32_t* out, int n_workgroups, int spin_ticks, void* stream);

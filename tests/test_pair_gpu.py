@@ -1,4 +1,5 @@
-"""Two Linear problems in one planned-tile launch (gemm2.hip::gemm_nt2_pair_kernel, bltvqg_linear_pair) through the C ABI.
+"""Two Linear problems in one planned-tile launch (gemm2.hip::gemm_nt2_pair_kernel, bltvqg_linear_pair) through the C ABI of the EXPERIMENTS
+library (include/bltvqg_hip_experiments.h: built, bit-identical, measured in the train step, not adopted — DESIGN.md 9).
 
 Reference call sites: the encoder stack and the posterior encoder stack (models/iq.py:31-34, run back to back in IQ.forward, iq.py:66-78)
 execute the same Linear positions (models/transformer_layers.py:260-275: q|k|v, attention output, the two FFN layers) on different rows
@@ -35,7 +36,7 @@ def _desc(**kw):
 def _pair(d1, d2, N, K, tile, relu=0, drop_p=0.0, seed=0, mask_scale=1.0, slots=0, parts=0, eps=1e-5):
     import gpu_ops as G
     from bltvqg_amd._lib import stream_ptr
-    return G.lib().bltvqg_linear_pair(ctypes.byref(d1), ctypes.byref(d2), N, K, int(relu), float(drop_p), int(seed), float(mask_scale), slots, parts,
+    return G.exp_lib().bltvqg_linear_pair(ctypes.byref(d1), ctypes.byref(d2), N, K, int(relu), float(drop_p), int(seed), float(mask_scale), slots, parts,
                                       float(eps), tile[0], tile[1], stream_ptr())
 
 
@@ -175,7 +176,7 @@ def test_pair_planned_tile_against_float64():
 
 
 def test_pair_refuses_mismatched_epilogue_terms():
-    from bltvqg_amd._lib import load
+    import gpu_ops as G
     g = torch.Generator().manual_seed(1)
     M, N, K = 300, 128, 64
     A, W, b, R = _operands(M, N, K, g)
@@ -184,7 +185,7 @@ def test_pair_refuses_mismatched_epilogue_terms():
     d1 = _desc(A=A, lda=K, W=W, ldw=K, C=C1, ldc=N, M=M, bias=b)
     d2 = _desc(A=A, lda=K, W=W, ldw=K, C=C2, ldc=N, M=M)                # no bias
     assert _pair(d1, d2, N, K, (0, 0)) != 0
-    assert b"same epilogue" in load().bltvqg_last_error_string()
+    assert b"same epilogue" in G.exp_lib().bltvqg_last_error_string()
     d3 = _desc(A=A, lda=K + 4, W=W, ldw=K, C=C2, ldc=N, M=M, bias=b)     # pitch not a multiple of 8
     assert _pair(d1, d3, N, K, (0, 0)) != 0
     d4 = _desc(A=A, lda=K, W=W, ldw=K, C=C2, ldc=N, M=0, bias=b)

@@ -243,6 +243,47 @@ __global__ __launch_bounds__(256) void img_pack_c3_kernel(const float* __restric
     }
 }
 
+// bf16, W % 4 == 0, Wp even, Wp <= 256: one WAVE per padded output row (four rows per workgroup).  A lane reads FOUR pixels of each plane as
+// one 16-byte load (coalesced along w), the row is assembled in LDS ([Wp] x 8 bytes, pad pixels zero) and leaves as 16-byte stores that are
+// consecutive across the wave — the per-pixel form above moves 4-byte loads and 8-byte stores (217 us for 263 MB at B = 256: 1.2 TB/s).
+__global__ __launch_bounds__(256) void img_pack_c3v_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int N, int H, int W, int pt, int pl, int Hp,
+                                                           int Wp) {
+    __shared__ __attribute__((aligned(16))) s16x4 row[4][256];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * 4 + wv;          // padded row index over the batch
+    const bool live = r < (long)N * Hp;
+    const int hp = live ? (int)(r % Hp) : 0;
+    const long n = live ? r / Hp : 0;
+    const int h = hp - pt;
+    const bool row_in = live && (unsigned)h < (unsigned)H;
+    const long plane = (long)H * W;
+    const float* p = src + (n * 3 * H + (row_in ? h : 0)) * W;
+    const s16x4 z = {0, 0, 0, 0};
+    if (row_in) {
+        for (int q = lane; q < W / 4; q += 64) {
+            const float4 a = *reinterpret_cast<const float4*>(p + 4 * q);
+            const float4 b = *reinterpret_cast<const float4*>(p + plane + 4 * q);
+            const float4 c = *reinterpret_cast<const float4*>(p + 2 * plane + 4 * q);
+            const float va[4] = {a.x, a.y, a.z, a.w}, vb[4] = {b.x, b.y, b.z, b.w}, vc[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                s16x4 o;
+                o[0] = __builtin_bit_cast(short, from_f32<bf16>(va[i])); o[1] = __builtin_bit_cast(short, from_f32<bf16>(vb[i]));
+                o[2] = __builtin_bit_cast(short, from_f32<bf16>(vc[i])); o[3] = 0;
+                row[wv][pl + 4 * q + i] = o;
+            }
+        }
+        for (int j = lane; j < Wp - W; j += 64) row[wv][j < pl ? j : W + j] = z;      // left / right border pixels
+    } else {
+        for (int wp = lane; wp < Wp; wp += 64) row[wv][wp] = z;                       // top / bottom border rows
+    }
+    __syncthreads();
+    if (!live) return;
+    uint4* o = reinterpret_cast<uint4*>(dst + r * (long)Wp * 4);
+    const uint4* rs = reinterpret_cast<const uint4*>(&row[wv][0]);
+    for (int i = lane; i < Wp / 2; i += 64) o[i] = rs[i];
+}
+
 // conv weight [Cout, Cin, KH, KW] fp32 -> [Cout, KH, KWpad, Cpad] T (k index = (r*KWpad + s)*Cpad + c)
 template <typename T>
 __global__ void conv_pack_w_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH, int KW, int Cpad, int KWpad) {
@@ -1012,6 +1053,10 @@ int blt_img_pack(int dtype, const float* nchw, void* nhwc, int N, int C, int H, 
     BLT_REQUIRE(nchw && nhwc && N > 0 && C > 0 && C <= Cpad && H > 0 && W > 0 && pt >= 0 && pl >= 0 && Hp >= H + pt && Wp >= W + pl, "img_pack: bad args");
     const long n = (long)N * Hp * Wp;
     if (C == 3 && Cpad == 4 && (long)N * Hp < (1l << 31) && ((uintptr_t)nhwc % 16) == 0) {
+        if (dtype == BLT_BF16 && W % 4 == 0 && Wp % 2 == 0 && Wp <= 256 && ((uintptr_t)nchw % 16) == 0 && blt_debug_get(27) != 1) {      // (key 27 = 1: A/B, the per-pixel form)
+            hipLaunchKernelGGL(img_pack_c3v_kernel, dim3((unsigned)(((long)N * Hp + 3) / 4)), dim3(256), 0, s, nchw, (bf16*)nhwc, N, H, W, pt, pl, Hp, Wp);
+            return blt_check_launch("img_pack");
+        }
         if (dtype == BLT_F32) hipLaunchKernelGGL(img_pack_c3_kernel<float>, dim3((unsigned)(N * Hp)), dim3(256), 0, s, nchw, (float*)nhwc, H, W, pt, pl, Hp, Wp);
         else hipLaunchKernelGGL(img_pack_c3_kernel<bf16>, dim3((unsigned)(N * Hp)), dim3(256), 0, s, nchw, (bf16*)nhwc, H, W, pt, pl, Hp, Wp);
         return blt_check_launch("img_pack");

@@ -878,3 +878,25 @@ def test_layernorm_folded_into_consumer_linear(shape):
     if use_bias:
         ref = ref + bias
     assert (C.float().cpu() - ref).abs().max() < 2e-2 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("geom", [(3, 224, 224, 230, 232), (5, 32, 56, 38, 62), (2, 30, 50, 36, 56), (1, 8, 260, 14, 266), (7, 12, 16, 20, 24)])
+@pytest.mark.parametrize("form", [0, 1])
+def test_img_pack_stem_layout(geom, form):
+    """fp32 NCHW image -> the stem's zero-bordered NHWC4 bf16 image (image at (3, 3); channel 3 and every border pixel zero): the
+    16-byte-vectorised form (one wave per padded row), the per-pixel form (debug key 27 = 1; also taken when W % 4 != 0 or the row is wider
+    than 256 pixels) — both exact against torch (one bf16 rounding per value).  Reference: the image tensor EncoderCNN.forward hands to
+    torchvision's conv1 (models/encoder_cnn.py:33)."""
+    import gpu_ops as G
+    N, H, W, Hp, Wp = geom
+    g = torch.Generator().manual_seed(H + W)
+    x = torch.randn(N, 3, H, W, generator=g)
+    G.lib().bltvqg_debug_set(27, form)
+    try:
+        out = G.img_pack(x.cuda(), torch.bfloat16, 4, 3, 3, Hp, Wp)
+        torch.cuda.synchronize()
+    finally:
+        G.lib().bltvqg_debug_set(27, 0)
+    ref = torch.zeros(N, Hp, Wp, 4, dtype=torch.bfloat16)
+    ref[:, 3:3 + H, 3:3 + W, :3] = x.permute(0, 2, 3, 1).bfloat16()
+    assert torch.equal(out.cpu(), ref)

@@ -89,6 +89,7 @@ SIGNATURES = {
     "bltvqg_bn1d_fwd": (I, [I, P, P, P, P, P, P, P, P, I, I, F, F, P]),
     "bltvqg_bn1d_bwd": (I, [I, P, P, P, P, P, P, P, P, I, I, P]),
     "bltvqg_attn_fwd": (I, [I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
+    "bltvqg_attn_fwd_rows": (I, [I, P, I, I, P, I, P, I, I, P, I, P, I, I, I, I, I, I, F, P]),
     "bltvqg_attn_bwd": (I, [I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, P, I, I, I, I, I, I, F, F, U64, U32, P]),
     "bltvqg_embed_gather": (I, [I, P, P, P, L, I, I, P]),
     "bltvqg_embed_scatter": (I, [I, P, I, P, P, L, I, I, P]),

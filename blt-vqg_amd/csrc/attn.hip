@@ -33,21 +33,22 @@ __device__ __forceinline__ float dot_rows(const float* a, const float* b, int d)
 
 // head slice [Tn, d] of a packed projection -> fp32 LDS rows of d+1 floats; 16-byte global loads when the layout allows
 template <typename T>
-__device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int b, int Tn, int h, int d, float* dst, int lane) {
+__device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int b, int Tn, int h, int d, float* dst, int lane, int rows = 0) {
     const int dp = att_dp(d);
+    if (rows == 0) rows = Tn;      // rows per batch element of the tensor (>= Tn: only the first Tn are loaded)
     if ((d & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)src) & 15) == 0) {
         const int d8 = d >> 3;
         for (int idx = lane; idx < Tn * d8; idx += ATT_THREADS) {
             const int i = idx / d8, c = (idx - i * d8) * 8;
             float v[8];
-            Vec8<T>::load(src + (size_t)(b * Tn + i) * ld + h * d + c, v);
+            Vec8<T>::load(src + (size_t)(b * rows + i) * ld + h * d + c, v);
             Vec8<float>::store(dst + i * dp + c, v);          // rows are 16-byte aligned (dp % 4 == 0)
         }
         return;
     }
     for (int idx = lane; idx < Tn * d; idx += ATT_THREADS) {
         const int i = idx / d, c = idx - i * d;
-        dst[i * dp + c] = to_f32(src[(size_t)(b * Tn + i) * ld + h * d + c]);
+        dst[i * dp + c] = to_f32(src[(size_t)(b * rows + i) * ld + h * d + c]);
     }
 }
 
@@ -55,8 +56,9 @@ __device__ __forceinline__ void load_head(const T* __restrict__ src, int ld, int
 // TRANS = false: out[i,c] = sum_j Wt[i*tp + j] * X[j*dp + c]   (rows of W);  TRANS = true: out[j,c] = sum_i Wt[i*tp + j] * X[i*dp + c]
 template <typename T, bool TRANS>
 __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, int nJ, const float* X, int dp, int d, float scale,
-                                             T* __restrict__ out, int ld, int b, int h, int lane) {
+                                             T* __restrict__ out, int ld, int b, int h, int lane, int orows = 0) {
     const int nOut = TRANS ? nJ : nI, nRed = TRANS ? nI : nJ;
+    if (orows == 0) orows = nOut;      // rows per batch element of `out`
     const bool vec = (d & 7) == 0 && (ld & 7) == 0 && (((uintptr_t)out) & 15) == 0;
     if (vec) {
         const int d8 = d >> 3;
@@ -73,7 +75,7 @@ __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, in
             }
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[e] *= scale;
-            Vec8<T>::store(out + (size_t)(b * nOut + o) * ld + h * d + c, acc);
+            Vec8<T>::store(out + (size_t)(b * orows + o) * ld + h * d + c, acc);
         }
         return;
     }
@@ -81,7 +83,7 @@ __device__ __forceinline__ void matmul_store(const float* Wt, int tp, int nI, in
         const int o = idx / d, c = idx - o * d;
         float acc = 0.f;
         for (int r = 0; r < nRed; ++r) acc += (TRANS ? Wt[r * tp + o] : Wt[o * tp + r]) * X[r * dp + c];
-        out[(size_t)(b * nOut + o) * ld + h * d + c] = from_f32<T>(acc * scale);
+        out[(size_t)(b * orows + o) * ld + h * d + c] = from_f32<T>(acc * scale);
     }
 }
 
@@ -93,7 +95,7 @@ __device__ __forceinline__ void scores_softmax(const AttnArgs& a, int b, const f
     for (int idx = lane; idx < a.Tq * a.Tk; idx += ATT_THREADS) {
         const int i = idx / a.Tk, j = idx - i * a.Tk;
         const float acc = dot_rows(Qs + i * dp, Ks + j * dp, a.d);
-        const bool masked = (a.key_ids != nullptr && a.key_ids[b * a.Tk + j] == 0) || (a.causal == 1 && j > i);
+        const bool masked = (a.key_ids != nullptr && a.key_ids[b * (a.k_rows ? a.k_rows : a.Tk) + j] == 0) || (a.causal == 1 && j > i);
         // causal == 2: a future key does not exist for this query (greedy decoding re-runs the decoder on the PREFIX, iq.py:134-141),
         // so it is excluded from the softmax instead of being filled with -1e18 (matters only for fully pad-masked rows)
         Pn[i * tp + j] = (a.causal == 2 && j > i) ? -INFINITY : (masked ? -1e18f : acc * a.scale);
@@ -139,9 +141,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnArgs a)
     float* Ks = Qs + a.Tq * dp;
     float* Vs = Ks + a.Tk * dp;
     float* Pn = Vs + a.Tk * dp;
-    load_head((const T*)a.Q, a.ldq, b, a.Tq, h, a.d, Qs, lane);
-    load_head((const T*)a.K, a.ldk, b, a.Tk, h, a.d, Ks, lane);
-    load_head((const T*)a.V, a.ldv, b, a.Tk, h, a.d, Vs, lane);
+    load_head((const T*)a.Q, a.ldq, b, a.Tq, h, a.d, Qs, lane, a.q_rows);
+    load_head((const T*)a.K, a.ldk, b, a.Tk, h, a.d, Ks, lane, a.k_rows);
+    load_head((const T*)a.V, a.ldv, b, a.Tk, h, a.d, Vs, lane, a.k_rows);
     __syncthreads();
     scores_softmax(a, b, Qs, Ks, Pn, lane);
     if (a.drop_p > 0.f) {
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const AttnArgs a)
         }
         __syncthreads();
     }
-    matmul_store<T, false>(Pn, tp, a.Tq, a.Tk, Vs, dp, a.d, 1.f, (T*)a.O, a.ldo, b, h, lane);
+    matmul_store<T, false>(Pn, tp, a.Tq, a.Tk, Vs, dp, a.d, 1.f, (T*)a.O, a.ldo, b, h, lane, a.q_rows);
 }
 
 template <typename T>
@@ -285,7 +287,7 @@ __device__ __forceinline__ void softmax_t(const AttnArgs& a, const MfmaHead& m, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * jt + 4 * m.g + r;
-            kid[jt][r] = (a.key_ids != nullptr && j < a.Tk) ? a.key_ids[m.b * a.Tk + j] : 1;
+            kid[jt][r] = (a.key_ids != nullptr && j < a.Tk) ? a.key_ids[m.b * (a.k_rows ? a.k_rows : a.Tk) + j] : 1;
         }
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
@@ -366,9 +368,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     m.b = m.hb / a.heads; m.h = m.hb % a.heads; m.n16 = lane & 15; m.g = lane >> 4;
     char* vimg = smc + w * (32 * PITCH);
     bf16x8 kf[2][KS], qf[2][KS], vf[2][KS];
-    load_slice<D>((const bf16*)a.K + (size_t)m.b * a.Tk * a.ldk + m.h * D, a.ldk, a.Tk, m, kf, nullptr);
-    load_slice<D>((const bf16*)a.Q + (size_t)m.b * a.Tq * a.ldq + m.h * D, a.ldq, a.Tq, m, qf, nullptr);
-    load_slice<D>((const bf16*)a.V + (size_t)m.b * a.Tk * a.ldv + m.h * D, a.ldv, a.Tk, m, vf, vimg);
+    const size_t qr = a.q_rows ? a.q_rows : a.Tq, kr = a.k_rows ? a.k_rows : a.Tk;      // rows per batch element of the tensors
+    load_slice<D>((const bf16*)a.K + (size_t)m.b * kr * a.ldk + m.h * D, a.ldk, a.Tk, m, kf, nullptr);
+    load_slice<D>((const bf16*)a.Q + (size_t)m.b * qr * a.ldq + m.h * D, a.ldq, a.Tq, m, qf, nullptr);
+    load_slice<D>((const bf16*)a.V + (size_t)m.b * kr * a.ldv + m.h * D, a.ldv, a.Tk, m, vf, vimg);
     f32x4 st[2][2];
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -400,7 +403,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnArgs a) {
     bf16x8 pb[2];
 #pragma unroll
     for (int it = 0; it < 2; ++it) pb[it] = pack8(st[0][it], st[1][it]);
-    bf16* O = (bf16*)a.O + (size_t)m.b * a.Tq * a.ldo + m.h * D;
+    bf16* O = (bf16*)a.O + (size_t)m.b * qr * a.ldo + m.h * D;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) {
         const bf16x8 vt = tr_operand<D, true>(vimg, ct, m);
@@ -686,6 +689,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnArgs a) {
 bool mfma_ok(int dtype, const AttnArgs& a, bool bwd) {
     if (dtype != BLT_BF16 || blt_debug_get(16) == 1) return false;      // debug key 16 = 1: the VALU kernels (A/B)
     if (!(a.d == 32 || a.d == 64 || a.d == 128) || a.Tq > 32 || a.Tk > 32) return false;
+    // a row-subset view takes the kernel its whole tensor would take, so that step t of an incremental pass reproduces row t of the full
+    // pass bit for bit (the two kernels round P differently: bf16 MFMA operand here, fp32 on the VALU)
+    if (a.q_rows > 32 || a.k_rows > 32) return false;
     auto al = [](const void* p, int ld) { return (((uintptr_t)p) & 15) == 0 && (ld & 7) == 0; };
     if (!al(a.Q, a.ldq) || !al(a.K, a.ldk) || !al(a.V, a.ldv)) return false;
     if (!bwd) return (((uintptr_t)a.O) & 7) == 0 && (a.ldo & 3) == 0;
@@ -726,8 +732,9 @@ int check(const AttnArgs& a, bool bwd) {
     BLT_REQUIRE(a.B > 0 && a.heads > 0 && a.d > 0, "attn: bad sizes");
     BLT_REQUIRE(a.Tq > 0 && a.Tq <= 64 && a.Tk > 0 && a.Tk <= 64, "attn: Tq=%d Tk=%d must be in 1..64", a.Tq, a.Tk);
     BLT_REQUIRE(a.drop_p >= 0.f && a.drop_p < 1.f, "attn: bad dropout p");
+    BLT_REQUIRE((a.q_rows == 0 || a.q_rows >= a.Tq) && (a.k_rows == 0 || a.k_rows >= a.Tk), "attn: q_rows=%d / k_rows=%d must be 0 or >= Tq / Tk", a.q_rows, a.k_rows);
     if (!bwd) BLT_REQUIRE(a.O != nullptr, "attn_fwd: null O");
-    else BLT_REQUIRE(a.dO && a.dQ && a.dK && a.dV, "attn_bwd: null gradient pointer");
+    else BLT_REQUIRE(a.dO && a.dQ && a.dK && a.dV && a.q_rows == 0 && a.k_rows == 0, "attn_bwd: null gradient pointer (or a row-subset view: forward only)");
     return BLT_OK;
 }
 
@@ -757,7 +764,7 @@ int set_lds(K kern, size_t bytes, const char* what) {
 
 #ifdef BLT_EXPERIMENTS
 bool blt_attn_out_fwd_ok(int dtype, const AttnArgs& a) {
-    return dtype == BLT_BF16 && a.d == 64 && a.heads >= 1 && a.heads <= 8 && a.Tq <= 32 && a.Tk <= 32 && mfma_ok(dtype, a, false) && a.Wo && a.Y &&
+    return dtype == BLT_BF16 && a.d == 64 && a.heads >= 1 && a.heads <= 8 && a.Tq <= 32 && a.Tk <= 32 && a.q_rows == 0 && a.k_rows == 0 && mfma_ok(dtype, a, false) && a.Wo && a.Y &&
            a.ldwo % 8 == 0 && (((uintptr_t)a.Wo) & 15) == 0 && a.ldo >= a.heads * 64;
 }
 int blt_attn_out_fwd(int dtype, const AttnArgs& a, hipStream_t s) {

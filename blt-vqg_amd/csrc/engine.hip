@@ -262,14 +262,10 @@ struct bltvqg_engine {
     int fold_rows_total = 0;
     float *stat_pool = nullptr, *stat_emb = nullptr;
     size_t stat_pool_floats = 0;
-    // statistics slots per row: one per column tile of the producing GEMM (plain stores; the consumer adds them in slot order)
+    // statistics slots per row: one per 64 columns of the row, whatever tile the producing GEMM takes (plain stores; the consumer adds them
+    // in slot order: the sums do not depend on tile shapes or row counts)
     int stat_slots = 8;
-    // how many column tiles the planned-tile kernel cuts an [M, H] result into when it also writes row statistics
-    int stat_parts(int M, int K) const {
-        int bm = 0, bn = 0;
-        blt_gemm_nt2_tile(M, H, K, &bm, &bn, true);
-        return bn > 0 ? (H + bn - 1) / bn : 1;
-    }
+    int stat_parts(int /*M*/, int /*K*/) const { return (H + 63) / 64; }
     bool fold_on() const { return fold_ok && blt_debug_get(25) != 1; }
     void add_fold(int which, const std::string& wname, int rows, const std::string& ln, const char* bias) {
         const PInfo& w = tpi(wname);
@@ -283,7 +279,7 @@ struct bltvqg_engine {
     }
     void build_fold() {
         fold_ok = dt == BLT_BF16 && ln_pp == 0 && H % 8 == 0;
-        stat_slots = (H + 63) / 64;      // the narrowest compiled tile has 64 columns
+        stat_slots = (H + 63) / 64;      // one slot per 64 columns of a row
         if (!fold_ok) return;
         const Stack* sts[3] = {&enc, &renc, &dec};
         for (const Stack* st : sts)
@@ -1063,6 +1059,77 @@ struct bltvqg_engine {
         return ln_fwd(x, st.prefix + ".layer_norm", st.out, st.mF, st.rF, rows_of(st, L - 1), s);
     }
 
+    // ---- incremental greedy decoding (round 4).  The reference re-decodes the whole prefix for every new token
+    // (iq.py:134-141: decoder.inference_forward on ys[:, :t+1]); round 2's form did the same with one decoder pass over all T rows per step.
+    // Position t's activations depend on the tokens 0..t only and those never change once written, so step t computes ROW t of every
+    // sample (B strided rows of the [B*T, .] tensors: row b*T + t, no gather) and attends over the q|k|v rows the earlier steps left in the
+    // layer buffers — they ARE the key / value cache.  Self-attention: one query against keys 0..t (pad keys replaced by -1e18 as in the
+    // full pass; "future keys do not exist" is the key count).  Cross-attention: the hoisted encoder-side key / value projections.
+    int attn_row(const void* q, int ldq, const void* k, const void* v, int ldkv, int k_rows, void* o, const int* key_ids, int Tk, hipStream_t s) {
+        AttnArgs a;
+        a.Q = q; a.ldq = ldq; a.q_rows = T; a.K = k; a.V = v; a.ldk = ldkv; a.ldv = ldkv; a.k_rows = k_rows; a.O = o; a.ldo = H; a.key_ids = key_ids;
+        a.B = B; a.heads = NH; a.Tq = 1; a.Tk = Tk; a.d = dh; a.causal = 0; a.scale = 1.f / sqrtf((float)dh_true);
+        return blt_attn_fwd(dt, a, s);
+    }
+    int dec_step_fwd(int t, const int* src_ids, hipStream_t s) {
+        Stack& st = dec;
+        const Rows rw{B, T * H, T * F, true};
+        const size_t oH = (size_t)t * H * es, oF = (size_t)t * F * es, o3 = (size_t)t * 3 * H * es;
+        auto at = [](void* p, size_t off) { return (void*)((char*)p + off); };
+        const bool fold = fold_on();
+        const void* x = (const char*)st.x_in + oH;
+        for (int l = 0; l < L; ++l) {
+            Layer& y = st.layers[l];
+            const std::string lp = st.prefix + ".dec." + std::to_string(l) + ".";
+            const std::string a1 = lp + "multi_head_attention_dec.", a2 = lp + "multi_head_attention_enc_dec.";
+            // q | k | v of row t (k and v join the cache)
+            if (fold) {
+                GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, at(y.qkv, o3), T * 3 * H, B, 3 * H, H);
+                if (l == 0) {      // the embedding GEMM's statistics are indexed by the row of the whole tensor
+                    set_fold(g, x, T * H, a1 + "query_linear.weight", st.stat_in + 2 * (size_t)stat_slots * t, st.stat_in_parts, y.m1, y.r1);
+                    g.fold_sstride = T * stat_slots;
+                } else {
+                    set_fold(g, x, T * H, a1 + "query_linear.weight", y.st1, stat_parts(B, F), y.m1, y.r1);
+                }
+                RC(gemm(dt, g, s));
+            } else {
+                RC(ln_fwd(x, lp + "layer_norm_mha_dec", at(y.xn1, oH), y.m1, y.r1, rw, s));
+                int ldw;
+                const void* w = W(a1 + "query_linear.weight", &ldw);
+                RC(gemm(dt, mk(at(y.xn1, oH), T * H, 0, w, ldw, 0, at(y.qkv, o3), T * 3 * H, B, 3 * H, H), s));
+            }
+            RC(attn_row(at(y.qkv, o3), 3 * H, (char*)y.qkv + (size_t)H * es, (char*)y.qkv + (size_t)2 * H * es, 3 * H, T, at(y.ctx, oH), st.key_ids, t + 1, s));
+            {
+                GemmArgs g = lin(at(y.ctx, oH), T * H, a1 + "output_linear.weight", nullptr, at(y.x1, oH), T * H, B);
+                g.R = x; g.ldr = T * H;
+                if (fold) set_stat(g, y.st2);
+                RC(gemm(dt, g, s));
+            }
+            // cross-attention: query of row t against the encoder-side keys / values (hoisted: dec_kv_fwd)
+            if (fold) {
+                GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, at(y.q2, oH), T * H, B, H, H);
+                set_fold(g, at(y.x1, oH), T * H, a2 + "query_linear.weight", y.st2, stat_parts(B, H), y.m2, y.r2);
+                RC(gemm(dt, g, s));
+            } else {
+                RC(ln_fwd(at(y.x1, oH), lp + "layer_norm_mha_enc", at(y.xn2, oH), y.m2, y.r2, rw, s));
+                RC(gemm(dt, lin(at(y.xn2, oH), T * H, a2 + "query_linear.weight", nullptr, at(y.q2, oH), T * H, B), s));
+            }
+            RC(attn_row(at(y.q2, oH), H, y.kv2, (char*)y.kv2 + (size_t)H * es, 2 * H, 0, at(y.ctx2, oH), src_ids, Sa, s));
+            {
+                GemmArgs g = lin(at(y.ctx2, oH), T * H, a2 + "output_linear.weight", nullptr, at(y.x1b, oH), T * H, B);
+                g.R = at(y.x1, oH); g.ldr = T * H;
+                if (fold) set_stat(g, y.st3);
+                RC(gemm(dt, g, s));
+            }
+            Layer yt = y;      // the FFN's buffers at row t
+            yt.h = at(y.h, oF); yt.x2 = at(y.x2, oH); yt.y2 = at(y.y2, oH);
+            float* next_stat = (fold && l + 1 < L) ? st.layers[l + 1].st1 : nullptr;
+            RC(ffn_fwd(lp + "positionwise_feed_forward.", lp + "layer_norm_ffn", at(y.xn3, oH), y.m3, y.r3, y.st3, at(y.x1b, oH), yt, rw, st.id, l, next_stat, s));
+            x = yt.x2;
+        }
+        return ln_fwd(x, st.prefix + ".layer_norm", at(st.out, oH), st.mF, st.rF, rw, s);
+    }
+
     // the LDS-patch kernel can take the previous convolution's raw output and apply its BatchNorm + ReLU on the staged patch
     bool conv_is_direct(const ConvSpec& cs) const {
         return cs.pp && dt == BLT_BF16 && cs.K == 3 && cs.stride == 1 && cs.pad == 1 && cs.Cin % 64 == 0 && cs.Cout % 64 == 0 && cs.Wo <= 62;
@@ -1521,14 +1588,23 @@ struct bltvqg_engine {
             RC(blt_latent_fwd(dt, mlvp, mlvp, eps_dev, zlat, stats + 6, B, Z, 2 * Z, s));      // reparameterise with the PRIOR; KL slot unused
             RC(gemm(dt, lin(zlat, Z, "latent_projection.weight", "latent_projection.bias", zproj, H, B), s));
         }
+        // the decoder layers' encoder-side key / value projections read encoder_outputs only (transformer_layers.py:330-342: the reference
+        // recomputes them in every one of its prefix re-decodes, iq.py:134-141): once per batch, not once per step (debug key 28 = 1: per step)
+        // debug key 29 = 1: the round-2 form, one decoder pass over all T rows per step (A/B and the equivalence test); it may also
+        // recompute the hoisted projections per step (key 28 = 1)
+        const bool incremental = blt_debug_get(29) != 1;
+        const bool hoist = incremental || blt_debug_get(28) != 1;
+        if (hoist) RC(dec_kv_fwd(s));
         for (int t = 0; t < T; ++t) {
             RC(embed(Ma, Mt));
             RC(dec_row0_add(phase2 ? zproj : nullptr, s));     // [:,0] += z + image_features
-            RC(stack_fwd(dec, enc.out, ctx32, s));
+            const int rc = incremental ? dec_step_fwd(t, ctx32, s) : stack_fwd(dec, enc.out, ctx32, s);
+            if (rc) { kv_hoisted = false; return rc; }
             GemmArgs g = lin((char*)dec.out + (size_t)t * H * es, T * H, "decoder.output.weight", "decoder.output.bias", zlogit, ldV, B);
             RC(gemm(dt, g, s));
             RC(blt_argmax_top6(dt, zlogit, ldV, B, V, t, T, ys, tokens, top_idx, top_val, s));
         }
+        kv_hoisted = false;
         return BLT_OK;
     }
 

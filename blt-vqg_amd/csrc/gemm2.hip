@@ -87,11 +87,10 @@ struct Nt2 {
     static_assert(LDS <= CAP, "LDS budget");
 };
 
-// sum over the GPR (8, 16 or 32) consecutive lanes that hold one result row (all lanes of the wave take part)
+// sum over GPR (8, 16 or 32) consecutive, GPR-aligned lanes (all lanes of the wave take part)
 template <int GPR>
 __device__ __forceinline__ float rowgroup_sum(float v) {
-    static_assert(GPR >= 8, "column groups per row");
-    if (GPR != 8 && GPR != 16 && GPR != 32) return v;      // (BN = 192: 24 lanes per row; the planner never picks such a tile for a launch with out_stat)
+    static_assert(GPR == 8 || GPR == 16 || GPR == 32, "lanes per group");
     v += dpp_mov<0xB1>(v);                       // quad_perm [1,0,3,2]
     v += dpp_mov<0x4E>(v);                       // quad_perm [2,3,0,1]
     v += dpp_mov<0x141>(v);                      // row_half_mirror: the other quad of the 8
@@ -202,7 +201,7 @@ __device__ __forceinline__ void nt2_body(const GemmArgs& p, const int tile_m, co
         // the first column tile also stores them for the LayerNorm's backward.
         if (tid < BM && m0 + tid < p.M) {
             const int m = m0 + tid;
-            const float2* sp = reinterpret_cast<const float2*>(p.fold_stat) + (size_t)m * p.stat_slots;
+            const float2* sp = reinterpret_cast<const float2*>(p.fold_stat) + (size_t)m * (p.fold_sstride ? p.fold_sstride : p.stat_slots);
             float s1 = 0.f, s2 = 0.f;
             for (int k0 = 0; k0 < p.fold_np; k0 += 8) {      // eight loads in flight, then added in slot order
                 float2 st[8];
@@ -394,12 +393,15 @@ __device__ __forceinline__ void nt2_body(const GemmArgs& p, const int tile_m, co
                 for (int e = 0; e < 8; ++e) { const float x = (float)ov[e]; st1 += x; st2 += x * x; }      // (of the row AS STORED)
             }
             }
-            // row statistics for the LayerNorm that reads this result and is folded into ITS consumer: the GPR lanes that hold one row
-            // add up (every lane of the wave takes part, inactive ones with zeros; a fixed butterfly: reproducible), then column group 0
-            // (active whenever its row is) stores this column tile's partial into its own slot
+            // row statistics for the LayerNorm that reads this result and is folded into ITS consumer, one slot per 64 COLUMNS of the row
+            // whatever the tile width: the 8 lanes that hold 64 consecutive columns add up (every lane of the wave takes part, inactive ones
+            // with zeros; a fixed butterfly), the first of them (active whenever any of the 8 is) stores slot (first column / 64).  The
+            // partition — and with it the consumer's in-order sum — does not depend on the tile shape or the row count of the launch:
+            // incremental decoding (B rows per launch) reproduces the full pass (B * T rows) bit for bit
             if (p.out_stat) {
-                st1 = rowgroup_sum<GPR>(st1); st2 = rowgroup_sum<GPR>(st2);
-                if (act && cg == 0) *reinterpret_cast<float2*>(p.out_stat + 2 * ((size_t)m * p.stat_slots + tile_n)) = make_float2(st1, st2);
+                st1 = rowgroup_sum<8>(st1); st2 = rowgroup_sum<8>(st2);
+                if (act && (cg & 7) == 0)
+                    *reinterpret_cast<float2*>(p.out_stat + 2 * ((size_t)m * p.stat_slots + tile_n * (BN / 64) + (cg >> 3))) = make_float2(st1, st2);
             }
         }
     }
@@ -764,7 +766,6 @@ int blt_gemm_nt2_plan(int M, int N, int K, int force_bm, int force_bn, bool row_
     for (int i = 0; i < kNumTiles; ++i) {
         const TileOpt& t = kTiles[i];
         if (force_bm && (t.bm != force_bm || t.bn != force_bn)) continue;
-        if (row_stat && t.bn == 192) continue;      // 24 column groups per row: no butterfly for the row statistics
         const long tiles = (long)(cdiv(M, t.bm) + (M2 > 0 ? cdiv(M2, t.bm) : 0)) * cdiv(N, t.bn);      // (M2: the second problem of a paired launch)
         const long rounds = (tiles + cus - 1) / cus;
         const double intake = (t.bm + t.bn) * 128.0 / 70e3;                   // us per K-step
@@ -792,14 +793,17 @@ bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a, bool any_rows) {
 
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm, int force_bn) {
     const int i = blt_gemm_nt2_plan(a.M, a.N, a.K, force_bm, force_bn, a.out_stat != nullptr);
-    BLT_REQUIRE(i >= 0, "gemm_nt2: no tile %dx%d compiled in%s", force_bm, force_bn, a.out_stat ? " (row statistics: not with 192-column tiles)" : "");
-    BLT_REQUIRE(!a.out_stat || cdiv(a.N, kTiles[i].bn) <= a.stat_slots, "gemm_nt2: %d column tiles but only %d statistics slots per row",
-                cdiv(a.N, kTiles[i].bn), a.stat_slots);
+    BLT_REQUIRE(i >= 0, "gemm_nt2: no tile %dx%d compiled in", force_bm, force_bn);
+    BLT_REQUIRE(!a.out_stat || cdiv(a.N, 64) <= a.stat_slots, "gemm_nt2: %d groups of 64 columns but only %d statistics slots per row", cdiv(a.N, 64),
+                a.stat_slots);
     BLT_REQUIRE(!a.fold_s || (a.fold_np >= 1 && a.fold_np <= a.stat_slots), "gemm_nt2: fold_np %d outside [1, stat_slots %d]", a.fold_np, a.stat_slots);
     return kTiles[i].launch(a, s);
 }
 void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat, int M2) {
-    const int i = blt_gemm_nt2_plan(M, N, K, 0, 0, row_stat, M2);
+    // the tile a launch WITHOUT a per-call shape takes: debug keys 9 / 10 (A/B: one tile shape for every planned-tile launch) apply here
+    // as they do in blt_gemm's dispatch, so that a consumer's count of statistics slots follows the producer's actual column tiles
+    const int i = blt_gemm_nt2_plan(M, N, K, blt_debug_get(9), blt_debug_get(9) ? blt_debug_get(10) : 0, row_stat, M2);
+    if (i < 0) { *bm = 0; *bn = 0; return; }      // (no such tile: the launch itself fails loudly)
     *bm = kTiles[i].bm; *bn = kTiles[i].bn;
 }
 
@@ -812,13 +816,13 @@ bool blt_gemm_nt2_pair_ok(int dtype, const GemmArgs& a, const GemmArgs& b) {
            a.drop_p == b.drop_p && a.seed == b.seed && a.mask_scale == b.mask_scale && a.accumulate == b.accumulate && !a.rowtab && !b.rowtab &&
            same_null(a.bias, b.bias) && same_null(a.maskY, b.maskY) && same_null(a.C2, b.C2) && same_null(a.R, b.R) && same_null(a.fold_s, b.fold_s) &&
            same_null(a.fold_mean, b.fold_mean) && same_null(a.out_stat, b.out_stat) && a.stat_slots == b.stat_slots && a.fold_np == b.fold_np &&
-           a.fold_n == b.fold_n && a.fold_eps == b.fold_eps && a.nt2_bm == b.nt2_bm && a.nt2_bn == b.nt2_bn;
+           a.fold_n == b.fold_n && a.fold_eps == b.fold_eps && a.fold_sstride == b.fold_sstride && a.nt2_bm == b.nt2_bm && a.nt2_bn == b.nt2_bn;
 }
 int blt_gemm_nt2_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     const int i = blt_gemm_nt2_plan(a.M, a.N, a.K, a.nt2_bm, a.nt2_bn, a.out_stat != nullptr, b.M);
     BLT_REQUIRE(i >= 0, "gemm_nt2_pair: no tile %dx%d compiled in", a.nt2_bm, a.nt2_bn);
-    BLT_REQUIRE(!a.out_stat || cdiv(a.N, kTiles[i].bn) <= a.stat_slots, "gemm_nt2_pair: %d column tiles but only %d statistics slots per row",
-                cdiv(a.N, kTiles[i].bn), a.stat_slots);
+    BLT_REQUIRE(!a.out_stat || cdiv(a.N, 64) <= a.stat_slots, "gemm_nt2_pair: %d groups of 64 columns but only %d statistics slots per row",
+                cdiv(a.N, 64), a.stat_slots);
     BLT_REQUIRE(!a.fold_s || (a.fold_np >= 1 && a.fold_np <= a.stat_slots), "gemm_nt2_pair: fold_np %d outside [1, stat_slots %d]", a.fold_np, a.stat_slots);
     GemmPair d;
     d.M = b.M; d.A = b.A; d.lda = b.lda; d.B = b.B; d.ldb = b.ldb; d.C = b.C; d.ldc = b.ldc; d.bias = b.bias; d.maskY = b.maskY; d.ldm = b.ldm;

@@ -89,11 +89,12 @@ struct GemmArgs {
     int fold_np = 1;
     float* fold_mean = nullptr;         // [M], written by the first column tile (the LayerNorm's backward reads them); may be null
     float* fold_rstd = nullptr;
+    int fold_sstride = 0;               // slots between consecutive rows of fold_stat (0 = stat_slots): strided row views of a wider statistics buffer
     float fold_eps = 1e-5f;
     float fold_n = 0.f;                 // features per row the statistics cover (the LayerNorm's width)
-    // out_stat[m][tile_n][0..1] = {sum, sum of squares} of the columns of result row m AS STORED (bf16-rounded) that column tile tile_n of
-    // this launch owns (plain stores, one slot per column tile: the consumer adds the cdiv(N, tile columns) partials in a fixed order, so
-    // the folded LayerNorm is bit-reproducible; blt_gemm_nt2_tile tells the host how many there are).  stat_slots = slots per row (both).
+    // out_stat[m][g][0..1] = {sum, sum of squares} of columns 64 g .. 64 g + 63 of result row m AS STORED (bf16-rounded): one slot per 64
+    // columns whatever the tile shape (plain stores; the consumer adds the cdiv(N, 64) partials in slot order, so the folded LayerNorm is
+    // bit-reproducible AND independent of tile shapes / row counts).  stat_slots = slots per row (both).
     float* out_stat = nullptr;
     int stat_slots = 1;
 };
@@ -125,7 +126,7 @@ int blt_gemm_splits(const GemmArgs& a, int dtype);
 // gemm2.hip: one-round-per-chip NT GEMM (bf16, k-contiguous operands, bf16 output): tile shape planned per problem
 bool blt_gemm_nt2_ok(int dtype, const GemmArgs& a, bool any_rows = false);
 int blt_gemm_nt2(const GemmArgs& a, hipStream_t s, int force_bm = 0, int force_bn = 0);
-void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat = false, int M2 = 0);      // row_stat: a launch with out_stat (no 192-column tiles); M2: rows of a paired launch's second problem
+void blt_gemm_nt2_tile(int M, int N, int K, int* bm, int* bn, bool row_stat = false, int M2 = 0);      // row_stat: a launch with out_stat; M2: rows of a paired launch's second problem
 bool blt_gemm_nt2_pair_ok(int dtype, const GemmArgs& a, const GemmArgs& b);
 int blt_gemm_nt2_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t s);
 // CUs the launch planners size a "round" for: 256 (the chip) unless the dependent chain runs on a CU partition (engine_set_cu_masks)
@@ -215,6 +216,10 @@ struct AttnArgs {
     void* O = nullptr; int ldo = 0;
     const int* key_ids = nullptr;   // [B, Tk] token ids; id == 0 -> key masked
     int B = 0, heads = 0, Tq = 0, Tk = 0, d = 0;
+    // forward only: rows per batch element of the Q / O tensors and of the K / V / key_ids tensors when only the first Tq / Tk of them take
+    // part (0 = Tq / Tk).  Incremental decoding: Q points at the newest row of a [B, T, ld] projection (Tq = 1, q_rows = T), K / V at row 0
+    // of the rows written so far (Tk = t + 1, k_rows = T) — the earlier steps' projections are the key / value cache.
+    int q_rows = 0, k_rows = 0;
     int causal = 0;
     float scale = 1.f;
     float drop_p = 0.f; uint64_t seed = 0; uint32_t stream_id = 0;

@@ -38,7 +38,9 @@ int bltvqg_version(void);
 const char* bltvqg_last_error_string(void);
 /* tuning switches for A/B benchmarks: key 0 = disable the LDS-DMA GEMM ring (value 1), key 1 = force a GEMM tile (64/128/12864) */
 void bltvqg_debug_set(int key, int value);
-int bltvqg_debug_get(int key);      /* keys 0..31; bench.py echoes every non-zero key in its JSON line */
+int bltvqg_debug_get(int key);      /* keys 0..31; bench.py echoes every non-zero key in its JSON line.  Round 4: 23 dead-work A/B, 24 LayerNorm-backward
+                                      * forms, 25 = 1 LayerNorm fold off, 27 = 1 per-pixel img_pack, 28 = 1 decode: cross K/V per step, 29 = 1 decode: one
+                                      * full decoder pass per step (the round-2 form) */
 /* 1 only in the ablation build (make -C blt-vqg_amd/csrc ablate -> libbltvqg_hip_ablate.so, -DBLT_ABLATE): there debug keys 14 (skip the
  * grouped weight-gradient launches) and 15 (skip the conv stack) exist as TIMING ablations with wrong results.  The shipped library has
  * no switch that skips work. */
@@ -69,10 +71,10 @@ int bltvqg_gemm_ex(const void* A, int lda, const void* B, int ldb, void* C, int 
  * c_n = sum_k beta[k] W[n,k] + b_n: the normalisation moves into the GEMM epilogue, the row sums come from the epilogue of the GEMM that
  * PRODUCED x, and the layernorm launch between the two disappears.
  * bltvqg_gemm_rowstat: bltvqg_gemm_ex's Linear (bias, relu, dropout, second output C2, residual R) that also STORES, per result row m and
- *   column tile t of the launch, the {sum, sum of squares} of the columns that tile owns, AS STORED (bf16-rounded), into
- *   out_stat[m][t][0..1] (stat_slots slots per row; plain stores, no atomics: the consumer adds the parts in slot order, so the folded
- *   LayerNorm is bit-reproducible).  bltvqg_gemm_rowstat_parts(M, N, K, tile_n) = how many parts that launch writes (tile_n = 0: the
- *   planner's tile; row statistics never take a 192-column tile).
+ *   group g of 64 columns, the {sum, sum of squares} of those columns AS STORED (bf16-rounded) into out_stat[m][g][0..1] (stat_slots slots
+ *   per row; plain stores, no atomics; one slot per 64 columns WHATEVER the tile shape: the consumer adds the slots in order, so the folded
+ *   LayerNorm is bit-reproducible and does not depend on tile shapes or on how many rows a launch covers — an incremental pass over some rows
+ *   reproduces the full pass).  bltvqg_gemm_rowstat_parts(M, N, K, tile_n) = how many slots that launch writes = ceil(N / 64).
  * bltvqg_ln_fold_prepare: W'[N,K] (bf16), s[N] (of the ROUNDED W'), c[N] (fp32 W; bias may be NULL) from the fp32 parameters.
  * bltvqg_linear_ln_folded: Y = [dropout][relu](rstd_m (X Wf^T - mean_m s_n) + c_n) with mean_m / rstd_m from row_stat[m] = {sum, sum of
  *   squares} of row m of X over its K features, given as stat_parts partial sums in the first slots of row_stat[m][stat_slots][2]
@@ -188,6 +190,13 @@ int bltvqg_bn1d_bwd(int dtype, const void* dy, const void* x, const float* gamma
 int bltvqg_attn_fwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                     const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal, float scale, float drop_p,
                     uint64_t seed, uint32_t stream_id, void* stream);
+/* The same forward on ROW SUBSETS of wider tensors (round 4, incremental greedy decoding: models/iq.py:134-141 re-decodes the whole prefix
+ * for every new token; here the projections of earlier steps are the key / value cache).  Q / O hold q_rows rows per batch element of which
+ * the first Tq (from the given pointer) are queries; K / V / key_ids hold k_rows rows per batch element of which the first Tk are keys
+ * (0 = Tq / Tk, i.e. bltvqg_attn_fwd).  No dropout (inference).  Query i against keys 0..Tk-1 gives the values bltvqg_attn_fwd gives for
+ * that query over the same keys. */
+int bltvqg_attn_fwd_rows(int dtype, const void* Q, int ldq, int q_rows, const void* K, int ldk, const void* V, int ldv, int k_rows, void* O, int ldo,
+                         const int32_t* key_ids, int B, int heads, int Tq, int Tk, int d, int causal, float scale, void* stream);
 int bltvqg_attn_bwd(int dtype, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, const void* dO, int lddo,
                     void* dQ, int lddq, void* dK, int lddk, void* dV, int lddv, const int32_t* key_ids, int B, int heads, int Tq,
                     int Tk, int d, int causal, float scale, float drop_p, uint64_t seed, uint32_t stream_id, void* stream);

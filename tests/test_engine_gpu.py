@@ -436,3 +436,42 @@ def test_trusted_weight_shadows_equal_a_full_refresh():
     e.forward(probe["images"], probe["answers"], probe["posteriors"], probe["questions"], probe["eps"], True, 0)
     fresh.forward(probe["images"], probe["answers"], probe["posteriors"], probe["questions"], probe["eps"], True, 0)
     assert torch.equal(e.read(0), fresh.read(0))
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("T", [13, 40])
+@pytest.mark.parametrize("phase2", [False, True])
+def test_incremental_greedy_decode_equals_the_prefix_redecode(dtype, T, phase2):
+    """Round 4: step t of bltvqg_engine_decode_greedy computes row t of every sample and attends over the q|k|v rows of the
+    earlier steps (the layer buffers are the key / value cache) instead of re-running the decoder over the whole prefix as the reference
+    does (models/iq.py:134-141) and as round 2's form did (debug key 29 = 1).  Tokens, top-6 indices AND top-6 probabilities must be
+    bit-identical between the two forms: T = 40 > 32 takes the VALU attention kernel in bf16 too, bf16 folds the LayerNorms (row statistics in
+    64-column slots: independent of the rows per launch), phase 2 adds z to row 0."""
+    import bltvqg_amd.synthetic as synthetic
+    from bltvqg_amd.engine import StepEngine, make_config
+    from bltvqg_amd.trainer import init_reference_style
+    B, H, F, L, NH, V = 24, 128, 256, 3, 2, 503
+    c = make_config(B, H, F, H, 40, L, NH, V, image_hw=(64, 64), len_target=T, dtype=dtype, attention_dropout=0.0, relu_dropout=0.0)
+    e = StepEngine(c, "cuda:0")
+    e.allocate()
+    init_reference_style(e, seed=3)
+    # a decisive model: scale the vocabulary projection up so that the argmax is not a coin toss between near-equal logits
+    with torch.no_grad():
+        e.view("decoder.output.weight", 0).mul_(30.0)
+    e.params_changed()
+    b = synthetic.make_batch(B, V, H, seed=11, image_hw=64)
+    img, ans, eps = b["images"].cuda(), b["answers"].cuda(), b["eps"].cuda()
+    outs = []
+    try:
+        for key in (1, 0):
+            e.lib.bltvqg_debug_set(29, key)
+            outs.append([x.clone() for x in e.decode_greedy(img, ans, eps, phase2)])
+            torch.cuda.synchronize()
+    finally:
+        e.lib.bltvqg_debug_set(29, 0)
+    full, inc = outs
+    assert torch.equal(full[0], inc[0])
+    assert torch.equal(full[1], inc[1])
+    assert torch.equal(full[2], inc[2])
+    # the sentences are not degenerate: several distinct tokens, and not every sample says the same thing
+    assert int(torch.unique(inc[0]).numel()) > 5 and not bool((inc[0] == inc[0][0:1]).all())

@@ -14,8 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-# (row statistics never take a 192-column tile: 24 column groups per row have no butterfly)
-TILES = [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (160, 64), (160, 128), (160, 256), (192, 64), (192, 128),
+TILES = [(0, 0), (64, 64), (64, 128), (128, 64), (128, 128), (160, 64), (160, 128), (160, 192), (160, 256), (192, 64), (192, 128), (192, 192),
          (192, 256), (128, 256), (256, 128), (256, 64), (224, 256), (96, 64), (32, 64)]
 
 
@@ -67,6 +66,35 @@ def test_row_statistics_are_those_of_the_rounded_output():
     x = C.double().cpu()
     assert float((st[:, 0].double().cpu() - x.sum(1)).abs().max()) < 1e-3
     assert float(((st[:, 1].double().cpu() - (x * x).sum(1)) / (x * x).sum(1)).abs().max()) < 1e-5
+
+
+def test_row_statistics_do_not_depend_on_the_tile_shape():
+    """One slot per 64 columns whatever the tile: every compiled tile leaves the SAME slot array, bit for bit (what makes an incremental
+    pass over B rows reproduce the full pass over B * T rows, engine.hip::dec_step_fwd)."""
+    g = torch.Generator().manual_seed(6)
+    M, N, K = 333, 328, 136
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.1).bfloat16().cuda()
+    R = torch.randn(M, N, generator=g).bfloat16().cuda()
+    import gpu_ops as G
+    from bltvqg_amd._lib import check, stream_ptr
+    ref = None
+    for tile in TILES:
+        C = torch.zeros(M, N, dtype=torch.bfloat16, device="cuda")
+        st = torch.zeros(M, 6, 2, dtype=torch.float32, device="cuda")
+        assert int(G.lib().bltvqg_gemm_rowstat_parts(M, N, K, tile[1])) == 6
+        check(G.lib().bltvqg_gemm_rowstat(G.ptr(A), K, G.ptr(W), K, G.ptr(C), N, M, N, K, None, 0, 0.0, 0, 0, None, 0, G.ptr(R), N, G.ptr(st), 6, tile[0],
+                                          tile[1], stream_ptr()), "gemm_rowstat")
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (C.clone(), st.clone())
+            x = C.float()
+            for gi in range(6):      # slot g = columns 64 g .. 64 g + 63 of the stored row
+                cols = x[:, 64 * gi:64 * gi + 64].double()
+                assert float((st[:, gi, 0].double() - cols.sum(1)).abs().max()) < 1e-3
+                assert float((st[:, gi, 1].double() - (cols * cols).sum(1)).abs().max()) < 1e-2
+        assert torch.equal(C, ref[0]), tile
+        assert torch.equal(st, ref[1]), tile
 
 
 def _prepare(W, gamma, beta, bias):

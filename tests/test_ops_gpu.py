@@ -900,3 +900,47 @@ def test_img_pack_stem_layout(geom, form):
     ref = torch.zeros(N, Hp, Wp, 4, dtype=torch.bfloat16)
     ref[:, 3:3 + H, 3:3 + W, :3] = x.permute(0, 2, 3, 1).bfloat16()
     assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T", [8, 21, 51])
+def test_attn_fwd_rows_equals_the_prefix_redecode_row(dtype, T):
+    """bltvqg_attn_fwd_rows (incremental greedy decoding): query row t against the first t + 1 key / value rows of [B, T, .] projections
+    — the earlier steps' rows are the cache — is BIT-IDENTICAL to row t of the full pass with causal = 2 ("future keys do not exist",
+    the reference's prefix re-decode, models/iq.py:134-141), pad keys included.  T = 51 (max_decode_length 50) takes the VALU kernel
+    in bf16 too; cross-attention form: q_rows = T, k_rows = 0."""
+    import gpu_ops as G
+    from gpu_ops import check, ptr, stream_ptr
+    B, heads, d = 5, 4, 64
+    Hd = heads * d
+    g = torch.Generator().manual_seed(T)
+    qkv = torch.randn(B * T, 3 * Hd, generator=g).to(dtype).cuda()
+    ids = torch.randint(0, 4, (B, T), generator=g, dtype=torch.int32)      # zeros = pad keys
+    ids[:, 0] = 1
+    ids = ids.cuda()
+    Q, K, V = qkv[:, :Hd], qkv[:, Hd:2 * Hd], qkv[:, 2 * Hd:]
+    scale = 1.0 / d ** 0.5
+    full = G.attn_fwd(Q, K, V, ids, B, heads, T, T, d, 2, scale)
+    torch.cuda.synchronize()
+    out = torch.zeros_like(full)
+    for t in range(T):
+        check(G.lib().bltvqg_attn_fwd_rows(G.DT[dtype], Q[t:].data_ptr(), 3 * Hd, T, ptr(K), 3 * Hd, ptr(V), 3 * Hd, T, out[t:].data_ptr(), Hd, ptr(ids),
+                                           B, heads, 1, t + 1, d, 0, scale, stream_ptr()), "attn_fwd_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(out, full)
+    assert float(full.float().abs().sum()) > 0
+    # cross-attention of one query row per batch element over a short, separately laid out key set
+    Sk = 5
+    kv = torch.randn(B * Sk, 2 * Hd, generator=g).to(dtype).cuda()
+    kid = torch.tensor([[1, 2, 0, 3, 0]] * B, dtype=torch.int32).cuda()
+    fullc = G.attn_fwd(Q, kv[:, :Hd], kv[:, Hd:], kid, B, heads, T, Sk, d, 0, scale)
+    outc = torch.zeros_like(fullc)
+    t = T - 2
+    check(G.lib().bltvqg_attn_fwd_rows(G.DT[dtype], Q[t:].data_ptr(), 3 * Hd, T, kv.data_ptr(), 2 * Hd, kv[:, Hd:].data_ptr(), 2 * Hd, 0, outc[t:].data_ptr(),
+                                       Hd, ptr(kid), B, heads, 1, Sk, d, 0, scale, stream_ptr()), "attn_fwd_rows")
+    torch.cuda.synchronize()
+    assert torch.equal(outc.view(B, T, Hd)[:, t], fullc.view(B, T, Hd)[:, t])
+    assert float(outc.view(B, T, Hd)[:, :t].float().abs().sum()) == 0
+    # a row-subset view is forward-only and must cover the rows it names
+    assert G.lib().bltvqg_attn_fwd_rows(G.DT[dtype], ptr(Q), 3 * Hd, 1, ptr(K), 3 * Hd, ptr(V), 3 * Hd, T, ptr(out), Hd, ptr(ids), B, heads, 2, T, d, 0,
+                                        scale, stream_ptr()) != 0

@@ -265,7 +265,7 @@ struct bltvqg_engine {
     // statistics slots per row: one per 64 columns of the row, whatever tile the producing GEMM takes (plain stores; the consumer adds them
     // in slot order: the sums do not depend on tile shapes or row counts)
     int stat_slots = 8;
-    int stat_parts(int /*M*/, int /*K*/) const { return (H + 63) / 64; }
+    int stat_parts() const { return (H + 63) / 64; }      // partial sums per row: one per 64 columns
     bool fold_on() const { return fold_ok && blt_debug_get(25) != 1; }
     void add_fold(int which, const std::string& wname, int rows, const std::string& ln, const char* bias) {
         const PInfo& w = tpi(wname);
@@ -972,7 +972,7 @@ struct bltvqg_engine {
         GemmArgs g;
         if (fold_on()) {
             g = mk(nullptr, 0, 0, nullptr, 0, 0, y.h, rw.ldF, rw.M, F, H);
-            set_fold(g, xres, rw.ldH, fp_ + "layers.0.weight", stat, stat_parts(rw.M, H), m, r);      // (xres = an attention output projection's result)
+            set_fold(g, xres, rw.ldH, fp_ + "layers.0.weight", stat, stat_parts(), m, r);      // (xres = an attention output projection's result)
         } else {
             RC(ln_fwd(xres, ln, xn, m, r, rw, s));
             g = lin(xn, rw.ldH, fp_ + "layers.0.weight", (fp_ + "layers.0.bias").c_str(), y.h, rw.ldF, rw.M);
@@ -1016,7 +1016,7 @@ struct bltvqg_engine {
             if (fold) {
                 GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, y.qkv, 3 * H, M, 3 * H, H);
                 // (x = the embedding GEMM's rows, or the second FFN Linear's result of the layer below — never the row-0-only top layer's)
-                set_fold(g, x, H, a1 + "query_linear.weight", l == 0 ? st.stat_in : y.st1, l == 0 ? st.stat_in_parts : stat_parts(M, F), y.m1, y.r1);
+                set_fold(g, x, H, a1 + "query_linear.weight", l == 0 ? st.stat_in : y.st1, l == 0 ? st.stat_in_parts : stat_parts(), y.m1, y.r1);
                 RC(gemm(dt, g, s));
             } else {
                 RC(ln_fwd(x, ln1, y.xn1, y.m1, y.r1, all, s));
@@ -1032,7 +1032,7 @@ struct bltvqg_engine {
                 const std::string a2 = lp + "multi_head_attention_enc_dec.";
                 if (fold) {
                     GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, y.q2, H, M, H, H);
-                    set_fold(g, y.x1, H, a2 + "query_linear.weight", y.st2, stat_parts(M, H), y.m2, y.r2);
+                    set_fold(g, y.x1, H, a2 + "query_linear.weight", y.st2, stat_parts(), y.m2, y.r2);
                     RC(gemm(dt, g, s));
                 } else {
                     RC(ln_fwd(y.x1, ln2, y.xn2, y.m2, y.r2, rw, s));
@@ -1089,7 +1089,7 @@ struct bltvqg_engine {
                     set_fold(g, x, T * H, a1 + "query_linear.weight", st.stat_in + 2 * (size_t)stat_slots * t, st.stat_in_parts, y.m1, y.r1);
                     g.fold_sstride = T * stat_slots;
                 } else {
-                    set_fold(g, x, T * H, a1 + "query_linear.weight", y.st1, stat_parts(B, F), y.m1, y.r1);
+                    set_fold(g, x, T * H, a1 + "query_linear.weight", y.st1, stat_parts(), y.m1, y.r1);
                 }
                 RC(gemm(dt, g, s));
             } else {
@@ -1108,7 +1108,7 @@ struct bltvqg_engine {
             // cross-attention: query of row t against the encoder-side keys / values (hoisted: dec_kv_fwd)
             if (fold) {
                 GemmArgs g = mk(nullptr, 0, 0, nullptr, 0, 0, at(y.q2, oH), T * H, B, H, H);
-                set_fold(g, at(y.x1, oH), T * H, a2 + "query_linear.weight", y.st2, stat_parts(B, H), y.m2, y.r2);
+                set_fold(g, at(y.x1, oH), T * H, a2 + "query_linear.weight", y.st2, stat_parts(), y.m2, y.r2);
                 RC(gemm(dt, g, s));
             } else {
                 RC(ln_fwd(at(y.x1, oH), lp + "layer_norm_mha_enc", at(y.xn2, oH), y.m2, y.r2, rw, s));
@@ -1468,7 +1468,7 @@ struct bltvqg_engine {
             g.rowtab = timing; g.rowidx = pos_all; g.ldt = H;
             if (fold_on()) {      // the first LayerNorm of every stack is folded into its q|k|v projection
                 set_stat(g, stat_emb);
-                enc.stat_in_parts = renc.stat_in_parts = dec.stat_in_parts = stat_parts(Memb, E);
+                enc.stat_in_parts = renc.stat_in_parts = dec.stat_in_parts = stat_parts();
             }
             RC(gemm(dt, g, se));
         }
@@ -1571,7 +1571,7 @@ struct bltvqg_engine {
             g.rowtab = timing; g.rowidx = pos_all + row0; g.ldt = H;
             if (fold_on()) {
                 set_stat(g, stat_emb + 2 * (size_t)stat_slots * row0);
-                (row0 == 0 ? enc : dec).stat_in_parts = stat_parts(rows, E);
+                (row0 == 0 ? enc : dec).stat_in_parts = stat_parts();
             }
             return gemm(dt, g, s);
         };

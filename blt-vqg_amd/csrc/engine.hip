@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <unordered_map>
 #include <utility>
 #include <vector>
 #include <math.h>
@@ -98,7 +99,7 @@ struct bltvqg_engine {
     int FD = 512;               // width of the pooled feature the trainable head projects (512 = ResNet-18, region_dim in region mode)
     std::string fcw, fcb;       // the head's projection: encoder_cnn.cnn.fc.* (encoder_cnn.py:20) or encoder_cnn.region_proj.*
     std::vector<PInfo> tp, fp;
-    std::map<std::string, int> ti, fi;
+    std::unordered_map<std::string, int> ti, fi;      // (keyed access only; ~1 300 lookups per step on the host's enqueue path)
     int64_t tsize = 0, late_off = 0, fsize = 0, ws_bytes = 0;
     // bound memory
     float *train = nullptr, *grad = nullptr, *adam_m = nullptr, *adam_v = nullptr, *frozen = nullptr;
@@ -127,7 +128,7 @@ struct bltvqg_engine {
     void* wshadowT = nullptr;   // same offsets, every dgrad operand stored TRANSPOSED ([K,N], ld N): dX = dY W becomes an NT GEMM
     struct TEnt { int off, rows, cols, tile0; };
     std::vector<TEnt> tlist;    // matrices with a transposed shadow (fused q|k|v and k|v groups are one matrix)
-    std::map<int64_t, int> trows;   // element offset -> rows of the transposed matrix registered there
+    std::unordered_map<int64_t, int> trows;   // element offset -> rows of the transposed matrix registered there
     void* ttable = nullptr;     // device copy of tlist
     int ttiles = 0;
     void* wemb_pad = nullptr;   // padded shadow of embedding.1.weight when E % chunk != 0
@@ -255,7 +256,7 @@ struct bltvqg_engine {
     bool fold_ok = false;
     void* wshadowF = nullptr;
     float *fold_s = nullptr, *fold_c = nullptr;
-    std::map<std::string, int> fold_srow;         // consumer weight -> first row in fold_s / fold_c
+    std::unordered_map<std::string, int> fold_srow;         // consumer weight -> first row in fold_s / fold_c
     std::vector<BltFoldEnt> fold_tab[2];          // [0] the two encoder stacks (stage-1 parameters of the optimiser), [1] the decoder
     int fold_nrows[2] = {0, 0};
     void* fold_tab_dev[2] = {nullptr, nullptr};

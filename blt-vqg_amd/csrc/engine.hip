@@ -279,7 +279,10 @@ struct bltvqg_engine {
         fold_tab[which].push_back(e);
     }
     void build_fold() {
-        fold_ok = dt == BLT_BF16 && ln_pp == 0 && H % 8 == 0;
+        // (head-padded widths too — hidden 300 = 4 heads of 75 in 80-column slots: the pad columns of every activation, of gamma / beta and
+        // of the consumers' weights are exact zeros, so the row sums, W' = W diag(gamma), s and c are those of the true width; only the divisor
+        // is H_true.  debug key 25 = 2: folded LayerNorms for unpadded widths only — the round-4 state before this, A/B)
+        fold_ok = dt == BLT_BF16 && H % 8 == 0 && (ln_pp == 0 || blt_debug_get(25) != 2);
         stat_slots = (H + 63) / 64;      // one slot per 64 columns of a row
         if (!fold_ok) return;
         const Stack* sts[3] = {&enc, &renc, &dec};
@@ -310,7 +313,8 @@ struct bltvqg_engine {
         g.bias = nullptr;
         const int sr = fold_srow.at(wname);
         g.stat_slots = stat_slots; g.fold_np = parts;
-        g.fold_s = fold_s + sr; g.fold_c = fold_c + sr; g.fold_stat = stat; g.fold_mean = m; g.fold_rstd = r; g.fold_eps = 1e-5f; g.fold_n = (float)H;
+        g.fold_s = fold_s + sr; g.fold_c = fold_c + sr; g.fold_stat = stat; g.fold_mean = m; g.fold_rstd = r; g.fold_eps = 1e-5f;
+        g.fold_n = ln_pp ? (float)(H / ln_pp * ln_pv) : (float)H;      // features the statistics cover (pad columns hold zeros)
     }
     void set_stat(GemmArgs& g, float* stat) { g.out_stat = stat; g.stat_slots = stat_slots; }
     bool use_streams = true;

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) void layernorm_bwd_kernel(const T* __restr
                             float bt[8], xo[8];
                             Vec8<float>::load(beta + c * 8, bt);
 #pragma unroll
-                            for (int e = 0; e < 8; ++e) xo[e] = xh[r][j][e] * g[j][e] + bt[e];
+                            for (int e = 0; e < 8; ++e) xo[e] = ((vm[j] >> e) & 1u) ? xh[r][j][e] * g[j][e] + bt[e] : 0.f;      // (pad columns: zeros, as the forward launch stores them)
                             Vec8<T>::store(xn_out + row * ld + c * 8, xo);
                         }
                         if (out2 != nullptr) {

@@ -39,7 +39,7 @@ const char* bltvqg_last_error_string(void);
 /* tuning switches for A/B benchmarks: key 0 = disable the LDS-DMA GEMM ring (value 1), key 1 = force a GEMM tile (64/128/12864) */
 void bltvqg_debug_set(int key, int value);
 int bltvqg_debug_get(int key);      /* keys 0..31; bench.py echoes every non-zero key in its JSON line.  Round 4: 23 dead-work A/B, 24 LayerNorm-backward
-                                      * forms, 25 = 1 LayerNorm fold off, 27 = 1 per-pixel img_pack, 28 = 1 decode: cross K/V per step, 29 = 1 decode: one
+                                      * forms, 25 = 1 LayerNorm fold off (2: off for head-padded widths only), 27 = 1 per-pixel img_pack, 28 = 1 decode: cross K/V per step, 29 = 1 decode: one
                                       * full decoder pass per step (the round-2 form) */
 /* 1 only in the ablation build (make -C blt-vqg_amd/csrc ablate -> libbltvqg_hip_ablate.so, -DBLT_ABLATE): there debug keys 14 (skip the
  * grouped weight-gradient launches) and 15 (skip the conv stack) exist as TIMING ablations with wrong results.  The shipped library has
